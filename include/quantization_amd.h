@@ -1,0 +1,281 @@
+/*
+ * quantization_amd.h — C ABI of the MI355X-native encode-and-score path.
+ *
+ * This is the drop-in boundary for qdrant/quantization's hot path.  The reference's own
+ * FFI is per (query, vector) PAIR — 7 x86 symbols declared at
+ *   quantization/src/encoded_vectors_u8.rs:476-483    impl_score_{dot,l1}_{avx,sse}
+ *   quantization/src/encoded_vectors_binary.rs:317-324 impl_xor_popcnt_sse_uint{128,64,32}
+ * — far too fine for a GPU (one launch per pair).  The boundary therefore moves up one
+ * level to the Rust methods that call them: one opaque handle per encoded store, with the
+ * methods of `trait EncodedVectors` (quantization/src/encoded_vectors.rs:21-35) plus the
+ * batched form of the caller loop `for i in 0..n { score_point(q, i) }`
+ * (demos/src/ann_benchmark.rs:247-252) as `*_score_all`.  Each entry point cites the
+ * reference interface it replaces.  INTEGRATION.md shows the Rust `extern "C"` block and
+ * the `impl EncodedVectors for ...` a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns a qamd_status.
+ *   - `qamd_mem` says whether a caller buffer is host or device (HBM) memory.  Device
+ *     buffers must belong to the handle's device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls that take
+ *     a stream only ENQUEUE when every buffer is device memory; host buffers make the call
+ *     synchronous.
+ *   - handles own device memory; row bytes handed in stay caller-owned.
+ *   - all score_* / topk calls are thread-safe on a shared handle (no interior mutation),
+ *     matching `&self` in the reference.
+ *   - no CPU fallback: every function fails with QAMD_ERR_DEVICE when no GPU is usable.
+ */
+#ifndef QUANTIZATION_AMD_H
+#define QUANTIZATION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QAMD_API __attribute__((visibility("default")))
+
+/* quantization/src/lib.rs:18-24 EncodingError{IOError,EncodingError,ArgumentsError,Stopped},
+ * plus std::io::Error for save/load (-> QAMD_ERR_IO), the slice-index panic of
+ * encoded_storage.rs:29 (-> QAMD_ERR_OUT_OF_RANGE) and HIP failures. */
+typedef enum {
+    QAMD_OK = 0,
+    QAMD_ERR_IO = 1,
+    QAMD_ERR_ENCODING = 2,
+    QAMD_ERR_ARGUMENTS = 3,
+    QAMD_ERR_STOPPED = 4,
+    QAMD_ERR_OUT_OF_RANGE = 5,
+    QAMD_ERR_DEVICE = 6
+} qamd_status;
+
+/* quantization/src/encoded_vectors.rs:6-11 */
+typedef enum { QAMD_DOT = 0, QAMD_L1 = 1, QAMD_L2 = 2 } qamd_distance;
+
+typedef enum { QAMD_MEM_HOST = 0, QAMD_MEM_DEVICE = 1 } qamd_mem;
+
+/* quantization/src/encoded_vectors.rs:13-19 VectorParameters */
+typedef struct {
+    uint64_t dim;
+    uint64_t count;
+    int32_t distance_type; /* qamd_distance */
+    int32_t invert;        /* bool */
+} qamd_vector_parameters;
+
+/* stop_condition: impl Fn() -> bool (encoded_vectors_u8.rs:39, _binary.rs:169, _pq.rs:62).
+ * Polled between device batches; non-zero => the encode returns QAMD_ERR_STOPPED. */
+typedef int (*qamd_stop_fn)(void *user);
+
+/* Last error text of the calling thread (the String inside EncodingError / io::Error). */
+QAMD_API const char *qamd_last_error(void);
+QAMD_API const char *qamd_version(void);
+/* Number of visible HIP devices (0 => nothing in this library can run). */
+QAMD_API int qamd_device_count(void);
+/* Device used by handles created afterwards on this thread (default 0). */
+QAMD_API qamd_status qamd_set_device(int device);
+
+/* ===================================================================================
+ * Scalar u8 quantizer — quantization/src/encoded_vectors_u8.rs
+ * =================================================================================== */
+typedef struct qamd_u8 qamd_u8;             /* EncodedVectorsU8<TStorage>  (:14-17) */
+typedef struct qamd_u8_query qamd_u8_query; /* EncodedQueryU8              (:19-22) */
+
+/* Metadata (:24-31), serde field order. */
+typedef struct {
+    uint64_t actual_dim;
+    float alpha;
+    float offset;
+    float multiplier;
+    qamd_vector_parameters vector_parameters;
+} qamd_u8_metadata;
+
+/* get_quantized_vector_size (:252-255) and get_actual_dim (:257-259). */
+QAMD_API uint64_t qamd_u8_quantized_vector_size(const qamd_vector_parameters *vp);
+QAMD_API uint64_t qamd_u8_actual_dim(const qamd_vector_parameters *vp);
+
+/* EncodedVectorsU8::encode (:34-140).  data: count*dim f32, row-major (the reference's
+ * `orig_data` iterator flattened).  quantile: NULL = None.  For count > 100 000 the
+ * reference draws a random sample (quantile.rs:31-34); here the sample is the first
+ * 100 000 rows of a fixed-seed permutation — same statistic, not the same bits.
+ * `alpha_offset` non-NULL overrides the interval search with {alpha, offset}
+ * (conditional parity for that sampled case). */
+QAMD_API qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem,
+                                    const qamd_vector_parameters *vp, const float *quantile,
+                                    const float *alpha_offset, qamd_stop_fn stop, void *stop_user,
+                                    void *stream, qamd_u8 **out);
+
+/* Adopt rows already in the reference's storage format — what
+ * EncodedStorage::get_vector_data serves (encoded_storage.rs:27-31): count rows of
+ * [vector_offset f32 ne][actual_dim codes].  Used by load and by callers holding a store
+ * encoded by the reference.  The rows are copied/re-laid-out into library-owned HBM. */
+QAMD_API qamd_status qamd_u8_from_rows(const uint8_t *rows, qamd_mem rows_mem,
+                                       const qamd_u8_metadata *meta, void *stream, qamd_u8 **out);
+
+/* The inverse: write the reference-format row bytes (count * quantized_vector_size). */
+QAMD_API qamd_status qamd_u8_export_rows(const qamd_u8 *h, uint8_t *rows, qamd_mem rows_mem,
+                                         void *stream);
+QAMD_API qamd_status qamd_u8_get_metadata(const qamd_u8 *h, qamd_u8_metadata *out);
+
+/* EncodedVectors::save / load (:263-288): raw row file + serde_json metadata file. */
+QAMD_API qamd_status qamd_u8_save(const qamd_u8 *h, const char *data_path, const char *meta_path);
+QAMD_API qamd_status qamd_u8_load(const char *data_path, const char *meta_path,
+                                  const qamd_vector_parameters *vp, qamd_u8 **out);
+
+/* EncodedVectors::encode_query (:290-329).  *query is created when NULL and re-used
+ * otherwise (no allocation on the hot loop).  qdim is `query.len()`. */
+QAMD_API qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t qdim,
+                                          qamd_mem query_mem, void *stream, qamd_u8_query **query_io);
+/* Inspect an encoded query: offset and the actual_dim code bytes (host buffers). */
+QAMD_API qamd_status qamd_u8_query_read(const qamd_u8_query *q, float *offset, uint8_t *codes,
+                                        uint64_t codes_capacity, uint64_t *codes_len);
+QAMD_API void qamd_u8_query_free(qamd_u8_query *q);
+
+/* EncodedVectors::score_point (:331-384) and score_internal (:386-453). */
+QAMD_API qamd_status qamd_u8_score_point(const qamd_u8 *h, const qamd_u8_query *q, uint32_t i,
+                                         float *out);
+QAMD_API qamd_status qamd_u8_score_internal(const qamd_u8 *h, uint32_t i, uint32_t j, float *out);
+
+/* NEW (batched caller loop, demos/src/ann_benchmark.rs:247-252):
+ * out[i] = score_point(q, i) for i in [0, count). */
+QAMD_API qamd_status qamd_u8_score_all(const qamd_u8 *h, const qamd_u8_query *q, float *out,
+                                       qamd_mem out_mem, void *stream);
+/* Random-access form (demos/benches/encode.rs "score random access"): out[k] = score_point(q, ids[k]). */
+QAMD_API qamd_status qamd_u8_score_ids(const qamd_u8 *h, const qamd_u8_query *q,
+                                       const uint32_t *ids, uint64_t n_ids, qamd_mem ids_mem,
+                                       float *out, qamd_mem out_mem, void *stream);
+/* Fused scan + selection (demos/src/ann_benchmark_data.rs:151-167 keeps the best 30 in a
+ * heap).  largest != 0 keeps the k largest scores, else the k smallest; ties break to the
+ * lower index; results are sorted best-first.  k <= 1024. */
+QAMD_API qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k,
+                                  int largest, uint32_t *out_ids, float *out_scores,
+                                  qamd_mem out_mem, void *stream);
+QAMD_API void qamd_u8_free(qamd_u8 *h);
+
+/* Extension (no reference counterpart): how a pair sum >= 2^24 (only possible for
+ * actual_dim > 1040) becomes f32.  0 (default): exact integer, rounded once — what the
+ * reference's scalar path does (encoded_vectors_u8.rs:158).  1: the 8-lane f32 summation
+ * order of impl_score_dot_avx (quantization/cpp/avx2.c:41-62), bit for bit. */
+QAMD_API qamd_status qamd_u8_set_lane_mode(qamd_u8 *h, int mode);
+
+/* ===================================================================================
+ * Binary quantizer — quantization/src/encoded_vectors_binary.rs
+ * =================================================================================== */
+typedef struct qamd_bin qamd_bin;             /* EncodedVectorsBin<TBitsStoreType,TStorage> (:11-15) */
+typedef struct qamd_bin_query qamd_bin_query; /* EncodedBinVector (:17-19) */
+
+typedef enum { QAMD_BITS_U8 = 0, QAMD_BITS_U128 = 1 } qamd_bits_store; /* BitsStoreType impls :44,:119 */
+
+/* get_quantized_vector_size_from_params (:210-213), bytes per row. */
+QAMD_API uint64_t qamd_bin_quantized_vector_size(const qamd_vector_parameters *vp,
+                                                 qamd_bits_store store);
+/* EncodedVectorsBin::encode (:165-191). */
+QAMD_API qamd_status qamd_bin_encode(const float *data, qamd_mem data_mem,
+                                     const qamd_vector_parameters *vp, qamd_bits_store store,
+                                     qamd_stop_fn stop, void *stop_user, void *stream,
+                                     qamd_bin **out);
+QAMD_API qamd_status qamd_bin_from_rows(const uint8_t *rows, qamd_mem rows_mem,
+                                        const qamd_vector_parameters *vp, qamd_bits_store store,
+                                        void *stream, qamd_bin **out);
+QAMD_API qamd_status qamd_bin_export_rows(const qamd_bin *h, uint8_t *rows, qamd_mem rows_mem,
+                                          void *stream);
+QAMD_API qamd_status qamd_bin_save(const qamd_bin *h, const char *data_path, const char *meta_path);
+QAMD_API qamd_status qamd_bin_load(const char *data_path, const char *meta_path,
+                                   const qamd_vector_parameters *vp, qamd_bits_store store,
+                                   qamd_bin **out);
+/* encode_query (:288-291). */
+QAMD_API qamd_status qamd_bin_encode_query(const qamd_bin *h, const float *query, uint64_t qdim,
+                                           qamd_mem query_mem, void *stream,
+                                           qamd_bin_query **query_io);
+QAMD_API qamd_status qamd_bin_query_read(const qamd_bin_query *q, uint8_t *bits,
+                                         uint64_t capacity, uint64_t *len);
+QAMD_API void qamd_bin_query_free(qamd_bin_query *q);
+/* score_point (:293-300), score_internal (:302-314). */
+QAMD_API qamd_status qamd_bin_score_point(const qamd_bin *h, const qamd_bin_query *q, uint32_t i,
+                                          float *out);
+QAMD_API qamd_status qamd_bin_score_internal(const qamd_bin *h, uint32_t i, uint32_t j, float *out);
+QAMD_API qamd_status qamd_bin_score_all(const qamd_bin *h, const qamd_bin_query *q, float *out,
+                                        qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_bin_score_ids(const qamd_bin *h, const qamd_bin_query *q,
+                                        const uint32_t *ids, uint64_t n_ids, qamd_mem ids_mem,
+                                        float *out, qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k,
+                                   int largest, uint32_t *out_ids, float *out_scores,
+                                   qamd_mem out_mem, void *stream);
+QAMD_API void qamd_bin_free(qamd_bin *h);
+
+/* ===================================================================================
+ * Product quantizer — quantization/src/encoded_vectors_pq.rs
+ * =================================================================================== */
+typedef struct qamd_pq qamd_pq;             /* EncodedVectorsPQ<TStorage> (:27-30) */
+typedef struct qamd_pq_query qamd_pq_query; /* EncodedQueryPQ{lut}        (:35-37) */
+
+#define QAMD_PQ_CENTROIDS 256 /* CENTROIDS_COUNT (:25) */
+
+/* get_quantized_vector_size (:109-114) == number of chunks. */
+QAMD_API uint64_t qamd_pq_quantized_vector_size(const qamd_vector_parameters *vp,
+                                                uint64_t chunk_size);
+/* EncodedVectorsPQ::encode (:56-107).  centroids: NULL => find_centroids (:278-342)
+ * runs (count <= 256: the vectors themselves, exactly as :290-297; otherwise k-means on a
+ * 10 000-row sample, kmeans.rs — its values are "parity unpinned", the reference's own
+ * are random).  Non-NULL: 256 x dim f32, centroid-major (Metadata.centroids, :39-44),
+ * host memory; encode_storage (:136-226) then runs with them (bit-exact path). */
+QAMD_API qamd_status qamd_pq_encode(const float *data, qamd_mem data_mem,
+                                    const qamd_vector_parameters *vp, uint64_t chunk_size,
+                                    const float *centroids, uint32_t max_kmeans_threads,
+                                    qamd_stop_fn stop, void *stop_user, void *stream,
+                                    qamd_pq **out);
+QAMD_API qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem,
+                                       const qamd_vector_parameters *vp, uint64_t chunk_size,
+                                       const float *centroids, void *stream, qamd_pq **out);
+QAMD_API qamd_status qamd_pq_export_rows(const qamd_pq *h, uint8_t *rows, qamd_mem rows_mem,
+                                         void *stream);
+/* Metadata.centroids (256 x dim f32, host). */
+QAMD_API qamd_status qamd_pq_get_centroids(const qamd_pq *h, float *centroids);
+QAMD_API qamd_status qamd_pq_save(const qamd_pq *h, const char *data_path, const char *meta_path);
+QAMD_API qamd_status qamd_pq_load(const char *data_path, const char *meta_path,
+                                  const qamd_vector_parameters *vp, qamd_pq **out);
+/* encode_query (:525-547): builds the chunk-major LUT. */
+QAMD_API qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t qdim,
+                                          qamd_mem query_mem, void *stream,
+                                          qamd_pq_query **query_io);
+QAMD_API qamd_status qamd_pq_query_read(const qamd_pq_query *q, float *lut, uint64_t capacity,
+                                        uint64_t *len);
+QAMD_API void qamd_pq_query_free(qamd_pq_query *q);
+/* score_point (:549-561 -> score_point_sse :405-440 summation order), score_internal (:566-593). */
+QAMD_API qamd_status qamd_pq_score_point(const qamd_pq *h, const qamd_pq_query *q, uint32_t i,
+                                         float *out);
+QAMD_API qamd_status qamd_pq_score_internal(const qamd_pq *h, uint32_t i, uint32_t j, float *out);
+QAMD_API qamd_status qamd_pq_score_all(const qamd_pq *h, const qamd_pq_query *q, float *out,
+                                       qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_pq_score_ids(const qamd_pq *h, const qamd_pq_query *q,
+                                       const uint32_t *ids, uint64_t n_ids, qamd_mem ids_mem,
+                                       float *out, qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k,
+                                  int largest, uint32_t *out_ids, float *out_scores,
+                                  qamd_mem out_mem, void *stream);
+QAMD_API void qamd_pq_free(qamd_pq *h);
+
+/* ===================================================================================
+ * Selection over an existing score array (device memory), e.g. after a multi-GPU gather.
+ * Same ordering contract as the *_topk entry points.
+ * =================================================================================== */
+QAMD_API qamd_status qamd_topk_scores(const float *scores_dev, uint64_t n, uint32_t k, int largest,
+                                      uint32_t *out_ids, float *out_scores, qamd_mem out_mem,
+                                      void *stream);
+
+/* ===================================================================================
+ * Measurement helpers (bench.py): HIP events on the caller's stream, and a plain
+ * streaming-read kernel that measures the box's achievable HBM read ceiling.
+ * =================================================================================== */
+/* Sums `bytes` of device memory with 16-byte loads; writes one u32 per workgroup to
+ * scratch (>= 64 KiB).  Used only to calibrate the roofline ceiling. */
+QAMD_API qamd_status qamd_stream_read(const void *dev_ptr, uint64_t bytes, void *scratch,
+                                      void *stream);
+/* Per-row store traffic of the u8 scan kernel: bytes read per scored row (codes + offset). */
+QAMD_API uint64_t qamd_u8_scan_bytes_per_row(const qamd_u8 *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUANTIZATION_AMD_H */

@@ -1,0 +1,92 @@
+"""Scoring methods shared by the three quantizers: the C ABI gives them identical shapes
+(`qamd_{u8,bin,pq}_score_*`), as `trait EncodedVectors` does in the reference
+(quantization/src/encoded_vectors.rs:21-35)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .encoded_vectors import check, in_buf, out_buf, stream_ptr
+
+
+class EncodedQueryBase:
+    _prefix = ""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            getattr(_lib.lib(), f"qamd_{self._prefix}_query_free")(self._h)
+            self._h = None
+
+
+class EncodedVectorsBase:
+    _prefix = ""
+    _query_cls = EncodedQueryBase
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+
+    def _fn(self, name):
+        return getattr(_lib.lib(), f"qamd_{self._prefix}_{name}")
+
+    @property
+    def count(self) -> int:
+        return self.vector_parameters.count
+
+    def encode_query(self, query, reuse=None, stream=None):
+        """EncodedVectors::encode_query.  `reuse` recycles an encoded-query object (no
+        allocation in a query loop)."""
+        buf = in_buf(query, np.float32)
+        n = int(np.prod(tuple(query.shape))) if hasattr(query, "shape") else len(query)
+        h = reuse._h if reuse is not None else C.c_void_p()
+        check(self._fn("encode_query")(self._h, buf.ptr, n, buf.mem, stream_ptr(stream), C.byref(h)))
+        return reuse if reuse is not None else self._query_cls(h)
+
+    def score_point(self, query, i: int) -> np.float32:
+        """EncodedVectors::score_point — one (query, row) pair.  A kernel launch per call:
+        use score_all / score_ids / topk on the hot path."""
+        out = C.c_float()
+        check(self._fn("score_point")(self._h, query._h, int(i), C.byref(out)))
+        return np.float32(out.value)
+
+    def score_internal(self, i: int, j: int) -> np.float32:
+        """EncodedVectors::score_internal — rows i and j of the store."""
+        out = C.c_float()
+        check(self._fn("score_internal")(self._h, int(i), int(j), C.byref(out)))
+        return np.float32(out.value)
+
+    def score_all(self, query, out=None, stream=None):
+        """scores[i] = score_point(query, i) for every row: the batched form of the caller
+        loop in demos/src/ann_benchmark.rs:247-252."""
+        buf, ret = out_buf(out, self.count, np.float32)
+        check(self._fn("score_all")(self._h, query._h, buf.ptr, buf.mem, stream_ptr(stream)))
+        return ret
+
+    def score_ids(self, query, ids, out=None, stream=None):
+        """scores[k] = score_point(query, ids[k]) (random access, demos/benches/encode.rs)."""
+        ib = in_buf(ids, np.uint32)
+        n = int(ids.numel()) if hasattr(ids, "numel") else len(ids)
+        buf, ret = out_buf(out, n, np.float32)
+        check(self._fn("score_ids")(self._h, query._h, ib.ptr, n, ib.mem, buf.ptr, buf.mem,
+                                    stream_ptr(stream)))
+        return ret
+
+    def topk(self, query, k: int, largest: bool = True, out_ids=None, out_scores=None, stream=None):
+        """Best-k rows of the scan (demos/src/ann_benchmark_data.rs:151-167 keeps 30 in a heap),
+        sorted best-first; ties go to the lower row id.  Returns (ids, scores)."""
+        ib, ids = out_buf(out_ids, k, np.uint32)
+        sb, sc = out_buf(out_scores, k, np.float32)
+        if ib.mem != sb.mem:
+            raise ValueError("out_ids and out_scores must both be host or both be device buffers")
+        check(self._fn("topk")(self._h, query._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem,
+                               stream_ptr(stream)))
+        return ids, sc
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._fn("free")(self._h)
+            self._h = None

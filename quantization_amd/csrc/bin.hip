@@ -1,0 +1,510 @@
+// Binary quantizer on MI355X (gfx950): sign-bit packing and the XOR+popcount scan.
+//
+// Host side mirrors EncodedVectorsBin (quantization/src/encoded_vectors_binary.rs); the scan
+// replaces impl_xor_popcnt_sse_uint{128,64,32} (quantization/cpp/sse.c:49-106), which the
+// reference calls once per (query, row) pair.
+//
+// HBM layout: rows keep the reference's byte layout (bit i of a vector = byte i/8, bit i%8,
+// identical for the u8 and u128 store types on little-endian, :193-208).  Device stride `ds`
+// is the reference's row size for rows >= 8 bytes (always a multiple of 8; of 16 above 128
+// dims, e.g. 128 B at dim 1024) and 4 bytes for the tiny rows (dim <= 32, 0..4 bytes).  Pad
+// bits are zero in rows and query alike, so they never reach the popcount (:36-37).
+//
+// Scan mapping: as the u8 scan — G lanes read one row in 16-byte pieces, one wave-load covers
+// 64/G consecutive rows — with v_xor + v_bcnt_u32_b32 instead of v_dot4.  All integer, exact;
+// the f32 metric (:219-253) is exact for dim < 2^23.
+#include <algorithm>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "topk.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace qamd;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint64_t kRowPad = 1024;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
+    u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+__device__ __forceinline__ uint32_t xpop16(const uint4 &a, const uint4 &b, uint32_t acc) {
+    acc += __popc(a.x ^ b.x);
+    acc += __popc(a.y ^ b.y);
+    acc += __popc(a.z ^ b.z);
+    acc += __popc(a.w ^ b.w);
+    return acc;
+}
+
+template <int G> __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// encoded_vectors_binary.rs:237-252 calculate_metric
+__device__ __forceinline__ float metric(uint32_t x, float dim_f, int is_dot, int invert) {
+    const float xor_product = (float)x;
+    const float zeros_count = dim_f - xor_product;
+    const bool zx = (is_dot != 0) != (invert != 0);  // Dot,!invert and L1/L2,invert -> zeros - xor
+    return zx ? zeros_count - xor_product : xor_product - zeros_count;
+}
+
+// Rows of ds >= 16 bytes (row_chunks = ds/16).
+template <int G, int ITERS, int UNROLL, bool EXACT>
+__global__ __launch_bounds__(kBlock) void bin_scan_kernel(const uint4 *__restrict__ rows,
+                                                         const uint4 *__restrict__ qbits, float dim_f,
+                                                         int is_dot, int invert, uint32_t n_rows,
+                                                         uint32_t row_chunks, float *__restrict__ out) {
+    constexpr int RW = 64 / G;
+    constexpr int TILE = RW * UNROLL;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+    uint4 q[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        uint32_t c = sub + it * G;
+        q[it] = c < row_chunks ? qbits[c] : make_uint4(0, 0, 0, 0);
+    }
+    for (uint64_t base = (uint64_t)wave * TILE; base < n_rows; base += (uint64_t)n_waves * TILE) {
+        uint4 v[UNROLL][ITERS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint64_t row = base + u * RW + rslot;
+            const uint4 *p = rows + row * row_chunks;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t c = sub + it * G;
+                if (EXACT) {
+                    v[u][it] = ld_nt(p + c);
+                } else {  // masked lane: read the row's last chunk, xor against itself -> 0 bits
+                    const bool in = c < row_chunks;
+                    uint4 t = ld_nt(p + (in ? c : row_chunks - 1));
+                    v[u][it] = in ? t : q[it];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) acc = xpop16(v[u][it], q[it], acc);
+            acc = group_sum<G>(acc);
+            const uint64_t row = base + u * RW + rslot;
+            if (sub == 0 && row < n_rows) out[row] = metric(acc, dim_f, is_dot, invert);
+        }
+    }
+}
+
+// Any row size, dword granularity: used for tiny rows (ds 4 or 8), very long rows and the
+// random-access entry points.  ids == nullptr scans rows [0, n).
+__global__ __launch_bounds__(kBlock) void bin_words_kernel(const uint32_t *__restrict__ rows,
+                                                          const uint32_t *qbits, float dim_f, int is_dot,
+                                                          int invert, const uint32_t *__restrict__ ids,
+                                                          uint64_t n, uint32_t n_rows, uint32_t row_words,
+                                                          float *__restrict__ out) {
+    constexpr int G = 16, RW = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    for (uint64_t base = wave * RW; base < n; base += n_waves * RW) {
+        const uint64_t k = base + rslot;
+        const uint32_t row = k < n ? (ids ? ids[k] : (uint32_t)k) : 0xFFFFFFFFu;
+        const bool ok = row < n_rows;
+        uint32_t acc = 0;
+        if (ok) {
+            const uint32_t *p = rows + (uint64_t)row * row_words;
+            for (uint32_t w = sub; w < row_words; w += G) acc += __popc(p[w] ^ qbits[w]);
+        }
+        acc = group_sum<G>(acc);
+        if (sub == 0 && k < n) out[k] = ok ? metric(acc, dim_f, is_dot, invert) : __builtin_nanf("");
+    }
+}
+
+// encode_vector (:193-208): one wave per row, 64 elements per ballot; lane (step % 64) keeps
+// the ballot of `step`, so after <= 64 steps every lane owns 8 output bytes (coalesced store).
+__global__ __launch_bounds__(kBlock) void bin_encode_kernel(const float *__restrict__ data, uint64_t n_rows,
+                                                           uint32_t dim, uint32_t row_words,
+                                                           uint32_t *__restrict__ rows, uint64_t row0) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const uint32_t steps = (dim + 63) / 64;
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const float *src = data + r * dim;
+        uint32_t *dst = rows + (row0 + r) * row_words;
+        unsigned long long mine = 0;
+        for (uint32_t st = 0; st < steps; st++) {
+            const uint32_t j = st * 64 + lane;
+            const float v = j < dim ? src[j] : 0.0f;
+            const unsigned long long b = __ballot(v > 0.0f);
+            if ((st & 63u) == (uint32_t)lane) mine = b;
+            if ((st & 63u) == 63u || st + 1 == steps) {
+                const uint32_t w = ((st & ~63u) + lane) * 2;  // this lane's first dword
+                if (w < row_words) dst[w] = (uint32_t)mine;
+                if (w + 1 < row_words) dst[w + 1] = (uint32_t)(mine >> 32);
+                mine = 0;
+            }
+        }
+    }
+}
+
+int grid_for(uint64_t work_items, uint64_t per_block, int blocks_per_cu) {
+    uint64_t want = (work_items + per_block - 1) / per_block;
+    uint64_t cap = (uint64_t)device_info().cu_count * blocks_per_cu;
+    if (want < 1) want = 1;
+    return (int)(want > cap ? cap : want);
+}
+
+// get_storage_size * size_of (:99-116 u8, :152-159 u128, :210-213)
+uint64_t row_bytes_of(uint64_t dim, int store) {
+    if (store == QAMD_BITS_U128) return (dim / 128 + (dim % 128 != 0)) * 16;
+    const uint64_t bytes_count = dim > 128 ? 16 : dim > 64 ? 8 : dim > 32 ? 4 : 1;
+    const uint64_t bits = 8 * bytes_count;
+    return (dim / bits + (dim % bits != 0)) * bytes_count;
+}
+
+uint64_t device_stride_of(uint64_t nb) { return nb >= 8 ? nb : 4; }
+
+}  // namespace
+
+struct qamd_bin {
+    int device = 0;
+    qamd_vector_parameters vp{};
+    int store = 0;
+    uint64_t count = 0;
+    uint64_t nb = 0;  // reference row bytes
+    uint64_t ds = 0;  // device row stride (bytes)
+    DevBuf rows;      // [padded_rows][ds]
+};
+
+struct qamd_bin_query {
+    int device = 0;
+    uint64_t nb = 0, ds = 0;
+    DevBuf buf;  // ds bytes (+ padding)
+};
+
+namespace {
+
+qamd_status alloc_store(qamd_bin *h) {
+    h->nb = row_bytes_of(h->vp.dim, h->store);
+    h->ds = device_stride_of(h->nb);
+    const uint64_t padded = round_up(h->count, kRowPad) + kRowPad;
+    return h->rows.alloc(padded * h->ds, true);
+}
+
+template <int G, int ITERS, int UNROLL>
+void launch_bin(const qamd_bin *h, const uint4 *qb, float *out, hipStream_t s) {
+    constexpr int TILE = (64 / G) * UNROLL;
+    const uint32_t rc = (uint32_t)(h->ds / 16);
+    const int is_dot = h->vp.distance_type == QAMD_DOT;
+    int grid = grid_for((h->count + TILE - 1) / TILE, kBlock / 64, 8);
+    if (rc == (uint32_t)(G * ITERS))
+        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, true>), dim3(grid), dim3(kBlock), 0, s,
+                           h->rows.as<uint4>(), qb, (float)h->vp.dim, is_dot, h->vp.invert, (uint32_t)h->count,
+                           rc, out);
+    else
+        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, false>), dim3(grid), dim3(kBlock), 0, s,
+                           h->rows.as<uint4>(), qb, (float)h->vp.dim, is_dot, h->vp.invert, (uint32_t)h->count,
+                           rc, out);
+}
+
+qamd_status words_launch(const qamd_bin *h, const uint32_t *qbits, const uint32_t *ids_dev, uint64_t n,
+                         float *out_dev, hipStream_t s) {
+    if (n == 0) return QAMD_OK;
+    int grid = grid_for((n + 3) / 4, kBlock / 64, 8);
+    hipLaunchKernelGGL(bin_words_kernel, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint32_t>(), qbits,
+                       (float)h->vp.dim, (int)(h->vp.distance_type == QAMD_DOT), h->vp.invert, ids_dev, n,
+                       (uint32_t)h->count, (uint32_t)(h->ds / 4), out_dev);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev, hipStream_t s) {
+    if (h->count == 0) return QAMD_OK;
+    const uint32_t rc = (uint32_t)(h->ds / 16);
+    if (h->ds % 16 != 0 || rc > 64)
+        return words_launch(h, q->buf.as<uint32_t>(), nullptr, h->count, out_dev, s);
+    const uint4 *qb = q->buf.as<uint4>();
+    if (rc == 1) launch_bin<1, 1, 4>(h, qb, out_dev, s);
+    else if (rc == 2) launch_bin<2, 1, 4>(h, qb, out_dev, s);
+    else if (rc <= 4) launch_bin<4, 1, 8>(h, qb, out_dev, s);
+    else if (rc <= 8) launch_bin<8, 1, 8>(h, qb, out_dev, s);
+    else if (rc <= 16) launch_bin<16, 1, 8>(h, qb, out_dev, s);
+    else if (rc <= 32) launch_bin<16, 2, 4>(h, qb, out_dev, s);
+    else if (rc <= 48) launch_bin<16, 3, 4>(h, qb, out_dev, s);
+    else launch_bin<16, 4, 2>(h, qb, out_dev, s);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+qamd_status check_query(const qamd_bin *h, const qamd_bin_query *q) {
+    if (!h || !q) return fail(QAMD_ERR_ARGUMENTS, "null handle or query");
+    if (q->nb != h->nb) return fail(QAMD_ERR_ARGUMENTS, "query has %llu bytes, rows have %llu",
+                                    (unsigned long long)q->nb, (unsigned long long)h->nb);
+    return QAMD_OK;
+}
+
+// Host rows at stride nb -> device stride ds (differs only for the tiny rows).
+qamd_status upload_rows(qamd_bin *h, const uint8_t *rows, qamd_mem mem, hipStream_t s) {
+    if (h->count == 0) return QAMD_OK;
+    if (h->nb == h->ds) return copy_in(h->rows.ptr, rows, mem, h->count * h->nb, s);
+    std::vector<uint8_t> host(h->count * h->nb), wide(h->count * h->ds, 0);
+    if (h->nb) {
+        if (mem == QAMD_MEM_DEVICE) QAMD_TRY(copy_out(host.data(), QAMD_MEM_HOST, rows, host.size(), s));
+        else memcpy(host.data(), rows, host.size());
+    }
+    for (uint64_t r = 0; r < h->count; r++) memcpy(&wide[r * h->ds], &host[r * h->nb], h->nb);
+    return copy_in(h->rows.ptr, wide.data(), QAMD_MEM_HOST, wide.size(), s);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t qamd_bin_quantized_vector_size(const qamd_vector_parameters *vp, qamd_bits_store store) {
+    return row_bytes_of(vp->dim, store);
+}
+
+qamd_status qamd_bin_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                            qamd_bits_store store, qamd_stop_fn stop, void *stop_user, void *stream,
+                            qamd_bin **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
+    QAMD_TRY(ensure_device(current_device()));
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<qamd_bin> h(new qamd_bin);
+    h->device = current_device();
+    h->vp = *vp;
+    h->store = store;
+    h->count = vp->count;
+    QAMD_TRY(alloc_store(h.get()));
+    const uint64_t dim = vp->dim, count = vp->count;
+    if (count && dim) {
+        const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, (256ull << 20) / (dim * 4)));
+        DevBuf stage;
+        if (data_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(batch_rows * dim * 4));
+        for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
+            if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :174-176
+            const uint64_t nr = std::min(batch_rows, count - r0);
+            const float *src = data + r0 * dim;
+            if (data_mem == QAMD_MEM_HOST) {
+                QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
+                src = stage.as<float>();
+            }
+            int grid = grid_for(nr, kBlock / 64, 8);
+            hipLaunchKernelGGL(bin_encode_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
+                               (uint32_t)(h->ds / 4), h->rows.as<uint32_t>(), r0);
+            QAMD_HIP(hipGetLastError());
+            if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
+        }
+        QAMD_HIP(hipStreamSynchronize(s));
+    } else if (stop && count && stop(stop_user)) {
+        return fail(QAMD_ERR_STOPPED, "Stopped");
+    }
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_vector_parameters *vp,
+                               qamd_bits_store store, void *stream, qamd_bin **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    QAMD_TRY(ensure_device(current_device()));
+    std::unique_ptr<qamd_bin> h(new qamd_bin);
+    h->device = current_device();
+    h->vp = *vp;
+    h->store = store;
+    h->count = vp->count;
+    QAMD_TRY(alloc_store(h.get()));
+    if (h->count && h->nb && !rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
+    QAMD_TRY(upload_rows(h.get(), rows, rows_mem, as_stream(stream)));
+    QAMD_HIP(hipStreamSynchronize(as_stream(stream)));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_export_rows(const qamd_bin *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (h->count == 0 || h->nb == 0) return QAMD_OK;
+    if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    if (h->nb == h->ds) return copy_out(rows, rows_mem, h->rows.ptr, h->count * h->nb, s);
+    std::vector<uint8_t> wide(h->count * h->ds), host(h->count * h->nb);
+    QAMD_TRY(copy_out(wide.data(), QAMD_MEM_HOST, h->rows.ptr, wide.size(), s));
+    for (uint64_t r = 0; r < h->count; r++) memcpy(&host[r * h->nb], &wide[r * h->ds], h->nb);
+    if (rows_mem == QAMD_MEM_HOST) memcpy(rows, host.data(), host.size());
+    else QAMD_TRY(copy_in(rows, host.data(), QAMD_MEM_HOST, host.size(), s));
+    return QAMD_OK;
+}
+
+// save/load (:260-286): Metadata{vector_parameters} as serde_json + raw row bytes.
+qamd_status qamd_bin_save(const qamd_bin *h, const char *data_path, const char *meta_path) {
+    if (!h || !data_path || !meta_path) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::string js = "{\"vector_parameters\":" + vector_parameters_json(h->vp) + "}";
+    make_parent_dirs(meta_path);
+    if (!write_file(meta_path, js.data(), js.size())) return fail(QAMD_ERR_IO, "cannot write %s", meta_path);
+    std::vector<uint8_t> rows(h->count * h->nb);
+    QAMD_TRY(qamd_bin_export_rows(h, rows.data(), QAMD_MEM_HOST, nullptr));
+    make_parent_dirs(data_path);
+    if (!write_file(data_path, rows.data(), rows.size())) return fail(QAMD_ERR_IO, "cannot write %s", data_path);
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_load(const char *data_path, const char *meta_path, const qamd_vector_parameters *vp,
+                          qamd_bits_store store, qamd_bin **out) {
+    if (!data_path || !meta_path || !vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::string js;
+    if (!read_file(meta_path, js)) return fail(QAMD_ERR_IO, "cannot read %s", meta_path);
+    qamd_vector_parameters file_vp{};
+    if (!parse_vector_parameters(js, file_vp)) return fail(QAMD_ERR_IO, "malformed metadata in %s", meta_path);
+    std::string bytes;
+    if (!read_file(data_path, bytes)) return fail(QAMD_ERR_IO, "cannot read %s", data_path);
+    const uint64_t expected = row_bytes_of(vp->dim, store) * vp->count;  // :277-279
+    if (bytes.size() != expected)
+        return fail(QAMD_ERR_IO, "Loaded storage size %zu is not equal to expected size %llu", bytes.size(),
+                    (unsigned long long)expected);
+    qamd_vector_parameters eff = file_vp;  // metadata rules the metric, the caller's params the sizes
+    eff.dim = vp->dim;
+    eff.count = vp->count;
+    return qamd_bin_from_rows(reinterpret_cast<const uint8_t *>(bytes.data()), QAMD_MEM_HOST, &eff, store, nullptr,
+                              out);
+}
+
+qamd_status qamd_bin_encode_query(const qamd_bin *h, const float *query, uint64_t qdim, qamd_mem query_mem,
+                                  void *stream, qamd_bin_query **query_io) {
+    if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    const uint64_t nb = row_bytes_of(qdim, h->store), ds = device_stride_of(nb);
+    qamd_bin_query *q = *query_io;
+    std::unique_ptr<qamd_bin_query> fresh;
+    if (!q) {
+        fresh.reset(new qamd_bin_query);
+        q = fresh.get();
+        q->device = h->device;
+    }
+    if (q->ds != ds || !q->buf.ptr) {
+        QAMD_TRY(q->buf.alloc(round_up(ds, 16) + 16, true));
+        q->nb = nb;
+        q->ds = ds;
+    }
+    if (query_mem == QAMD_MEM_DEVICE) {
+        if (qdim) {
+            hipLaunchKernelGGL(bin_encode_kernel, dim3(1), dim3(kBlock), 0, s, query, (uint64_t)1, (uint32_t)qdim,
+                               (uint32_t)(ds / 4), q->buf.as<uint32_t>(), (uint64_t)0);
+            QAMD_HIP(hipGetLastError());
+        }
+    } else {
+        std::vector<uint8_t> bits(ds, 0);  // :193-208
+        for (uint64_t i = 0; i < qdim; i++)
+            if (query[i] > 0.0f) bits[i / 8] |= (uint8_t)(1u << (i % 8));
+        QAMD_TRY(copy_in(q->buf.ptr, bits.data(), QAMD_MEM_HOST, ds, s));
+    }
+    if (fresh) *query_io = fresh.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_query_read(const qamd_bin_query *q, uint8_t *bits, uint64_t capacity, uint64_t *len) {
+    if (!q) return fail(QAMD_ERR_ARGUMENTS, "null query");
+    if (len) *len = q->nb;
+    if (bits) {
+        if (capacity < q->nb) return fail(QAMD_ERR_ARGUMENTS, "bits buffer too small");
+        QAMD_TRY(ensure_device(q->device));
+        QAMD_TRY(copy_out(bits, QAMD_MEM_HOST, q->buf.ptr, q->nb, nullptr));
+    }
+    return QAMD_OK;
+}
+
+void qamd_bin_query_free(qamd_bin_query *q) { delete q; }
+
+qamd_status qamd_bin_score_all(const qamd_bin *h, const qamd_bin_query *q, float *out, qamd_mem out_mem,
+                               void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (h->count == 0) return QAMD_OK;
+    if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    if (out_mem == QAMD_MEM_DEVICE) return scan_into(h, q, out, s);
+    DevBuf tmp;
+    QAMD_TRY(tmp.alloc(h->count * 4));
+    QAMD_TRY(scan_into(h, q, tmp.as<float>(), s));
+    return copy_out(out, QAMD_MEM_HOST, tmp.ptr, h->count * 4, s);
+}
+
+qamd_status qamd_bin_score_ids(const qamd_bin *h, const qamd_bin_query *q, const uint32_t *ids, uint64_t n_ids,
+                               qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (n_ids == 0) return QAMD_OK;
+    if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    DevBuf ids_tmp, out_tmp;
+    const uint32_t *ids_dev = ids;
+    if (ids_mem == QAMD_MEM_HOST) {
+        for (uint64_t k = 0; k < n_ids; k++)
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+        QAMD_TRY(ids_tmp.alloc(n_ids * 4));
+        QAMD_TRY(copy_in(ids_tmp.ptr, ids, QAMD_MEM_HOST, n_ids * 4, s));
+        ids_dev = ids_tmp.as<uint32_t>();
+    }
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(out_tmp.alloc(n_ids * 4));
+        out_dev = out_tmp.as<float>();
+    }
+    QAMD_TRY(words_launch(h, q->buf.as<uint32_t>(), ids_dev, n_ids, out_dev, s));
+    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, n_ids * 4, s));
+    else if (ids_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_score_point(const qamd_bin *h, const qamd_bin_query *q, uint32_t i, float *out) {
+    return qamd_bin_score_ids(h, q, &i, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
+}
+
+qamd_status qamd_bin_score_internal(const qamd_bin *h, uint32_t i, uint32_t j, float *out) {
+    if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (i >= h->count || j >= h->count)
+        return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
+    QAMD_TRY(ensure_device(h->device));
+    DevBuf tmp;
+    QAMD_TRY(tmp.alloc(16));
+    QAMD_TRY(copy_in(tmp.ptr, &j, QAMD_MEM_HOST, 4, nullptr));
+    const uint32_t *qrow = h->rows.as<uint32_t>() + (uint64_t)i * (h->ds / 4);
+    QAMD_TRY(words_launch(h, qrow, tmp.as<uint32_t>(), 1, tmp.as<float>() + 1, nullptr));
+    return copy_out(out, QAMD_MEM_HOST, tmp.as<float>() + 1, 4, nullptr);
+}
+
+qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k, int largest, uint32_t *out_ids,
+                          float *out_scores, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (k == 0) return QAMD_OK;
+    if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    float *scores = nullptr;
+    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+    qamd_status st = scan_into(h, q, scores, s);
+    if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
+    (void)hipFreeAsync(scores, s);
+    return st;
+}
+
+void qamd_bin_free(qamd_bin *h) { delete h; }
+
+}  // extern "C"

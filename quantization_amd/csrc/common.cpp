@@ -1,0 +1,240 @@
+// Host-side plumbing shared by the three quantizers (see common.hpp).
+#include "common.hpp"
+
+#include <sys/stat.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <mutex>
+
+namespace qamd {
+
+static thread_local std::string g_last_error;
+static thread_local int g_device = 0;
+
+std::string &last_error() { return g_last_error; }
+
+qamd_status fail(qamd_status st, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return st;
+}
+
+int current_device() { return g_device; }
+
+qamd_status ensure_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(QAMD_ERR_DEVICE, "no HIP device is visible (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(QAMD_ERR_ARGUMENTS, "device %d out of range (have %d)", device, n);
+    QAMD_HIP(hipSetDevice(device));
+    return QAMD_OK;
+}
+
+qamd_status DevBuf::alloc(size_t n, bool zero) {
+    release();
+    if (n == 0) n = 16;  // keep a valid pointer for empty stores
+    QAMD_HIP(hipMalloc(&ptr, n));
+    bytes = n;
+    if (zero) QAMD_HIP(hipMemset(ptr, 0, n));
+    return QAMD_OK;
+}
+
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+qamd_status copy_in(void *dev_dst, const void *src, qamd_mem src_mem, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return QAMD_OK;
+    if (src_mem == QAMD_MEM_DEVICE) {
+        QAMD_HIP(hipMemcpyAsync(dev_dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    } else {
+        QAMD_HIP(hipMemcpyAsync(dev_dst, src, bytes, hipMemcpyHostToDevice, s));
+        QAMD_HIP(hipStreamSynchronize(s));
+    }
+    return QAMD_OK;
+}
+
+qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return QAMD_OK;
+    if (dst_mem == QAMD_MEM_DEVICE) {
+        QAMD_HIP(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToDevice, s));
+    } else {
+        QAMD_HIP(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+        QAMD_HIP(hipStreamSynchronize(s));
+    }
+    return QAMD_OK;
+}
+
+const DeviceInfo &device_info() {
+    static DeviceInfo info;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        hipDeviceProp_t p;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
+            p.multiProcessorCount > 0)
+            info.cu_count = p.multiProcessorCount;
+    });
+    return info;
+}
+
+// ---------------------------------------------------------------------------------- JSON
+std::string json_f32(float v) {
+    if (!std::isfinite(v)) return "null";  // serde_json writes null for NaN/inf
+    char buf[64];
+    for (int p = 1; p <= 9; p++) {
+        snprintf(buf, sizeof buf, "%.*g", p, (double)v);
+        if (strtof(buf, nullptr) == v) break;
+    }
+    std::string s(buf);
+    // serde_json (ryu) always prints a fraction or exponent for floats: 1 -> 1.0
+    if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
+    return s;
+}
+
+bool read_file(const char *path, std::string &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    std::streamoff n = f.tellg();
+    f.seekg(0, std::ios::beg);
+    out.resize((size_t)n);
+    if (n > 0) f.read(&out[0], n);
+    return bool(f) || f.eof();
+}
+
+bool write_file(const char *path, const void *data, size_t bytes) {
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f) return false;
+    if (bytes) f.write(static_cast<const char *>(data), (std::streamsize)bytes);
+    f.flush();
+    return bool(f);
+}
+
+void make_parent_dirs(const char *path) {
+    std::string p(path);
+    size_t pos = p.find_last_of('/');
+    if (pos == std::string::npos || pos == 0) return;
+    std::string dir = p.substr(0, pos);
+    for (size_t i = 1; i <= dir.size(); i++) {
+        if (i == dir.size() || dir[i] == '/') {
+            std::string sub = dir.substr(0, i);
+            if (mkdir(sub.c_str(), 0777) != 0 && errno != EEXIST) return;
+        }
+    }
+}
+
+static size_t json_value_pos(const std::string &s, const char *key) {
+    std::string k = std::string("\"") + key + "\"";
+    size_t p = s.find(k);
+    if (p == std::string::npos) return p;
+    p = s.find(':', p + k.size());
+    if (p == std::string::npos) return p;
+    p++;
+    while (p < s.size() && (s[p] == ' ' || s[p] == '\n' || s[p] == '\t' || s[p] == '\r')) p++;
+    return p;
+}
+
+bool json_find_number(const std::string &s, const char *key, double &out) {
+    size_t p = json_value_pos(s, key);
+    if (p == std::string::npos) return false;
+    if (s.compare(p, 4, "null") == 0) {
+        out = NAN;
+        return true;
+    }
+    char *end = nullptr;
+    out = strtod(s.c_str() + p, &end);
+    return end != s.c_str() + p;
+}
+
+bool json_find_string(const std::string &s, const char *key, std::string &out) {
+    size_t p = json_value_pos(s, key);
+    if (p == std::string::npos || s[p] != '"') return false;
+    size_t e = s.find('"', p + 1);
+    if (e == std::string::npos) return false;
+    out = s.substr(p + 1, e - p - 1);
+    return true;
+}
+
+bool json_find_bool(const std::string &s, const char *key, bool &out) {
+    size_t p = json_value_pos(s, key);
+    if (p == std::string::npos) return false;
+    if (s.compare(p, 4, "true") == 0) {
+        out = true;
+        return true;
+    }
+    if (s.compare(p, 5, "false") == 0) {
+        out = false;
+        return true;
+    }
+    return false;
+}
+
+const char *distance_name(int d) { return d == QAMD_DOT ? "Dot" : d == QAMD_L1 ? "L1" : "L2"; }
+
+bool parse_distance(const std::string &s, int &d) {
+    if (s == "Dot") d = QAMD_DOT;
+    else if (s == "L1") d = QAMD_L1;
+    else if (s == "L2") d = QAMD_L2;
+    else return false;
+    return true;
+}
+
+// serde field order of VectorParameters (encoded_vectors.rs:13-19)
+std::string vector_parameters_json(const qamd_vector_parameters &vp) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "{\"dim\":%llu,\"count\":%llu,\"distance_type\":\"%s\",\"invert\":%s}",
+             (unsigned long long)vp.dim, (unsigned long long)vp.count, distance_name(vp.distance_type),
+             vp.invert ? "true" : "false");
+    return buf;
+}
+
+bool parse_vector_parameters(const std::string &json, qamd_vector_parameters &vp) {
+    size_t p = json.find("\"vector_parameters\"");
+    std::string sub = p == std::string::npos ? json : json.substr(p);
+    double dim, count;
+    std::string dist;
+    bool inv;
+    if (!json_find_number(sub, "dim", dim) || !json_find_number(sub, "count", count) ||
+        !json_find_string(sub, "distance_type", dist) || !json_find_bool(sub, "invert", inv))
+        return false;
+    int d;
+    if (!parse_distance(dist, d)) return false;
+    vp.dim = (uint64_t)dim;
+    vp.count = (uint64_t)count;
+    vp.distance_type = d;
+    vp.invert = inv ? 1 : 0;
+    return true;
+}
+
+}  // namespace qamd
+
+extern "C" {
+
+const char *qamd_last_error(void) { return qamd::last_error().c_str(); }
+const char *qamd_version(void) { return "quantization_amd 0.1 (gfx950)"; }
+
+int qamd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+qamd_status qamd_set_device(int device) {
+    qamd_status st = qamd::ensure_device(device);
+    if (st == QAMD_OK) qamd::g_device = device;
+    return st;
+}
+}

@@ -1,0 +1,792 @@
+// Product quantizer on MI355X (gfx950): nearest-centroid encode, query LUT, LUT-gather scan,
+// and k-means centroid training.
+//
+// Host side mirrors EncodedVectorsPQ (quantization/src/encoded_vectors_pq.rs).
+//
+// HBM layout: rows are the reference's m code bytes (m = number of chunks, :109-114) at a
+// device stride of round_up(m, 4) so that a row is a whole number of dwords; centroids stay
+// centroid-major with full-dim rows, 256 x dim f32 (Metadata.centroids, :39-44).
+//
+// Scan (score_point_sse, :405-440, is the order reproduced bit for bit): the query's
+// chunk-major LUT (m x 256 f32; 96 KiB at m = 96) is staged ONCE per workgroup in LDS — one
+// 1024-thread workgroup per CU, the whole CU's 160 KiB — and four adjacent lanes own one row:
+// lane k plays SSE lane k, walking chunks k, k+4, k+8, ... in order with one ds_read_b32
+// gather and one f32 add each, so its running sum is exactly the reference's lane sum; the
+// combine is (l0+l2)+(l1+l3) by two cross-lane adds and lane 0 appends the m%4 tail.  Bound:
+// 96 B/row of HBM reads nominally, but the 96 bank-conflicting LDS gathers per row are the
+// expected limiter.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "topk.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace qamd;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kScanBlock = 1024;
+constexpr uint64_t kRowPad = 1024;
+constexpr int kCentroids = QAMD_PQ_CENTROIDS;
+constexpr uint64_t kKmeansSample = 10000;  // KMEANS_SAMPLE_SIZE (:22)
+constexpr int kKmeansMaxIter = 100;        // KMEANS_MAX_ITERATIONS (:23)
+constexpr float kKmeansAccuracy = 1e-5f;   // KMEANS_ACCURACY (:24)
+constexpr size_t kLdsBudget = 160 * 1024 - 1024;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
+    u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+// ------------------------------------------------------------------------------ scan
+// LUT_IN_LDS: lut staged in dynamic LDS (m*1024 bytes); else gathered through L1/L2.
+// ids == nullptr scans rows [0, n).
+template <bool LUT_IN_LDS, bool VEC16>
+__global__ __launch_bounds__(kScanBlock) void pq_scan_kernel(const uint32_t *__restrict__ rows32,
+                                                            const float *__restrict__ lut_g,
+                                                            const uint32_t *__restrict__ ids, uint64_t n,
+                                                            uint32_t n_rows, uint32_t m, uint32_t row_words,
+                                                            float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];
+    const float *lut = lut_g;
+    if (LUT_IN_LDS) {
+        const uint32_t total4 = m * (kCentroids / 4);
+        const float4 *src = reinterpret_cast<const float4 *>(lut_g);
+        float4 *dst = reinterpret_cast<float4 *>(lut_s);
+        for (uint32_t i = threadIdx.x; i < total4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        lut = lut_s;
+    }
+    const int lane = threadIdx.x & 63;
+    const int k = lane & 3;       // SSE lane
+    const int rslot = lane >> 2;  // row within the wave step (16 rows)
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t wave = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
+    const uint32_t groups = m / 4;
+    const float *lut_k = lut + k * kCentroids;
+    const uint32_t shift = 8 * k;
+    for (uint64_t base = wave * 16; base < n; base += n_waves * 16) {
+        const uint64_t idx = base + rslot;
+        const uint32_t row = idx < n ? (ids ? ids[idx] : (uint32_t)idx) : 0xFFFFFFFFu;
+        const bool ok = row < n_rows;
+        const uint32_t *p = rows32 + (uint64_t)(ok ? row : 0) * row_words;
+        float acc = 0.0f;
+        uint32_t t = 0;
+        if (VEC16) {  // row_words % 4 == 0: 16-byte loads, four chunk groups per load
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
+            for (; t + 4 <= groups; t += 4) {
+                const uint4 w = ld_nt(p4 + (t >> 2));
+                const float *l = lut_k + (size_t)t * 4 * kCentroids;
+                acc += l[(w.x >> shift) & 255u];
+                acc += l[4 * kCentroids + ((w.y >> shift) & 255u)];
+                acc += l[8 * kCentroids + ((w.z >> shift) & 255u)];
+                acc += l[12 * kCentroids + ((w.w >> shift) & 255u)];
+            }
+        }
+        for (; t < groups; t++) {
+            const uint32_t w = p[t];
+            acc += lut_k[(size_t)t * 4 * kCentroids + ((w >> shift) & 255u)];
+        }
+        // (l0 + l2) + (l1 + l3)  (:430-432)
+        float a = acc + __shfl_xor(acc, 2, 64);
+        float s = a + __shfl_xor(a, 1, 64);
+        if (k == 0 && idx < n) {
+            if (ok) {
+                for (uint32_t c = groups * 4; c < m; c++) {  // tail (:434-438)
+                    const uint32_t code = (p[c >> 2] >> (8 * (c & 3))) & 255u;
+                    s += lut[(size_t)c * kCentroids + code];
+                }
+                out[idx] = s;
+            } else {
+                out[idx] = __builtin_nanf("");
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ encode
+// encode_vector (:237-265): a thread owns one (row, chunk) and walks the 256 centroids in
+// index order with the reference's strict '<', so ties and NaNs resolve identically.  The
+// chunk's 256 sub-centroids sit in LDS and are read as wave-wide broadcasts.
+// Workgroup = 256 rows x all chunks of one chunk-slice (blockIdx.y).
+__global__ __launch_bounds__(kBlock) void pq_encode_kernel(const float *__restrict__ data, uint64_t n_rows,
+                                                          uint32_t dim, uint32_t chunk_size, uint32_t m,
+                                                          const float *__restrict__ centroids /*[256][dim]*/,
+                                                          uint8_t *__restrict__ rows, uint32_t row_stride,
+                                                          uint64_t row0, uint32_t chunks_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) float cen_s[];  // [256][chunk_size]
+    const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = r < n_rows;
+    const float *src = data + (active ? r : 0) * dim;
+    const uint32_t c_begin = blockIdx.y * chunks_per_slice;
+    const uint32_t c_end = min(m, c_begin + chunks_per_slice);
+    for (uint32_t c = c_begin; c < c_end; c++) {
+        const uint32_t lo = c * chunk_size;
+        const uint32_t len = min(chunk_size, dim - lo);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < kCentroids * len; i += kBlock) {
+            const uint32_t kc = i / len, j = i - kc * len;
+            cen_s[kc * chunk_size + j] = centroids[(size_t)kc * dim + lo + j];
+        }
+        __syncthreads();
+        if (!active) continue;
+        float min_d = 3.40282347e+38f;
+        uint32_t min_i = 0;
+        for (uint32_t kc = 0; kc < (uint32_t)kCentroids; kc++) {
+            const float *cen = cen_s + kc * chunk_size;
+            float d = 0.0f;
+            for (uint32_t j = 0; j < len; j++) {
+                const float t = src[lo + j] - cen[j];
+                d += t * t;  // (a-b).powi(2), sequential f32 sum
+            }
+            if (d < min_d) {
+                min_d = d;
+                min_i = kc;
+            }
+        }
+        rows[(row0 + r) * row_stride + c] = (uint8_t)min_i;
+    }
+}
+
+// encode_query (:525-547): one thread per LUT entry, sequential f32 over the chunk
+// (DistanceType::distance, encoded_vectors.rs:37-45).
+__global__ __launch_bounds__(kBlock) void pq_lut_kernel(const float *__restrict__ query, uint32_t dim,
+                                                       uint32_t chunk_size, uint32_t m,
+                                                       const float *__restrict__ centroids, int distance,
+                                                       int invert, float *__restrict__ lut) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m * kCentroids) return;
+    const uint32_t c = i / kCentroids, kc = i % kCentroids;
+    const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
+    const float *a = query + lo, *b = centroids + (size_t)kc * dim + lo;
+    float s = 0.0f;
+    if (distance == QAMD_DOT)
+        for (uint32_t j = 0; j < len; j++) s += a[j] * b[j];
+    else if (distance == QAMD_L1)
+        for (uint32_t j = 0; j < len; j++) s += fabsf(a[j] - b[j]);
+    else
+        for (uint32_t j = 0; j < len; j++) s += (a[j] - b[j]) * (a[j] - b[j]);
+    lut[i] = invert ? -s : s;
+}
+
+// score_internal (:566-593): decode both rows to centroid sub-vectors, sequential f32.
+__global__ void pq_internal_kernel(const uint8_t *__restrict__ rows, uint32_t row_stride, uint32_t dim,
+                                   uint32_t chunk_size, uint32_t m, const float *__restrict__ centroids,
+                                   int distance, int invert, uint32_t i, uint32_t j, float *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint8_t *ci = rows + (size_t)i * row_stride, *cj = rows + (size_t)j * row_stride;
+    float total = 0.0f;
+    for (uint32_t c = 0; c < m; c++) {
+        const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
+        const float *a = centroids + (size_t)ci[c] * dim + lo, *b = centroids + (size_t)cj[c] * dim + lo;
+        float s = 0.0f;
+        if (distance == QAMD_DOT)
+            for (uint32_t t = 0; t < len; t++) s += a[t] * b[t];
+        else if (distance == QAMD_L1)
+            for (uint32_t t = 0; t < len; t++) s += fabsf(a[t] - b[t]);
+        else
+            for (uint32_t t = 0; t < len; t++) s += (a[t] - b[t]) * (a[t] - b[t]);
+        total += s;
+    }
+    *out = invert ? -total : total;
+}
+
+// Reference rows (stride m) <-> device rows (stride round_up(m,4)).
+__global__ __launch_bounds__(kBlock) void pq_restride_kernel(const uint8_t *__restrict__ src, uint32_t src_stride,
+                                                            uint8_t *__restrict__ dst, uint32_t dst_stride,
+                                                            uint64_t n_rows, uint32_t m) {
+    const uint64_t total = n_rows * m;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t r = t / m;
+        const uint32_t c = (uint32_t)(t - r * m);
+        dst[r * dst_stride + c] = src[r * src_stride + c];
+    }
+}
+
+// ------------------------------------------------------------------------------ k-means (kmeans.rs)
+// All chunks iterate in lockstep; a converged chunk (done[c] != 0) is frozen.
+// sample: [S][dim]; cen: [256][dim] (centroid-major, like Metadata.centroids).
+__global__ __launch_bounds__(kBlock) void km_assign_accumulate_kernel(
+    const float *__restrict__ sample, uint32_t S, uint32_t dim, uint32_t chunk_size, uint32_t m,
+    const float *__restrict__ cen, const int *__restrict__ done, double *__restrict__ acc /*[256][dim]*/,
+    uint32_t *__restrict__ cnt /*[m][256]*/) {
+    extern __shared__ __attribute__((aligned(16))) float cen_s[];
+    const uint32_t c = blockIdx.y;
+    if (done[c]) return;
+    const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
+    for (uint32_t i = threadIdx.x; i < kCentroids * len; i += kBlock) {
+        const uint32_t kc = i / len, j = i - kc * len;
+        cen_s[kc * chunk_size + j] = cen[(size_t)kc * dim + lo + j];
+    }
+    __syncthreads();
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= S) return;
+    const float *src = sample + (size_t)s * dim + lo;
+    float min_d = 3.40282347e+38f;
+    uint32_t min_i = 0;
+    for (uint32_t kc = 0; kc < (uint32_t)kCentroids; kc++) {  // update_indexes, kmeans.rs:139-166
+        float d = 0.0f;
+        for (uint32_t j = 0; j < len; j++) {
+            const float t = src[j] - cen_s[kc * chunk_size + j];
+            d += t * t;
+        }
+        if (d < min_d) {
+            min_d = d;
+            min_i = kc;
+        }
+    }
+    atomicAdd(&cnt[c * kCentroids + min_i], 1u);  // update_centroids, kmeans.rs:49-100 (f64 sums)
+    for (uint32_t j = 0; j < len; j++) atomicAdd(&acc[(size_t)min_i * dim + lo + j], (double)src[j]);
+}
+
+__global__ __launch_bounds__(kBlock) void km_finalize_kernel(const float *__restrict__ sample, uint32_t S,
+                                                            uint32_t dim, uint32_t chunk_size, uint32_t m,
+                                                            float *__restrict__ cen, const int *__restrict__ done,
+                                                            double *__restrict__ acc, const uint32_t *__restrict__ cnt,
+                                                            float *__restrict__ diff /*[m]*/, uint32_t iter) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (uint32_t)kCentroids * dim) return;
+    const uint32_t kc = i / dim, j = i - kc * dim;
+    const uint32_t c = j / chunk_size;
+    if (done[c]) return;
+    const uint32_t n = cnt[c * kCentroids + kc];
+    float nv;
+    if (n == 0) {
+        // kmeans.rs:111-118 takes a thread_rng row; here a fixed hash of (chunk, centroid, iter)
+        uint32_t hsh = (c * 2654435761u) ^ (kc * 40503u) ^ (iter * 2246822519u);
+        hsh ^= hsh >> 15;
+        hsh *= 2246822519u;
+        hsh ^= hsh >> 13;
+        nv = sample[(size_t)(hsh % S) * dim + j];
+    } else {
+        nv = (float)(acc[i] / (double)n);
+    }
+    atomicAdd(&diff[c], fabsf(cen[i] - nv));  // kmeans.rs:125-135
+    cen[i] = nv;
+    acc[i] = 0.0;
+}
+
+int grid_for(uint64_t work_items, uint64_t per_block, int blocks_per_cu) {
+    uint64_t want = (work_items + per_block - 1) / per_block;
+    uint64_t cap = (uint64_t)device_info().cu_count * blocks_per_cu;
+    if (want < 1) want = 1;
+    return (int)(want > cap ? cap : want);
+}
+
+uint64_t chunks_of(uint64_t dim, uint64_t chunk_size) { return (dim + chunk_size - 1) / chunk_size; }
+
+}  // namespace
+
+struct qamd_pq {
+    int device = 0;
+    qamd_vector_parameters vp{};
+    uint64_t chunk_size = 0;
+    uint64_t m = 0;           // chunks = reference row bytes
+    uint64_t ds = 0;          // device row stride
+    uint64_t count = 0;
+    std::vector<float> centroids_host;  // [256][dim]
+    DevBuf centroids;                   // same on device
+    DevBuf rows;                        // [padded][ds]
+};
+
+struct qamd_pq_query {
+    int device = 0;
+    uint64_t m = 0;
+    DevBuf lut;  // m*256 f32
+};
+
+namespace {
+
+qamd_status alloc_store(qamd_pq *h) {
+    h->m = chunks_of(h->vp.dim, h->chunk_size);
+    h->ds = round_up(std::max<uint64_t>(h->m, 1), 4);
+    const uint64_t padded = round_up(h->count, kRowPad) + kRowPad;
+    return h->rows.alloc(padded * h->ds, true);
+}
+
+qamd_status set_centroids(qamd_pq *h, const float *centroids_host, hipStream_t s) {
+    const size_t n = (size_t)kCentroids * h->vp.dim;
+    h->centroids_host.assign(centroids_host, centroids_host + n);
+    QAMD_TRY(h->centroids.alloc(std::max<size_t>(n, 4) * sizeof(float)));
+    return copy_in(h->centroids.ptr, h->centroids_host.data(), QAMD_MEM_HOST, n * sizeof(float), s);
+}
+
+qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *ids_dev, uint64_t n,
+                        float *out_dev, hipStream_t s) {
+    if (n == 0) return QAMD_OK;
+    const uint32_t m = (uint32_t)h->m, row_words = (uint32_t)(h->ds / 4);
+    const size_t lds = (size_t)m * kCentroids * sizeof(float);
+    const bool in_lds = lds <= kLdsBudget && n >= 4096;  // small batches: not worth staging 96 KiB per CU
+    const bool vec16 = (row_words % 4) == 0;
+    const int cu = device_info().cu_count;
+#define QAMD_PQ_LAUNCH(LDSF, V16, GRID, SH)                                                                 \
+    hipLaunchKernelGGL((pq_scan_kernel<LDSF, V16>), dim3(GRID), dim3(kScanBlock), SH, s, h->rows.as<uint32_t>(), \
+                       lut_dev, ids_dev, n, (uint32_t)h->count, m, row_words, out_dev)
+    if (in_lds) {
+        static std::once_flag once;  // opt in to > 64 KiB dynamic LDS once per kernel
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+        });
+        const int grid = (int)std::min<uint64_t>(cu, (n + 255) / 256);
+        if (vec16) QAMD_PQ_LAUNCH(true, true, grid, lds);
+        else QAMD_PQ_LAUNCH(true, false, grid, lds);
+    } else {
+        const int grid = (int)std::min<uint64_t>((uint64_t)cu * 2, (n + 255) / 256);
+        if (vec16) QAMD_PQ_LAUNCH(false, true, grid, 0);
+        else QAMD_PQ_LAUNCH(false, false, grid, 0);
+    }
+#undef QAMD_PQ_LAUNCH
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+qamd_status check_query(const qamd_pq *h, const qamd_pq_query *q) {
+    if (!h || !q) return fail(QAMD_ERR_ARGUMENTS, "null handle or query");
+    if (q->m != h->m) return fail(QAMD_ERR_ARGUMENTS, "query LUT has %llu chunks, store has %llu",
+                                  (unsigned long long)q->m, (unsigned long long)h->m);
+    return QAMD_OK;
+}
+
+qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_stop_fn stop, void *stop_user,
+                        hipStream_t s) {
+    const uint64_t dim = h->vp.dim, count = h->count;
+    if (count == 0 || dim == 0) return QAMD_OK;
+    const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, (256ull << 20) / (dim * 4)));
+    DevBuf stage;
+    if (data_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(batch_rows * dim * 4));
+    const size_t lds = (size_t)kCentroids * h->chunk_size * sizeof(float);
+    if (lds > kLdsBudget) return fail(QAMD_ERR_ARGUMENTS, "chunk_size %llu too large", (unsigned long long)h->chunk_size);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_encode_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    });
+    for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
+        if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :198-200
+        const uint64_t nr = std::min(batch_rows, count - r0);
+        const float *src = data + r0 * dim;
+        if (data_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
+            src = stage.as<float>();
+        }
+        const uint32_t gx = (uint32_t)((nr + kBlock - 1) / kBlock);
+        // few row blocks -> split the chunk loop over blockIdx.y to fill the chip
+        uint32_t slices = 1;
+        const uint32_t want = (uint32_t)device_info().cu_count * 4;
+        if (gx < want) slices = std::min<uint32_t>((uint32_t)h->m, (want + gx - 1) / gx);
+        const uint32_t per = (uint32_t)((h->m + slices - 1) / slices);
+        slices = (uint32_t)((h->m + per - 1) / per);
+        hipLaunchKernelGGL(pq_encode_kernel, dim3(gx, slices), dim3(kBlock), lds, s, src, nr, (uint32_t)dim,
+                           (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(), h->rows.as<uint8_t>(),
+                           (uint32_t)h->ds, r0, per);
+        QAMD_HIP(hipGetLastError());
+        if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
+    }
+    QAMD_HIP(hipStreamSynchronize(s));
+    return QAMD_OK;
+}
+
+// find_centroids (:278-342) for count > 256: k-means on a <= 10 000-row sample.
+qamd_status train_centroids(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_stop_fn stop, void *stop_user,
+                            hipStream_t s) {
+    const uint64_t dim = h->vp.dim, count = h->count;
+    const uint32_t S = (uint32_t)std::min<uint64_t>(kKmeansSample, count);
+    const uint32_t m = (uint32_t)h->m;
+    // The reference samples with a random Permutor and sorts the picks (:300-307); here an
+    // evenly strided subset in index order (deterministic; centroid values are parity-unpinned).
+    DevBuf sample;
+    QAMD_TRY(sample.alloc((size_t)S * dim * 4));
+    for (uint32_t k = 0; k < S; k++) {
+        const uint64_t r = (uint64_t)((unsigned __int128)k * count / S);
+        QAMD_HIP(hipMemcpyAsync(sample.as<float>() + (size_t)k * dim, data + r * dim, dim * 4,
+                                data_mem == QAMD_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    }
+    if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :303-305
+    const size_t ncen = (size_t)kCentroids * dim;
+    DevBuf cen, acc, cnt, done, diff;
+    QAMD_TRY(cen.alloc(ncen * 4));
+    QAMD_TRY(acc.alloc(ncen * 8, true));
+    QAMD_TRY(cnt.alloc((size_t)m * kCentroids * 4));
+    QAMD_TRY(done.alloc((size_t)m * 4, true));
+    QAMD_TRY(diff.alloc((size_t)m * 4));
+    // initial centroids = the first 256 sample rows (kmeans.rs:25)
+    QAMD_HIP(hipMemcpyAsync(cen.ptr, sample.ptr, ncen * 4, hipMemcpyDeviceToDevice, s));
+    const size_t lds = (size_t)kCentroids * h->chunk_size * sizeof(float);
+    if (lds > kLdsBudget) return fail(QAMD_ERR_ARGUMENTS, "chunk_size %llu too large", (unsigned long long)h->chunk_size);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&km_assign_accumulate_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    });
+    std::vector<int> done_h(m, 0);
+    std::vector<float> diff_h(m);
+    for (int iter = 0; iter < kKmeansMaxIter; iter++) {
+        if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // kmeans.rs:29-31
+        QAMD_HIP(hipMemsetAsync(cnt.ptr, 0, (size_t)m * kCentroids * 4, s));
+        QAMD_HIP(hipMemsetAsync(diff.ptr, 0, (size_t)m * 4, s));
+        hipLaunchKernelGGL(km_assign_accumulate_kernel, dim3((S + kBlock - 1) / kBlock, m), dim3(kBlock), lds, s,
+                           sample.as<float>(), S, (uint32_t)dim, (uint32_t)h->chunk_size, m, cen.as<float>(),
+                           done.as<int>(), acc.as<double>(), cnt.as<uint32_t>());
+        hipLaunchKernelGGL(km_finalize_kernel, dim3((uint32_t)((ncen + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                           sample.as<float>(), S, (uint32_t)dim, (uint32_t)h->chunk_size, m, cen.as<float>(),
+                           done.as<int>(), acc.as<double>(), cnt.as<uint32_t>(), diff.as<float>(), (uint32_t)iter);
+        QAMD_HIP(hipGetLastError());
+        QAMD_TRY(copy_out(diff_h.data(), QAMD_MEM_HOST, diff.ptr, (size_t)m * 4, s));
+        bool all = true;
+        for (uint32_t c = 0; c < m; c++) {
+            if (!done_h[c] && diff_h[c] < kKmeansAccuracy) done_h[c] = 1;
+            all = all && done_h[c];
+        }
+        if (all) break;
+        QAMD_TRY(copy_in(done.ptr, done_h.data(), QAMD_MEM_HOST, (size_t)m * 4, s));
+    }
+    std::vector<float> cen_h(ncen);
+    QAMD_TRY(copy_out(cen_h.data(), QAMD_MEM_HOST, cen.ptr, ncen * 4, s));
+    return set_centroids(h, cen_h.data(), s);
+}
+
+std::string centroids_json(const qamd_pq *h) {
+    std::string js = "[";
+    const uint64_t dim = h->vp.dim;
+    for (int k = 0; k < kCentroids; k++) {
+        js += k ? ",[" : "[";
+        for (uint64_t j = 0; j < dim; j++) {
+            if (j) js += ",";
+            js += json_f32(h->centroids_host[(size_t)k * dim + j]);
+        }
+        js += "]";
+    }
+    return js + "]";
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t qamd_pq_quantized_vector_size(const qamd_vector_parameters *vp, uint64_t chunk_size) {
+    return chunk_size ? chunks_of(vp->dim, chunk_size) : 0;
+}
+
+qamd_status qamd_pq_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                           uint64_t chunk_size, const float *centroids, uint32_t max_kmeans_threads,
+                           qamd_stop_fn stop, void *stop_user, void *stream, qamd_pq **out) {
+    (void)max_kmeans_threads;  // CPU thread count in the reference; the GPU needs none
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
+    QAMD_TRY(ensure_device(current_device()));
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<qamd_pq> h(new qamd_pq);
+    h->device = current_device();
+    h->vp = *vp;
+    h->chunk_size = chunk_size;
+    h->count = vp->count;
+    QAMD_TRY(alloc_store(h.get()));
+    const uint64_t dim = vp->dim, count = vp->count;
+    if (centroids) {
+        QAMD_TRY(set_centroids(h.get(), centroids, s));
+    } else if (count <= (uint64_t)kCentroids) {
+        // :290-297: the vectors themselves, zero-filled up to 256
+        std::vector<float> cen((size_t)kCentroids * dim, 0.0f);
+        if (count && dim) {
+            if (data_mem == QAMD_MEM_HOST) memcpy(cen.data(), data, count * dim * 4);
+            else QAMD_TRY(copy_out(cen.data(), QAMD_MEM_HOST, data, count * dim * 4, s));
+        }
+        QAMD_TRY(set_centroids(h.get(), cen.data(), s));
+    } else {
+        QAMD_TRY(train_centroids(h.get(), data, data_mem, stop, stop_user, s));
+    }
+    QAMD_TRY(encode_rows(h.get(), data, data_mem, stop, stop_user, s));
+    if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :95-106
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_vector_parameters *vp,
+                              uint64_t chunk_size, const float *centroids, void *stream, qamd_pq **out) {
+    if (!vp || !out || !centroids) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    QAMD_TRY(ensure_device(current_device()));
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<qamd_pq> h(new qamd_pq);
+    h->device = current_device();
+    h->vp = *vp;
+    h->chunk_size = chunk_size;
+    h->count = vp->count;
+    QAMD_TRY(alloc_store(h.get()));
+    QAMD_TRY(set_centroids(h.get(), centroids, s));
+    if (h->count && h->m) {
+        if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
+        if (h->m == h->ds) {
+            QAMD_TRY(copy_in(h->rows.ptr, rows, rows_mem, h->count * h->m, s));
+        } else {
+            DevBuf stage;
+            const uint8_t *src = rows;
+            if (rows_mem == QAMD_MEM_HOST) {
+                QAMD_TRY(stage.alloc(h->count * h->m));
+                QAMD_TRY(copy_in(stage.ptr, rows, QAMD_MEM_HOST, h->count * h->m, s));
+                src = stage.as<uint8_t>();
+            }
+            hipLaunchKernelGGL(pq_restride_kernel, dim3(grid_for(h->count * h->m, kBlock * 4, 8)), dim3(kBlock), 0, s,
+                               src, (uint32_t)h->m, h->rows.as<uint8_t>(), (uint32_t)h->ds, h->count, (uint32_t)h->m);
+            QAMD_HIP(hipGetLastError());
+            QAMD_HIP(hipStreamSynchronize(s));
+        }
+    }
+    QAMD_HIP(hipStreamSynchronize(s));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_export_rows(const qamd_pq *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (h->count == 0 || h->m == 0) return QAMD_OK;
+    if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    if (h->m == h->ds) return copy_out(rows, rows_mem, h->rows.ptr, h->count * h->m, s);
+    DevBuf stage;
+    uint8_t *dst = rows;
+    if (rows_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(stage.alloc(h->count * h->m));
+        dst = stage.as<uint8_t>();
+    }
+    hipLaunchKernelGGL(pq_restride_kernel, dim3(grid_for(h->count * h->m, kBlock * 4, 8)), dim3(kBlock), 0, s,
+                       h->rows.as<uint8_t>(), (uint32_t)h->ds, dst, (uint32_t)h->m, h->count, (uint32_t)h->m);
+    QAMD_HIP(hipGetLastError());
+    if (rows_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(rows, QAMD_MEM_HOST, dst, h->count * h->m, s));
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_get_centroids(const qamd_pq *h, float *centroids) {
+    if (!h || !centroids) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    memcpy(centroids, h->centroids_host.data(), h->centroids_host.size() * sizeof(float));
+    return QAMD_OK;
+}
+
+// save (:498-506): Metadata{centroids, vector_division:[{start,end}], vector_parameters}.
+qamd_status qamd_pq_save(const qamd_pq *h, const char *data_path, const char *meta_path) {
+    if (!h || !data_path || !meta_path) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::string js = "{\"centroids\":" + centroids_json(h) + ",\"vector_division\":[";
+    for (uint64_t c = 0; c < h->m; c++) {
+        const uint64_t lo = c * h->chunk_size, hi = std::min<uint64_t>(lo + h->chunk_size, h->vp.dim);
+        if (c) js += ",";
+        js += "{\"start\":" + std::to_string(lo) + ",\"end\":" + std::to_string(hi) + "}";
+    }
+    js += "],\"vector_parameters\":" + vector_parameters_json(h->vp) + "}";
+    make_parent_dirs(meta_path);
+    if (!write_file(meta_path, js.data(), js.size())) return fail(QAMD_ERR_IO, "cannot write %s", meta_path);
+    std::vector<uint8_t> rows(h->count * h->m);
+    QAMD_TRY(qamd_pq_export_rows(h, rows.data(), QAMD_MEM_HOST, nullptr));
+    make_parent_dirs(data_path);
+    if (!write_file(data_path, rows.data(), rows.size())) return fail(QAMD_ERR_IO, "cannot write %s", data_path);
+    return QAMD_OK;
+}
+
+// load (:508-523): row size = metadata.vector_division.len(), count from the caller.
+qamd_status qamd_pq_load(const char *data_path, const char *meta_path, const qamd_vector_parameters *vp,
+                         qamd_pq **out) {
+    if (!data_path || !meta_path || !vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::string js;
+    if (!read_file(meta_path, js)) return fail(QAMD_ERR_IO, "cannot read %s", meta_path);
+    qamd_vector_parameters file_vp{};
+    if (!parse_vector_parameters(js, file_vp)) return fail(QAMD_ERR_IO, "malformed metadata in %s", meta_path);
+    // centroids: 256 arrays of dim numbers
+    size_t p = js.find("\"centroids\"");
+    if (p == std::string::npos) return fail(QAMD_ERR_IO, "metadata has no centroids");
+    p = js.find('[', p);
+    std::vector<float> cen;
+    cen.reserve((size_t)kCentroids * file_vp.dim);
+    int depth = 0;
+    size_t i = p;
+    for (; i < js.size(); i++) {
+        const char ch = js[i];
+        if (ch == '[') depth++;
+        else if (ch == ']') {
+            if (--depth == 0) break;
+        } else if (ch == '-' || ch == 'n' || (ch >= '0' && ch <= '9')) {
+            if (ch == 'n') {
+                cen.push_back(NAN);
+                i += 3;
+            } else {
+                char *end = nullptr;
+                cen.push_back(strtof(js.c_str() + i, &end));
+                i = (size_t)(end - js.c_str()) - 1;
+            }
+        }
+    }
+    if (cen.size() != (size_t)kCentroids * file_vp.dim)
+        return fail(QAMD_ERR_IO, "metadata holds %zu centroid values, expected %llu", cen.size(),
+                    (unsigned long long)((uint64_t)kCentroids * file_vp.dim));
+    // vector_division: the first range's length is the chunk size; its count is the row size
+    size_t d = js.find("\"vector_division\"", i);
+    if (d == std::string::npos) return fail(QAMD_ERR_IO, "metadata has no vector_division");
+    const size_t dend = js.find(']', d);
+    uint64_t m = 0, chunk_size = 0;
+    for (size_t q = js.find("\"start\"", d); q != std::string::npos && q < dend; q = js.find("\"start\"", q + 1)) {
+        double st = 0, en = 0;
+        const std::string sub = js.substr(q, 64);
+        json_find_number(sub, "start", st);
+        json_find_number(sub, "end", en);
+        if (m == 0) chunk_size = (uint64_t)(en - st);
+        m++;
+    }
+    if (chunk_size == 0) chunk_size = 1;
+    std::string bytes;
+    if (!read_file(data_path, bytes)) return fail(QAMD_ERR_IO, "cannot read %s", data_path);
+    const uint64_t expected = m * vp->count;
+    if (bytes.size() != expected)
+        return fail(QAMD_ERR_IO, "Loaded storage size %zu is not equal to expected size %llu", bytes.size(),
+                    (unsigned long long)expected);
+    qamd_vector_parameters eff = file_vp;
+    eff.count = vp->count;
+    if (chunks_of(eff.dim, chunk_size) != m) return fail(QAMD_ERR_IO, "vector_division does not tile dim");
+    return qamd_pq_from_rows(reinterpret_cast<const uint8_t *>(bytes.data()), QAMD_MEM_HOST, &eff, chunk_size,
+                             cen.data(), nullptr, out);
+}
+
+qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t qdim, qamd_mem query_mem,
+                                 void *stream, qamd_pq_query **query_io) {
+    if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (qdim != h->vp.dim)  // the reference slices query[range] and would panic (:529)
+        return fail(QAMD_ERR_ARGUMENTS, "query has %llu dims, store has %llu", (unsigned long long)qdim,
+                    (unsigned long long)h->vp.dim);
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    qamd_pq_query *q = *query_io;
+    std::unique_ptr<qamd_pq_query> fresh;
+    if (!q) {
+        fresh.reset(new qamd_pq_query);
+        q = fresh.get();
+        q->device = h->device;
+    }
+    const size_t n = (size_t)h->m * kCentroids;
+    if (q->m != h->m || !q->lut.ptr) {
+        QAMD_TRY(q->lut.alloc(std::max<size_t>(n, 4) * sizeof(float)));
+        q->m = h->m;
+    }
+    if (n) {
+        DevBuf qtmp;
+        const float *qd = query;
+        if (query_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(qtmp.alloc(qdim * 4));
+            QAMD_TRY(copy_in(qtmp.ptr, query, QAMD_MEM_HOST, qdim * 4, s));
+            qd = qtmp.as<float>();
+        }
+        hipLaunchKernelGGL(pq_lut_kernel, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, qd,
+                           (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
+                           h->vp.distance_type, h->vp.invert, q->lut.as<float>());
+        QAMD_HIP(hipGetLastError());
+        if (query_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));  // qtmp is freed on return
+    }
+    if (fresh) *query_io = fresh.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_query_read(const qamd_pq_query *q, float *lut, uint64_t capacity, uint64_t *len) {
+    if (!q) return fail(QAMD_ERR_ARGUMENTS, "null query");
+    const uint64_t n = q->m * kCentroids;
+    if (len) *len = n;
+    if (lut) {
+        if (capacity < n) return fail(QAMD_ERR_ARGUMENTS, "lut buffer too small");
+        QAMD_TRY(ensure_device(q->device));
+        QAMD_TRY(copy_out(lut, QAMD_MEM_HOST, q->lut.ptr, n * 4, nullptr));
+    }
+    return QAMD_OK;
+}
+
+void qamd_pq_query_free(qamd_pq_query *q) { delete q; }
+
+qamd_status qamd_pq_score_all(const qamd_pq *h, const qamd_pq_query *q, float *out, qamd_mem out_mem,
+                              void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (h->count == 0) return QAMD_OK;
+    if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    if (out_mem == QAMD_MEM_DEVICE) return scan_launch(h, q->lut.as<float>(), nullptr, h->count, out, s);
+    DevBuf tmp;
+    QAMD_TRY(tmp.alloc(h->count * 4));
+    QAMD_TRY(scan_launch(h, q->lut.as<float>(), nullptr, h->count, tmp.as<float>(), s));
+    return copy_out(out, QAMD_MEM_HOST, tmp.ptr, h->count * 4, s);
+}
+
+qamd_status qamd_pq_score_ids(const qamd_pq *h, const qamd_pq_query *q, const uint32_t *ids, uint64_t n_ids,
+                              qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (n_ids == 0) return QAMD_OK;
+    if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    DevBuf ids_tmp, out_tmp;
+    const uint32_t *ids_dev = ids;
+    if (ids_mem == QAMD_MEM_HOST) {
+        for (uint64_t k = 0; k < n_ids; k++)
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+        QAMD_TRY(ids_tmp.alloc(n_ids * 4));
+        QAMD_TRY(copy_in(ids_tmp.ptr, ids, QAMD_MEM_HOST, n_ids * 4, s));
+        ids_dev = ids_tmp.as<uint32_t>();
+    }
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(out_tmp.alloc(n_ids * 4));
+        out_dev = out_tmp.as<float>();
+    }
+    QAMD_TRY(scan_launch(h, q->lut.as<float>(), ids_dev, n_ids, out_dev, s));
+    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, n_ids * 4, s));
+    else if (ids_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_score_point(const qamd_pq *h, const qamd_pq_query *q, uint32_t i, float *out) {
+    return qamd_pq_score_ids(h, q, &i, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
+}
+
+qamd_status qamd_pq_score_internal(const qamd_pq *h, uint32_t i, uint32_t j, float *out) {
+    if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (i >= h->count || j >= h->count)
+        return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
+    QAMD_TRY(ensure_device(h->device));
+    DevBuf tmp;
+    QAMD_TRY(tmp.alloc(16));
+    hipLaunchKernelGGL(pq_internal_kernel, dim3(1), dim3(64), 0, nullptr, h->rows.as<uint8_t>(), (uint32_t)h->ds,
+                       (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
+                       h->vp.distance_type, h->vp.invert, i, j, tmp.as<float>());
+    QAMD_HIP(hipGetLastError());
+    return copy_out(out, QAMD_MEM_HOST, tmp.ptr, 4, nullptr);
+}
+
+qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, int largest, uint32_t *out_ids,
+                         float *out_scores, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (k == 0) return QAMD_OK;
+    if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    float *scores = nullptr;
+    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+    qamd_status st = scan_launch(h, q->lut.as<float>(), nullptr, h->count, scores, s);
+    if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
+    (void)hipFreeAsync(scores, s);
+    return st;
+}
+
+void qamd_pq_free(qamd_pq *h) { delete h; }
+
+}  // extern "C"

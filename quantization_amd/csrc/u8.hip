@@ -1,0 +1,1040 @@
+// Scalar u8 quantizer on MI355X (gfx950): encode, query encode, and the query-vs-store scan.
+//
+// Host class mirrors EncodedVectorsU8 (quantization/src/encoded_vectors_u8.rs); the kernels
+// replace the per-pair SIMD FFI (quantization/cpp/avx2.c:25-122) by whole-store launches.
+//
+// HBM layout (library-owned copy).  The reference row is AoS [vector_offset f32][codes]
+// with stride actual_dim+4 (772 B at dim 768: only 4-byte aligned).  On device it is split
+// into  codes[count_padded][actual_dim]  (rows 16-byte aligned, contiguous) and
+// offsets[count] f32.  Same 772 algorithmic bytes per scored row; every code load is an
+// aligned 16-byte `global_load_dwordx4`.
+//
+// Scan mapping (HBM-bound integer work, no MFMA): a row is read by G = min(16, pow2(chunks))
+// adjacent lanes, 16 B per lane per iteration, so one wave-load covers 64/G consecutive rows
+// = fully used 128-B lines.  The query's 16-byte chunks live in VGPRs for the whole kernel.
+// v_dot4_u32_u8 accumulates in 32-bit integers (exact), a log2(G)-step cross-lane add
+// finishes the row, and the f32 epilogue is evaluated in the reference's order
+// ((multiplier*s) + q.offset) + vector_offset  (encoded_vectors_u8.rs:347), no FMA.
+//
+// Exactness: codes <= 127 => the integer sum is what every reference kernel computes; the
+// reference converts lane sums to f32 before adding them (avx2.c:59-62), which is the same
+// number whenever the sum is < 2^24 (always for actual_dim <= 1040).  Above that the GPU
+// returns the exact integer rounded ONCE to f32 (= the reference's scalar path,
+// encoded_vectors_u8.rs:158), or — mode QAMD_U8_LANES_AVX2 — reproduces avx2.c's 8-lane f32
+// summation bit for bit.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "topk.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace qamd;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint64_t kRowPad = 1024;  // rows are padded so that every wave tile is in bounds
+constexpr uint64_t kQuantileSample = 100000;  // QUANTILE_SAMPLE_SIZE, quantile.rs:3
+
+enum Epilogue : int { EPI_POINT = 0, EPI_INTERNAL = 1 };
+
+// ------------------------------------------------------------------------------ device helpers
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Streamed-once 16-byte loads: `global_load_dwordx4 ... nt`.
+__device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
+    u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ float4 ld_nt(const float4 *p) {
+    f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
+__device__ __forceinline__ uint32_t dot16(const uint4 &a, const uint4 &b, uint32_t acc) {
+    acc = __builtin_amdgcn_udot4(a.x, b.x, acc, false);
+    acc = __builtin_amdgcn_udot4(a.y, b.y, acc, false);
+    acc = __builtin_amdgcn_udot4(a.z, b.z, acc, false);
+    acc = __builtin_amdgcn_udot4(a.w, b.w, acc, false);
+    return acc;
+}
+
+__device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b, uint32_t acc) {
+    acc = __builtin_amdgcn_sad_u8(a.x, b.x, acc);
+    acc = __builtin_amdgcn_sad_u8(a.y, b.y, acc);
+    acc = __builtin_amdgcn_sad_u8(a.z, b.z, acc);
+    acc = __builtin_amdgcn_sad_u8(a.w, b.w, acc);
+    return acc;
+}
+
+template <int G> __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// encoded_vectors_u8.rs:347 / :409.  s is the exact integer pair sum.
+__device__ __forceinline__ float epilogue(float multiplier, uint32_t s, float q_off, float v_off,
+                                          float diff, int mode) {
+    float sf = (float)(int32_t)s;
+    float ms = multiplier * sf;
+    if (mode == EPI_POINT) return (ms + q_off) + v_off;
+    return ms + ((q_off + v_off) - diff);
+}
+
+// encoded_vectors_u8.rs:234-237  ((v-offset)/alpha).clamp(0,127) as u8
+__device__ __forceinline__ uint32_t f32_to_u8(float v, float alpha, float offset) {
+    float x = (v - offset) / alpha;  // IEEE division (hipcc: correctly rounded f32 divide)
+    x = (x < 0.0f) ? 0.0f : x;
+    x = (x > 127.0f) ? 127.0f : x;
+    return (x != x) ? 0u : (uint32_t)x;
+}
+
+// ------------------------------------------------------------------------------ scan kernel
+// One wave iteration covers (64/G)*UNROLL consecutive rows.  ITERS = ceil(row_chunks / G).
+// EXACT: row_chunks == G*ITERS, so no lane is ever past the row end.  Otherwise loads stay
+// unconditional (clamped address + select) so that they still issue back to back.
+template <int G, int ITERS, int UNROLL, bool IS_L1, bool EXACT>
+__global__ __launch_bounds__(kBlock) void u8_scan_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets,
+    const uint4 *__restrict__ qcodes, const float *__restrict__ q_off_p, float multiplier,
+    uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out) {
+    constexpr int RW = 64 / G;
+    constexpr int TILE = RW * UNROLL;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G;
+    const int rslot = lane / G;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+
+    uint4 q[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        uint32_t c = sub + it * G;
+        q[it] = c < row_chunks ? qcodes[c] : make_uint4(0, 0, 0, 0);
+    }
+    const float q_off = *q_off_p;
+
+    for (uint64_t base = (uint64_t)wave * TILE; base < n_rows; base += (uint64_t)n_waves * TILE) {
+        uint4 v[UNROLL][ITERS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint64_t row = base + u * RW + rslot;
+            const uint4 *p = codes + row * row_chunks;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t c = sub + it * G;
+                if (EXACT) {
+                    v[u][it] = ld_nt(p + c);
+                } else {
+                    const uint32_t cc = c < row_chunks ? c : row_chunks - 1;
+                    uint4 t = ld_nt(p + cc);
+                    const bool in = c < row_chunks;
+                    v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++)
+                acc = IS_L1 ? sad16(v[u][it], q[it], acc) : dot16(v[u][it], q[it], acc);
+            acc = group_sum<G>(acc);
+            const uint64_t row = base + u * RW + rslot;
+            if (sub == 0 && row < n_rows)
+                out[row] = epilogue(multiplier, acc, q_off, offsets[row], 0.0f, EPI_POINT);
+        }
+    }
+}
+
+// Generic dims (row_chunks > 16*8): runtime chunk loop, query re-read through L1/L2.
+template <bool IS_L1>
+__global__ __launch_bounds__(kBlock) void u8_scan_generic_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets,
+    const uint4 *__restrict__ qcodes, const float *__restrict__ q_off_p, float multiplier,
+    uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out) {
+    constexpr int G = 16, RW = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+    const float q_off = *q_off_p;
+    for (uint64_t base = (uint64_t)wave * RW; base < n_rows; base += (uint64_t)n_waves * RW) {
+        const uint64_t row = base + rslot;
+        const uint4 *p = codes + row * row_chunks;
+        uint32_t acc = 0;
+        for (uint32_t c = sub; c < row_chunks; c += G) {
+            uint4 v = ld_nt(p + c);
+            uint4 qv = qcodes[c];
+            acc = IS_L1 ? sad16(v, qv, acc) : dot16(v, qv, acc);
+        }
+        acc = group_sum<G>(acc);
+        if (sub == 0 && row < n_rows)
+            out[row] = epilogue(multiplier, acc, q_off, offsets[row], 0.0f, EPI_POINT);
+    }
+}
+
+// avx2.c lane-exact variant (any dim): lane k of the reference's 8 x i32 accumulator gets
+// byte pairs p with p % 8 == k of every 32-byte block (avx2.c:41-45) and bytes 2k,2k+1 of a
+// 16-byte tail (:49-58).  Within a 16-byte chunk c (two per block) dword j holds pairs
+// 2j, 2j+1 of that chunk, i.e. lanes (2j + 8*(c&1)... ) -> since a block has 16 pairs and
+// lane = pair % 8, both chunks of a block map dword j to lanes 2j and 2j+1.  So 8 integer
+// accumulators: acc[2j] += lo-half products of dword j, acc[2j+1] += hi-half products.
+// Each is converted to f32 and summed ((l0+l4)+(l2+l6))+((l1+l5)+(l3+l7)) (HSUM256_PS).
+template <bool DUMMY>
+__global__ __launch_bounds__(kBlock) void u8_scan_avx2_lanes_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets,
+    const uint4 *__restrict__ qcodes, const float *__restrict__ q_off_p, float multiplier,
+    uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out) {
+    constexpr int G = 16, RW = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+    const float q_off = *q_off_p;
+    for (uint64_t base = (uint64_t)wave * RW; base < n_rows; base += (uint64_t)n_waves * RW) {
+        const uint64_t row = base + rslot;
+        const uint4 *p = codes + row * row_chunks;
+        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t c = sub; c < row_chunks; c += G) {
+            uint4 v = ld_nt(p + c);
+            uint4 qv = qcodes[c];
+            const uint32_t vd[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t qd[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[2 * j] = __builtin_amdgcn_udot4(vd[j], qd[j] & 0x0000FFFFu, acc[2 * j], false);
+                acc[2 * j + 1] = __builtin_amdgcn_udot4(vd[j], qd[j] & 0xFFFF0000u, acc[2 * j + 1], false);
+            }
+        }
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] = (float)(int32_t)group_sum<G>(acc[k]);
+        float a0 = f[0] + f[4], a1 = f[1] + f[5], a2 = f[2] + f[6], a3 = f[3] + f[7];
+        float s = (a0 + a2) + (a1 + a3);
+        if (sub == 0 && row < n_rows) out[row] = (multiplier * s + q_off) + offsets[row];
+    }
+}
+
+// Random access: out[k] = score(q, ids[k]).  One 16-lane group per id.  qcodes/q_off_p may
+// point into the store itself (score_internal: "query" = row i).
+template <bool IS_L1>
+__global__ __launch_bounds__(kBlock) void u8_score_ids_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint4 *qcodes,
+    const float *q_off_p, float multiplier, float diff, int mode, const uint32_t *__restrict__ ids,
+    uint64_t n_ids, uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out) {
+    constexpr int G = 16, RW = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const float q_off = *q_off_p;
+    for (uint64_t base = wave * RW; base < n_ids; base += n_waves * RW) {
+        const uint64_t k = base + rslot;
+        const uint32_t row = k < n_ids ? ids[k] : 0xFFFFFFFFu;
+        const bool ok = row < n_rows;
+        uint32_t acc = 0;
+        if (ok) {
+            const uint4 *p = codes + (uint64_t)row * row_chunks;
+            for (uint32_t c = sub; c < row_chunks; c += G) {
+                uint4 v = p[c];
+                uint4 qv = qcodes[c];
+                acc = IS_L1 ? sad16(v, qv, acc) : dot16(v, qv, acc);
+            }
+        }
+        acc = group_sum<G>(acc);
+        if (sub == 0 && k < n_ids)
+            out[k] = ok ? epilogue(multiplier, acc, q_off, offsets[row], diff, mode)
+                        : __builtin_nanf("");
+    }
+}
+
+// ------------------------------------------------------------------------------ encode kernels
+// Pass 1: global min / max (quantile.rs:5-19).  `value < min` / `value > max` ignore NaN,
+// as fminf/fmaxf do.  Per-block partials; the host folds them.
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const float *__restrict__ data, uint64_t n,
+                                                       float *__restrict__ partial /* 2 per block */) {
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t n4 = ((reinterpret_cast<uintptr_t>(data) & 15) == 0) ? n / 4 : 0;
+    const float4 *d4 = reinterpret_cast<const float4 *>(data);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        float4 v = ld_nt(d4 + i);
+        mn = v.x < mn ? v.x : mn; mx = v.x > mx ? v.x : mx;
+        mn = v.y < mn ? v.y : mn; mx = v.y > mx ? v.y : mx;
+        mn = v.z < mn ? v.z : mn; mx = v.z > mx ? v.z : mx;
+        mn = v.w < mn ? v.w : mn; mx = v.w > mx ? v.w : mx;
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float v = data[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        float o = __shfl_xor(mn, m, 64);
+        mn = o < mn ? o : mn;
+        o = __shfl_xor(mx, m, 64);
+        mx = o > mx ? o : mx;
+    }
+    __shared__ float smn[kBlock / 64], smx[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) {
+        smn[threadIdx.x >> 6] = mn;
+        smx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) {
+            mn = smn[w] < mn ? smn[w] : mn;
+            mx = smx[w] > mx ? smx[w] : mx;
+        }
+        partial[2 * blockIdx.x] = mn;
+        partial[2 * blockIdx.x + 1] = mx;
+    }
+}
+
+// Pass 2: one wave per row (encoded_vectors_u8.rs:73-118).  Lane l quantizes elements
+// 4l..4l+3 of each 256-element slab into one dword of codes; the row's code sums are exact
+// integers.  vector_offset is the reference's sequential f32 sum: identical to the integer
+// sum while that is < 2^24; beyond it (only possible for sum of squares at actual_dim > 1040)
+// lane 0 replays the sequential f32 loop.
+__global__ __launch_bounds__(kBlock) void quantize_kernel(
+    const float *__restrict__ data, uint64_t n_rows, uint32_t dim, uint32_t actual_dim, float alpha,
+    float offset, int distance, int invert, uint32_t *__restrict__ codes32 /* row stride actual_dim/4 */,
+    float *__restrict__ offsets, uint64_t row0) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const float placeholder = (distance == QAMD_DOT) ? 0.0f : offset;
+    const uint32_t pad_code = f32_to_u8(placeholder, alpha, offset);
+    const uint32_t dwords = actual_dim / 4;
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const float *src = data + r * dim;
+        uint32_t *dst = codes32 + (row0 + r) * dwords;
+        uint32_t s1 = 0, s2 = 0;
+        const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15) == 0);
+        for (uint32_t d = lane; d < dwords; d += 64) {
+            uint32_t packed = 0;
+            if (vec4 && d * 4 < dim) {  // whole dword inside the row: one aligned 16-byte load
+                const float4 f = ld_nt(reinterpret_cast<const float4 *>(src) + d);
+                const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint32_t c = f32_to_u8(fv[b], alpha, offset);
+                    packed |= c << (8 * b);
+                    s1 += c;
+                    s2 += c * c;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint32_t j = d * 4 + b;
+                    uint32_t c = j < dim ? f32_to_u8(src[j], alpha, offset) : pad_code;
+                    packed |= c << (8 * b);
+                    s1 += c;
+                    s2 += c * c;
+                }
+            }
+            dst[d] = packed;
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+        }
+        if (lane == 0) {
+            float vo;
+            const float D = (float)actual_dim;
+            if (distance == QAMD_DOT) {
+                float s = (float)s1;  // 127*actual_dim < 2^24 for every dim < 132k
+                if (s1 >= (1u << 24)) {
+                    s = 0.0f;
+                    for (uint32_t j = 0; j < actual_dim; j++)
+                        s += (float)(j < dim ? f32_to_u8(src[j], alpha, offset) : pad_code);
+                }
+                vo = D * offset * offset + s * alpha * offset;
+            } else if (distance == QAMD_L1) {
+                vo = 0.0f;
+            } else {
+                float s = (float)s2;
+                if (s2 >= (1u << 24)) {
+                    s = 0.0f;
+                    for (uint32_t j = 0; j < actual_dim; j++) {
+                        float c = (float)(j < dim ? f32_to_u8(src[j], alpha, offset) : pad_code);
+                        s += c * c;
+                    }
+                }
+                vo = D * offset * offset + s * alpha * alpha;
+            }
+            offsets[row0 + r] = invert ? -vo : vo;
+        }
+    }
+}
+
+// encode_query on device (encoded_vectors_u8.rs:290-329): one wave.
+// qbuf: [0] offset f32, [16..] codes.
+__global__ __launch_bounds__(64) void encode_query_kernel(const float *__restrict__ query,
+                                                         uint32_t qdim, uint32_t actual_dim,
+                                                         float alpha, float offset, int distance,
+                                                         int invert, uint8_t *__restrict__ qbuf) {
+    const int lane = threadIdx.x;
+    const float placeholder = (distance == QAMD_DOT) ? 0.0f : offset;
+    const uint32_t pad_code = f32_to_u8(placeholder, alpha, offset);
+    uint8_t *codes = qbuf + 16;
+    uint32_t s1 = 0, s2 = 0;
+    for (uint32_t j = lane; j < actual_dim; j += 64) {
+        uint32_t c = j < qdim ? f32_to_u8(query[j], alpha, offset) : pad_code;
+        codes[j] = (uint8_t)c;
+        s1 += c;
+        s2 += c * c;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane == 0) {
+        float off;
+        if (distance == QAMD_DOT) {
+            float s = (float)s1;
+            if (s1 >= (1u << 24)) {
+                s = 0.0f;
+                for (uint32_t j = 0; j < actual_dim; j++)
+                    s += (float)(j < qdim ? f32_to_u8(query[j], alpha, offset) : pad_code);
+            }
+            off = s * alpha * offset;
+        } else if (distance == QAMD_L1) {
+            off = 0.0f;
+        } else {
+            float s = (float)s2;
+            if (s2 >= (1u << 24)) {
+                s = 0.0f;
+                for (uint32_t j = 0; j < actual_dim; j++) {
+                    float c = (float)(j < qdim ? f32_to_u8(query[j], alpha, offset) : pad_code);
+                    s += c * c;
+                }
+            }
+            off = s * alpha * alpha;
+        }
+        *reinterpret_cast<float *>(qbuf) = invert ? -off : off;
+    }
+}
+
+// Reference-format rows <-> device layout (encoded_storage.rs:27-31, row stride actual_dim+4).
+__global__ __launch_bounds__(kBlock) void split_rows_kernel(const uint32_t *__restrict__ rows32,
+                                                           uint64_t n_rows, uint32_t row_dwords,
+                                                           uint32_t *__restrict__ codes32,
+                                                           float *__restrict__ offsets) {
+    const uint64_t total = n_rows * row_dwords;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        uint64_t r = t / row_dwords;
+        uint32_t k = (uint32_t)(t - r * row_dwords);
+        uint32_t w = rows32[t];
+        if (k == 0)
+            offsets[r] = __uint_as_float(w);
+        else
+            codes32[r * (row_dwords - 1) + (k - 1)] = w;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void join_rows_kernel(const uint32_t *__restrict__ codes32,
+                                                          const float *__restrict__ offsets,
+                                                          uint64_t n_rows, uint32_t row_dwords,
+                                                          uint32_t *__restrict__ rows32) {
+    const uint64_t total = n_rows * row_dwords;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        uint64_t r = t / row_dwords;
+        uint32_t k = (uint32_t)(t - r * row_dwords);
+        rows32[t] = k == 0 ? __float_as_uint(offsets[r]) : codes32[r * (row_dwords - 1) + (k - 1)];
+    }
+}
+
+int grid_for(uint64_t work_items, uint64_t per_block, int blocks_per_cu) {
+    uint64_t want = (work_items + per_block - 1) / per_block;
+    uint64_t cap = (uint64_t)device_info().cu_count * blocks_per_cu;
+    if (want < 1) want = 1;
+    return (int)(want > cap ? cap : want);
+}
+
+// ------------------------------------------------------------------------------ host mirror
+// encoded_vectors_u8.rs:234-237 on the host (used by encode_query for host queries).
+inline uint8_t host_f32_to_u8(float v, float alpha, float offset) {
+    float x = (v - offset) / alpha;
+    if (x < 0.0f) x = 0.0f;
+    if (x > 127.0f) x = 127.0f;
+    if (x != x) return 0;
+    return (uint8_t)x;
+}
+
+float host_multiplier(float alpha, int distance, int invert) {  // :119-128
+    float m = distance == QAMD_DOT ? alpha * alpha : distance == QAMD_L1 ? alpha : -2.0f * alpha * alpha;
+    return invert ? -m : m;
+}
+
+uint64_t actual_dim_of(uint64_t dim) { return dim + (16 - dim % 16) % 16; }  // :257-259
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ handles
+struct qamd_u8 {
+    int device = 0;
+    qamd_u8_metadata meta{};
+    uint64_t count = 0;
+    uint64_t padded_rows = 0;
+    uint32_t row_chunks = 0;  // actual_dim / 16
+    int lane_mode = 0;        // 0: integer sum rounded once; 1: avx2.c lane order
+    DevBuf codes;             // [padded_rows][actual_dim]
+    DevBuf offsets;           // [padded_rows] f32
+};
+
+struct qamd_u8_query {
+    int device = 0;
+    uint64_t actual_dim = 0;
+    DevBuf buf;  // [0..4) offset f32, [16..16+actual_dim) codes
+};
+
+namespace {
+
+qamd_status alloc_store(qamd_u8 *h) {
+    h->padded_rows = round_up(h->count, kRowPad) + kRowPad;
+    h->row_chunks = (uint32_t)(h->meta.actual_dim / 16);
+    QAMD_TRY(h->codes.alloc(h->padded_rows * h->meta.actual_dim, true));
+    QAMD_TRY(h->offsets.alloc(h->padded_rows * sizeof(float), true));
+    return QAMD_OK;
+}
+
+template <bool IS_L1> struct ScanLaunch {
+    template <int G, int ITERS, int UNROLL>
+    static void go(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, hipStream_t s) {
+        constexpr int TILE = (64 / G) * UNROLL;
+        uint64_t waves = (h->count + TILE - 1) / TILE;
+        int grid = grid_for(waves, kBlock / 64, 8);
+        if (h->row_chunks == (uint32_t)(G * ITERS))
+            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, true>), dim3(grid), dim3(kBlock), 0,
+                               s, h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
+                               (uint32_t)h->count, h->row_chunks, out);
+        else
+            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, false>), dim3(grid), dim3(kBlock), 0,
+                               s, h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
+                               (uint32_t)h->count, h->row_chunks, out);
+    }
+};
+
+template <bool IS_L1>
+void launch_scan(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, hipStream_t s) {
+    using L = ScanLaunch<IS_L1>;
+    const uint32_t rc = h->row_chunks;
+    if (rc == 1) return L::template go<1, 1, 4>(h, qc, qo, out, s);
+    if (rc == 2) return L::template go<2, 1, 4>(h, qc, qo, out, s);
+    if (rc <= 4) return L::template go<4, 1, 8>(h, qc, qo, out, s);
+    if (rc <= 8) return L::template go<8, 1, 8>(h, qc, qo, out, s);
+    switch ((rc + 15) / 16) {
+        case 1: return L::template go<16, 1, 8>(h, qc, qo, out, s);
+        case 2: return L::template go<16, 2, 4>(h, qc, qo, out, s);
+        case 3: return L::template go<16, 3, 4>(h, qc, qo, out, s);
+        case 4: return L::template go<16, 4, 2>(h, qc, qo, out, s);
+        case 5: return L::template go<16, 5, 2>(h, qc, qo, out, s);
+        case 6: return L::template go<16, 6, 2>(h, qc, qo, out, s);
+        case 7: return L::template go<16, 7, 2>(h, qc, qo, out, s);
+        case 8: return L::template go<16, 8, 2>(h, qc, qo, out, s);
+        default: break;
+    }
+    uint64_t waves = (h->count + 3) / 4;
+    int grid = grid_for(waves, kBlock / 64, 8);
+    hipLaunchKernelGGL((u8_scan_generic_kernel<IS_L1>), dim3(grid), dim3(kBlock), 0, s,
+                       h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
+                       (uint32_t)h->count, rc, out);
+}
+
+qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, hipStream_t s) {
+    if (h->count == 0) return QAMD_OK;
+    const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
+    const float *qo = q->buf.as<float>();
+    const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+    if (!is_l1 && h->lane_mode == 1) {
+        uint64_t waves = (h->count + 3) / 4;
+        int grid = grid_for(waves, kBlock / 64, 8);
+        hipLaunchKernelGGL((u8_scan_avx2_lanes_kernel<true>), dim3(grid), dim3(kBlock), 0, s,
+                           h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
+                           (uint32_t)h->count, h->row_chunks, out_dev);
+    } else if (is_l1) {
+        launch_scan<true>(h, qc, qo, out_dev, s);
+    } else {
+        launch_scan<false>(h, qc, qo, out_dev, s);
+    }
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+qamd_status check_query(const qamd_u8 *h, const qamd_u8_query *q) {
+    if (!h || !q) return fail(QAMD_ERR_ARGUMENTS, "null handle or query");
+    if (q->actual_dim != h->meta.actual_dim)
+        return fail(QAMD_ERR_ARGUMENTS, "query has %llu codes, store rows have %llu",
+                    (unsigned long long)q->actual_dim, (unsigned long long)h->meta.actual_dim);
+    return QAMD_OK;
+}
+
+qamd_status score_ids_dev(const qamd_u8 *h, const uint4 *qc, const float *qo, float diff, int mode,
+                          const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t s) {
+    if (n_ids == 0) return QAMD_OK;
+    int grid = grid_for((n_ids + 3) / 4, kBlock / 64, 8);
+    if (h->meta.vector_parameters.distance_type == QAMD_L1)
+        hipLaunchKernelGGL((u8_score_ids_kernel<true>), dim3(grid), dim3(kBlock), 0, s,
+                           h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier, diff,
+                           mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
+    else
+        hipLaunchKernelGGL((u8_score_ids_kernel<false>), dim3(grid), dim3(kBlock), 0, s,
+                           h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier, diff,
+                           mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+// find_quantile_interval (quantile.rs:21-71) on the host over a bounded sample.
+bool quantile_interval(std::vector<float> &sample, uint64_t slice_size, float quantile, float &mn,
+                       float &mx) {
+    const uint64_t len = sample.size();
+    if (len < 4) return false;
+    uint64_t cut = std::min<uint64_t>((len - 1) / 2, (uint64_t)((float)slice_size * (1.0f - quantile) / 2.0f));
+    cut = std::max<uint64_t>(cut, 1);
+    auto cmp = [](float a, float b) { return a < b; };
+    std::nth_element(sample.begin(), sample.begin() + (len - cut), sample.end(), cmp);
+    // left part [0, len-cut); second selection at `cut` keeps (cut, len-cut)
+    std::nth_element(sample.begin(), sample.begin() + cut, sample.begin() + (len - cut), cmp);
+    const uint64_t lo = cut + 1, hi = len - cut;
+    if (hi <= lo || hi - lo < 2) return false;
+    mn = 3.40282347e+38f;
+    mx = -3.40282347e+38f;
+    for (uint64_t i = lo; i < hi; i++) {
+        float v = sample[i];
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+    return true;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" {
+
+uint64_t qamd_u8_actual_dim(const qamd_vector_parameters *vp) { return actual_dim_of(vp->dim); }
+
+uint64_t qamd_u8_quantized_vector_size(const qamd_vector_parameters *vp) {
+    return actual_dim_of(vp->dim) + sizeof(float);
+}
+
+qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                           const float *quantile, const float *alpha_offset, qamd_stop_fn stop,
+                           void *stop_user, void *stream, qamd_u8 **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (vp->distance_type < 0 || vp->distance_type > 2)
+        return fail(QAMD_ERR_ARGUMENTS, "bad distance_type %d", vp->distance_type);
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
+    QAMD_TRY(ensure_device(current_device()));
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<qamd_u8> h(new qamd_u8);
+    h->device = current_device();
+    h->count = vp->count;
+    h->meta.actual_dim = actual_dim_of(vp->dim);
+    h->meta.vector_parameters = *vp;
+    QAMD_TRY(alloc_store(h.get()));
+    if (vp->count == 0) {  // encoded_vectors_u8.rs:43-54
+        h->meta.alpha = h->meta.offset = h->meta.multiplier = 0.0f;
+        *out = h.release();
+        return QAMD_OK;
+    }
+    const uint64_t dim = vp->dim, count = vp->count;
+    const uint64_t total = count * dim;
+
+    // Source rows: device-resident as they are, host rows staged in bounded batches.
+    const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, (256ull << 20) / (dim * 4 + 1)));
+    DevBuf stage;
+    if (data_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(batch_rows * dim * sizeof(float)));
+
+    float alpha, offset;
+    if (alpha_offset) {
+        alpha = alpha_offset[0];
+        offset = alpha_offset[1];
+    } else {
+        // PASS 1 (:57): global min/max.
+        const int mm_grid = device_info().cu_count * 4;
+        DevBuf partial;
+        QAMD_TRY(partial.alloc((size_t)mm_grid * 2 * sizeof(float)));
+        std::vector<float> hp((size_t)mm_grid * 2);
+        float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+        for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
+            if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
+            const uint64_t nr = std::min(batch_rows, count - r0);
+            const float *src = data + r0 * dim;
+            if (data_mem == QAMD_MEM_HOST) {
+                QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
+                src = stage.as<float>();
+            }
+            hipLaunchKernelGGL(minmax_kernel, dim3(mm_grid), dim3(kBlock), 0, s, src, nr * dim,
+                               partial.as<float>());
+            QAMD_HIP(hipGetLastError());
+            QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, hp.size() * 4, s));
+            for (int b = 0; b < mm_grid; b++) {
+                if (hp[2 * b] < mn) mn = hp[2 * b];
+                if (hp[2 * b + 1] > mx) mx = hp[2 * b + 1];
+            }
+        }
+        alpha = (mx - mn) / 127.0f;  // :228-232
+        offset = mn;
+        // PASS 1b (:58-71): quantile interval on <= 100 000 sampled vectors.
+        if (quantile && !(count < 127 || *quantile >= 1.0f)) {
+            const uint64_t slice = std::min<uint64_t>(count, kQuantileSample);
+            std::vector<float> sample(slice * dim);
+            // count <= 100 000: every vector (exactly the reference).  Larger stores: an
+            // evenly strided subset (the reference draws a random one; statistic, not bits).
+            std::vector<float> rowbuf;
+            for (uint64_t k = 0; k < slice; k++) {
+                const uint64_t r = slice == count ? k : (uint64_t)((unsigned __int128)k * count / slice);
+                if (data_mem == QAMD_MEM_HOST)
+                    memcpy(&sample[k * dim], data + r * dim, dim * 4);
+                else
+                    QAMD_HIP(hipMemcpyAsync(&sample[k * dim], data + r * dim, dim * 4, hipMemcpyDeviceToHost, s));
+            }
+            if (data_mem == QAMD_MEM_DEVICE) QAMD_HIP(hipStreamSynchronize(s));
+            float qmn, qmx;
+            if (quantile_interval(sample, slice, *quantile, qmn, qmx)) {
+                alpha = (qmx - qmn) / 127.0f;
+                offset = qmn;
+            }
+        }
+    }
+    (void)total;
+
+    // PASS 2 (:73-118): quantize rows, stop_condition polled between batches.
+    for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
+        if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
+        const uint64_t nr = std::min(batch_rows, count - r0);
+        const float *src = data + r0 * dim;
+        if (data_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
+            src = stage.as<float>();
+        }
+        int grid = grid_for(nr, kBlock / 64, 8);
+        hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
+                           (uint32_t)h->meta.actual_dim, alpha, offset, vp->distance_type, vp->invert,
+                           h->codes.as<uint32_t>(), h->offsets.as<float>(), r0);
+        QAMD_HIP(hipGetLastError());
+        if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
+    }
+    QAMD_HIP(hipStreamSynchronize(s));
+    h->meta.alpha = alpha;
+    h->meta.offset = offset;
+    h->meta.multiplier = host_multiplier(alpha, vp->distance_type, vp->invert);
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_u8_metadata *meta,
+                              void *stream, qamd_u8 **out) {
+    if (!meta || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    const qamd_vector_parameters &vp = meta->vector_parameters;
+    if (meta->actual_dim != actual_dim_of(vp.dim))
+        return fail(QAMD_ERR_ARGUMENTS, "metadata actual_dim %llu does not match dim %llu",
+                    (unsigned long long)meta->actual_dim, (unsigned long long)vp.dim);
+    if (vp.count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    if (vp.count > 0 && !rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
+    QAMD_TRY(ensure_device(current_device()));
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<qamd_u8> h(new qamd_u8);
+    h->device = current_device();
+    h->count = vp.count;
+    h->meta = *meta;
+    QAMD_TRY(alloc_store(h.get()));
+    const uint64_t stride = meta->actual_dim + 4;
+    const uint32_t row_dwords = (uint32_t)(stride / 4);
+    const uint64_t batch_rows = std::max<uint64_t>(1, (256ull << 20) / stride);
+    DevBuf stage;
+    if (rows_mem == QAMD_MEM_HOST && vp.count)
+        QAMD_TRY(stage.alloc(std::min<uint64_t>(batch_rows, vp.count) * stride));
+    for (uint64_t r0 = 0; r0 < vp.count; r0 += batch_rows) {
+        const uint64_t nr = std::min(batch_rows, vp.count - r0);
+        const uint8_t *src = rows + r0 * stride;
+        if (rows_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * stride, s));
+            src = stage.as<uint8_t>();
+        }
+        int grid = grid_for(nr * row_dwords, kBlock * 4, 8);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(kBlock), 0, s,
+                           reinterpret_cast<const uint32_t *>(src), nr, row_dwords,
+                           h->codes.as<uint32_t>() + r0 * (row_dwords - 1), h->offsets.as<float>() + r0);
+        QAMD_HIP(hipGetLastError());
+        if (rows_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
+    }
+    QAMD_HIP(hipStreamSynchronize(s));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_export_rows(const qamd_u8 *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (h->count == 0) return QAMD_OK;
+    if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    const uint64_t stride = h->meta.actual_dim + 4;
+    const uint32_t row_dwords = (uint32_t)(stride / 4);
+    const uint64_t batch_rows = std::max<uint64_t>(1, (256ull << 20) / stride);
+    DevBuf stage;
+    if (rows_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(std::min<uint64_t>(batch_rows, h->count) * stride));
+    for (uint64_t r0 = 0; r0 < h->count; r0 += batch_rows) {
+        const uint64_t nr = std::min(batch_rows, h->count - r0);
+        uint8_t *dst = rows_mem == QAMD_MEM_HOST ? stage.as<uint8_t>() : rows + r0 * stride;
+        int grid = grid_for(nr * row_dwords, kBlock * 4, 8);
+        hipLaunchKernelGGL(join_rows_kernel, dim3(grid), dim3(kBlock), 0, s,
+                           h->codes.as<uint32_t>() + r0 * (row_dwords - 1), h->offsets.as<float>() + r0, nr,
+                           row_dwords, reinterpret_cast<uint32_t *>(dst));
+        QAMD_HIP(hipGetLastError());
+        if (rows_mem == QAMD_MEM_HOST)
+            QAMD_TRY(copy_out(rows + r0 * stride, QAMD_MEM_HOST, dst, nr * stride, s));
+    }
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_get_metadata(const qamd_u8 *h, qamd_u8_metadata *out) {
+    if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    *out = h->meta;
+    return QAMD_OK;
+}
+
+// save (:263-271): serde_json metadata in struct field order, then the raw row file.
+qamd_status qamd_u8_save(const qamd_u8 *h, const char *data_path, const char *meta_path) {
+    if (!h || !data_path || !meta_path) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::string js = "{\"actual_dim\":" + std::to_string(h->meta.actual_dim) +
+                     ",\"alpha\":" + json_f32(h->meta.alpha) + ",\"offset\":" + json_f32(h->meta.offset) +
+                     ",\"multiplier\":" + json_f32(h->meta.multiplier) +
+                     ",\"vector_parameters\":" + vector_parameters_json(h->meta.vector_parameters) + "}";
+    make_parent_dirs(meta_path);
+    if (!write_file(meta_path, js.data(), js.size()))
+        return fail(QAMD_ERR_IO, "cannot write %s", meta_path);
+    const uint64_t stride = h->meta.actual_dim + 4;
+    std::vector<uint8_t> rows(h->count * stride);
+    QAMD_TRY(qamd_u8_export_rows(h, rows.data(), QAMD_MEM_HOST, nullptr));
+    make_parent_dirs(data_path);
+    if (!write_file(data_path, rows.data(), rows.size()))
+        return fail(QAMD_ERR_IO, "cannot write %s", data_path);
+    return QAMD_OK;
+}
+
+// load (:273-288): metadata from JSON; row size/count from the CALLER's vector_parameters;
+// the file length must equal size*count (encoded_storage.rs:40-51).
+qamd_status qamd_u8_load(const char *data_path, const char *meta_path, const qamd_vector_parameters *vp,
+                         qamd_u8 **out) {
+    if (!data_path || !meta_path || !vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::string js;
+    if (!read_file(meta_path, js)) return fail(QAMD_ERR_IO, "cannot read %s", meta_path);
+    qamd_u8_metadata meta{};
+    double ad, a, o, m;
+    if (!json_find_number(js, "actual_dim", ad) || !json_find_number(js, "alpha", a) ||
+        !json_find_number(js, "offset", o) || !json_find_number(js, "multiplier", m) ||
+        !parse_vector_parameters(js, meta.vector_parameters))
+        return fail(QAMD_ERR_IO, "malformed metadata in %s", meta_path);
+    meta.actual_dim = (uint64_t)ad;
+    meta.alpha = (float)a;
+    meta.offset = (float)o;
+    meta.multiplier = (float)m;
+    {  // re-parse the f32 fields straight from their decimal text (no double rounding)
+        auto f32_of = [&](const char *key, float &dst) {
+            std::string k = std::string("\"") + key + "\":";
+            size_t p = js.find(k);
+            if (p != std::string::npos && js.compare(p + k.size(), 4, "null") != 0)
+                dst = strtof(js.c_str() + p + k.size(), nullptr);
+        };
+        f32_of("alpha", meta.alpha);
+        f32_of("offset", meta.offset);
+        f32_of("multiplier", meta.multiplier);
+    }
+    const uint64_t size = qamd_u8_quantized_vector_size(vp);
+    std::string bytes;
+    if (!read_file(data_path, bytes)) return fail(QAMD_ERR_IO, "cannot read %s", data_path);
+    const uint64_t expected = size * vp->count;
+    if (bytes.size() != expected)
+        return fail(QAMD_ERR_IO, "Loaded storage size %zu is not equal to expected size %llu", bytes.size(),
+                    (unsigned long long)expected);
+    // The reference keeps the file's metadata but sizes rows from the caller's parameters.
+    qamd_u8_metadata eff = meta;
+    eff.vector_parameters.dim = vp->dim;
+    eff.vector_parameters.count = vp->count;
+    eff.actual_dim = actual_dim_of(vp->dim);
+    qamd_status st = qamd_u8_from_rows(reinterpret_cast<const uint8_t *>(bytes.data()), QAMD_MEM_HOST, &eff,
+                                       nullptr, out);
+    if (st == QAMD_OK) (*out)->meta = meta.actual_dim == eff.actual_dim ? meta : eff;
+    return st;
+}
+
+qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t qdim, qamd_mem query_mem,
+                                 void *stream, qamd_u8_query **query_io) {
+    if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    const uint64_t ad = actual_dim_of(qdim);
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    qamd_u8_query *q = *query_io;
+    std::unique_ptr<qamd_u8_query> fresh;
+    if (!q) {
+        fresh.reset(new qamd_u8_query);
+        q = fresh.get();
+        q->device = h->device;
+    }
+    if (q->actual_dim != ad || !q->buf.ptr) {
+        QAMD_TRY(q->buf.alloc(16 + ad + 16, true));
+        q->actual_dim = ad;
+    }
+    const qamd_vector_parameters &vp = h->meta.vector_parameters;
+    if (query_mem == QAMD_MEM_DEVICE) {
+        hipLaunchKernelGGL(encode_query_kernel, dim3(1), dim3(64), 0, s, query, (uint32_t)qdim, (uint32_t)ad,
+                           h->meta.alpha, h->meta.offset, vp.distance_type, vp.invert, q->buf.as<uint8_t>());
+        QAMD_HIP(hipGetLastError());
+    } else {
+        // Host mirror of :290-329, then one small upload.
+        std::vector<uint8_t> img(16 + ad, 0);
+        uint8_t *codes = img.data() + 16;
+        const float alpha = h->meta.alpha, offset = h->meta.offset;
+        for (uint64_t j = 0; j < qdim; j++) codes[j] = host_f32_to_u8(query[j], alpha, offset);
+        if (qdim % 16 != 0) {
+            const float placeholder = vp.distance_type == QAMD_DOT ? 0.0f : offset;
+            const uint8_t pc = host_f32_to_u8(placeholder, alpha, offset);
+            for (uint64_t j = qdim; j < ad; j++) codes[j] = pc;
+        }
+        float off;
+        if (vp.distance_type == QAMD_DOT) {
+            float sum = 0.0f;
+            for (uint64_t j = 0; j < ad; j++) sum += (float)codes[j];
+            off = sum * alpha * offset;
+        } else if (vp.distance_type == QAMD_L1) {
+            off = 0.0f;
+        } else {
+            float sum = 0.0f;
+            for (uint64_t j = 0; j < ad; j++) sum += (float)codes[j] * (float)codes[j];
+            off = sum * alpha * alpha;
+        }
+        if (vp.invert) off = -off;
+        memcpy(img.data(), &off, 4);
+        QAMD_TRY(copy_in(q->buf.ptr, img.data(), QAMD_MEM_HOST, img.size(), s));
+    }
+    if (fresh) *query_io = fresh.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_query_read(const qamd_u8_query *q, float *offset, uint8_t *codes, uint64_t capacity,
+                               uint64_t *codes_len) {
+    if (!q) return fail(QAMD_ERR_ARGUMENTS, "null query");
+    QAMD_TRY(ensure_device(q->device));
+    if (codes_len) *codes_len = q->actual_dim;
+    if (offset) QAMD_TRY(copy_out(offset, QAMD_MEM_HOST, q->buf.ptr, 4, nullptr));
+    if (codes) {
+        if (capacity < q->actual_dim) return fail(QAMD_ERR_ARGUMENTS, "codes buffer too small");
+        QAMD_TRY(copy_out(codes, QAMD_MEM_HOST, q->buf.as<uint8_t>() + 16, q->actual_dim, nullptr));
+    }
+    return QAMD_OK;
+}
+
+void qamd_u8_query_free(qamd_u8_query *q) { delete q; }
+
+qamd_status qamd_u8_score_all(const qamd_u8 *h, const qamd_u8_query *q, float *out, qamd_mem out_mem,
+                              void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (h->count == 0) return QAMD_OK;
+    if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    if (out_mem == QAMD_MEM_DEVICE) return scan_into(h, q, out, s);
+    DevBuf tmp;
+    QAMD_TRY(tmp.alloc(h->count * sizeof(float)));
+    QAMD_TRY(scan_into(h, q, tmp.as<float>(), s));
+    return copy_out(out, QAMD_MEM_HOST, tmp.ptr, h->count * sizeof(float), s);
+}
+
+qamd_status qamd_u8_score_ids(const qamd_u8 *h, const qamd_u8_query *q, const uint32_t *ids, uint64_t n_ids,
+                              qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (n_ids == 0) return QAMD_OK;
+    if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    DevBuf ids_tmp, out_tmp;
+    const uint32_t *ids_dev = ids;
+    if (ids_mem == QAMD_MEM_HOST) {
+        for (uint64_t k = 0; k < n_ids; k++)
+            if (ids[k] >= h->count)  // the reference panics here (encoded_storage.rs:29)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+        QAMD_TRY(ids_tmp.alloc(n_ids * 4));
+        QAMD_TRY(copy_in(ids_tmp.ptr, ids, QAMD_MEM_HOST, n_ids * 4, s));
+        ids_dev = ids_tmp.as<uint32_t>();
+    }
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(out_tmp.alloc(n_ids * 4));
+        out_dev = out_tmp.as<float>();
+    }
+    const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
+    QAMD_TRY(score_ids_dev(h, qc, q->buf.as<float>(), 0.0f, EPI_POINT, ids_dev, n_ids, out_dev, s));
+    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, n_ids * 4, s));
+    else if (ids_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_score_point(const qamd_u8 *h, const qamd_u8_query *q, uint32_t i, float *out) {
+    return qamd_u8_score_ids(h, q, &i, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
+}
+
+qamd_status qamd_u8_score_internal(const qamd_u8 *h, uint32_t i, uint32_t j, float *out) {
+    if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (i >= h->count || j >= h->count)
+        return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
+    QAMD_TRY(ensure_device(h->device));
+    // :389-395  diff = actual_dim*offset*offset (negated if invert)
+    float diff = (float)h->meta.actual_dim * h->meta.offset * h->meta.offset;
+    if (h->meta.vector_parameters.invert) diff = -diff;
+    DevBuf tmp;
+    QAMD_TRY(tmp.alloc(16));
+    QAMD_TRY(copy_in(tmp.ptr, &j, QAMD_MEM_HOST, 4, nullptr));
+    const uint4 *qc = h->codes.as<uint4>() + (uint64_t)i * h->row_chunks;
+    const float *qo = h->offsets.as<float>() + i;
+    QAMD_TRY(score_ids_dev(h, qc, qo, diff, EPI_INTERNAL, tmp.as<uint32_t>(), 1, tmp.as<float>() + 1, nullptr));
+    return copy_out(out, QAMD_MEM_HOST, tmp.as<float>() + 1, 4, nullptr);
+}
+
+qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, int largest, uint32_t *out_ids,
+                         float *out_scores, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_query(h, q));
+    if (k == 0) return QAMD_OK;
+    if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    float *scores = nullptr;
+    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+    qamd_status st = scan_into(h, q, scores, s);
+    if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
+    (void)hipFreeAsync(scores, s);
+    return st;
+}
+
+void qamd_u8_free(qamd_u8 *h) { delete h; }
+
+uint64_t qamd_u8_scan_bytes_per_row(const qamd_u8 *h) { return h ? h->meta.actual_dim + 4 : 0; }
+
+// Selects how sums above 2^24 are rounded (0: once, 1: avx2.c lane order).  Not part of the
+// reference surface; see the header of this file.
+qamd_status qamd_u8_set_lane_mode(qamd_u8 *h, int mode) {
+    if (!h || mode < 0 || mode > 1) return fail(QAMD_ERR_ARGUMENTS, "bad lane mode");
+    h->lane_mode = mode;
+    return QAMD_OK;
+}
+
+}  // extern "C"

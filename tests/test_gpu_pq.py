@@ -1,0 +1,136 @@
+"""HIP PQ path vs the oracle: codes, LUT and scores bit-exact GIVEN centroids (the reference's
+k-means is randomised: centroid values are parity-unpinned); the reference's
+tolerance spec (quantization/tests/test_pq.rs) is re-run on trained centroids."""
+import numpy as np
+import pytest
+
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+qa = pytest.importorskip("quantization_amd")
+D = qa.DistanceType
+
+CASES = [(513, 65, 1), (300, 64, 2), (1000, 768, 8), (200, 100, 7), (64, 16, 16), (150, 1024, 2), (90, 33, 4)]
+
+
+def _data(n, dim, seed=42):
+    rng = np.random.default_rng(seed)
+    return rng.random((n, dim), dtype=np.float32), rng.random(dim, dtype=np.float32), \
+        rng.random((256, dim), dtype=np.float32)
+
+
+@pytest.mark.parametrize("n,dim,chunk", CASES)
+@pytest.mark.parametrize("dist", [D.Dot, D.L1, D.L2])
+@pytest.mark.parametrize("invert", [False, True])
+def test_pq_bit_exact_given_centroids(qo, n, dim, chunk, dist, invert):
+    data, query, cen = _data(n, dim)
+    vp = qa.VectorParameters(dim, n, dist, invert)
+    enc = qa.EncodedVectorsPQ.encode(data, vp, chunk, centroids=cen)
+    assert qa.EncodedVectorsPQ.get_quantized_vector_size(vp, chunk) == qo.pq_chunks(dim, chunk)
+    rows = qo.pq_encode(data, chunk, cen)
+    assert np.array_equal(enc.storage_bytes(), rows), "PQ codes differ"
+    q = enc.encode_query(query)
+    lut = qo.pq_encode_query(query, chunk, cen, int(dist), invert)
+    assert_bits_equal(q.lut, lut, "LUT")
+    want = qo.pq_score_all(rows, lut, order=qo.ORDER_SSE)
+    assert_bits_equal(enc.score_all(q), want, "score_all (score_point_sse order)")
+    for i in (0, n // 2, n - 1):
+        assert_bits_equal([enc.score_point(q, i)], [want[i]], "score_point")
+        j = (i * 5 + 1) % n
+        assert_bits_equal([enc.score_internal(i, j)],
+                          [qo.pq_score_internal(rows, dim, chunk, cen, int(dist), invert, i, j)], "score_internal")
+    ids = np.array([n - 1, 3, 3, 0], dtype=np.uint32)
+    assert_bits_equal(enc.score_ids(q, ids), want[ids], "score_ids")
+
+
+def test_pq_large_scan_uses_lds_lut(qo):
+    """n >= 4096 takes the LDS-resident-LUT kernel (96 KiB at m = 96)."""
+    n, dim, chunk = 20000, 768, 8
+    data, query, cen = _data(n, dim, seed=7)
+    enc = qa.EncodedVectorsPQ.encode(data, qa.VectorParameters(dim, n, D.Dot, False), chunk, centroids=cen)
+    rows = qo.pq_encode(data, chunk, cen)
+    assert np.array_equal(enc.storage_bytes(), rows)
+    lut = qo.pq_encode_query(query, chunk, cen, qo.DOT, False)
+    assert_bits_equal(enc.score_all(enc.encode_query(query)), qo.pq_score_all(rows, lut, order=qo.ORDER_SSE), "LDS LUT scan")
+
+
+def test_pq_small_count_centroids_are_the_vectors(qo):
+    """encoded_vectors_pq.rs:290-297: count <= 256."""
+    n, dim, chunk = 100, 40, 4
+    data, query, _ = _data(n, dim, seed=3)
+    enc = qa.EncodedVectorsPQ.encode(data, qa.VectorParameters(dim, n, D.L2, False), chunk)
+    cen = qo.pq_centroids_small(data)
+    assert np.array_equal(enc.centroids, cen)
+    rows = qo.pq_encode(data, chunk, cen)
+    assert np.array_equal(enc.storage_bytes(), rows)
+    # every vector is its own nearest centroid: distance-to-self scores 0 under L2
+    for i in (0, 50, 99):
+        assert enc.score_internal(i, i) == 0.0
+
+
+@pytest.mark.parametrize("dist", [D.Dot, D.L1, D.L2])
+@pytest.mark.parametrize("invert", [False, True])
+def test_pq_reference_tolerance_spec_with_trained_centroids(qo, dist, invert):
+    """quantization/tests/test_pq.rs:16-50: 513 x 65, chunk 1, |score - metric| < dim*0.05."""
+    n, dim = 513, 65
+    data, query, _ = _data(n, dim)
+    enc = qa.EncodedVectorsPQ.encode(data, qa.VectorParameters(dim, n, dist, invert), 1, max_kmeans_threads=1)
+    q = enc.encode_query(query)
+    scores = enc.score_all(q)
+    for i in range(n):
+        orig = qo.metric_f32(int(dist), query, data[i])
+        orig = -orig if invert else orig
+        assert abs(scores[i] - orig) < dim * 0.05
+    # and the whole pipeline is self-consistent with the oracle GIVEN those centroids
+    cen = enc.centroids
+    rows = qo.pq_encode(data, 1, cen)
+    assert np.array_equal(enc.storage_bytes(), rows)
+    lut = qo.pq_encode_query(query, 1, cen, int(dist), invert)
+    assert_bits_equal(scores, qo.pq_score_all(rows, lut, order=qo.ORDER_SSE), "scores given trained centroids")
+    for i in range(0, n - 1, 64):
+        orig = qo.metric_f32(int(dist), data[i], data[i + 1])
+        orig = -orig if invert else orig
+        assert abs(enc.score_internal(i, i + 1) - orig) < dim * 0.05
+
+
+def test_pq_kmeans_reduces_distortion():
+    """k-means (kmeans.rs) quality: trained centroids beat the first-256-rows initialisation."""
+    rng = np.random.default_rng(0)
+    n, dim, chunk = 4000, 32, 4
+    centers = rng.standard_normal((64, dim)).astype(np.float32) * 3
+    data = (centers[rng.integers(0, 64, n)] + rng.standard_normal((n, dim)).astype(np.float32) * 0.3).astype(np.float32)
+    vp = qa.VectorParameters(dim, n, D.L2, False)
+    trained = qa.EncodedVectorsPQ.encode(data, vp, chunk)
+    naive = qa.EncodedVectorsPQ.encode(data, vp, chunk, centroids=np.concatenate([data[:256]]))
+
+    def distortion(enc):
+        cen, codes = enc.centroids, enc.storage_bytes()
+        rec = np.concatenate([cen[codes[:, c], c * chunk:(c + 1) * chunk] for c in range(dim // chunk)], axis=1)
+        return float(((rec - data) ** 2).sum(axis=1).mean())
+
+    assert distortion(trained) < distortion(naive) * 0.9
+
+
+def test_pq_save_load_empty_and_stop(qo, tmp_path):
+    import json
+    n, dim, chunk = 300, 24, 5
+    data, query, cen = _data(n, dim, seed=8)
+    vp = qa.VectorParameters(dim, n, D.Dot, True)
+    enc = qa.EncodedVectorsPQ.encode(data, vp, chunk, centroids=cen)
+    enc.save(tmp_path / "p.bin", tmp_path / "p.json")
+    js = json.load(open(tmp_path / "p.json"))
+    assert list(js.keys()) == ["centroids", "vector_division", "vector_parameters"]
+    assert js["vector_division"][-1] == {"start": 20, "end": 24} and len(js["vector_division"]) == 5
+    assert np.array_equal(np.array(js["centroids"], dtype=np.float32), cen)
+    back = qa.EncodedVectorsPQ.load(tmp_path / "p.bin", tmp_path / "p.json", vp)
+    assert_bits_equal(back.score_all(back.encode_query(query)), enc.score_all(enc.encode_query(query)), "reload")
+    # empty storage (quantization/tests/empty_storage.rs)
+    vp0 = qa.VectorParameters(dim, 0, D.Dot, False)
+    e0 = qa.EncodedVectorsPQ.encode(np.zeros((0, dim), np.float32), vp0, chunk)
+    e0.save(tmp_path / "e.bin", tmp_path / "e.json")
+    b0 = qa.EncodedVectorsPQ.load(tmp_path / "e.bin", tmp_path / "e.json", vp0)
+    assert b0.score_all(b0.encode_query(query)).size == 0
+    with pytest.raises(qa.EncodingError) as e:
+        qa.EncodedVectorsPQ.encode(data, vp, chunk, centroids=cen, stop_condition=lambda: True)
+    assert e.value.stopped
