@@ -229,7 +229,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("rows_per_launch") == n and j.get("dim") == dim:
+                if j.get("rows_per_launch") == n and j.get("algorithmic_read_bytes_per_launch") == n * bytes_per_row:
                     roofline["traffic"] = j.get("traffic_bytes_per_launch")
                     roofline["traffic_source"] = "profiles/r01_pmc_u8_scan.json (rocprofv3 --pmc, FETCH_SIZE x2 per guide)"
             except Exception:

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/prof/...) into the small summaries kept under
+profiles/.  Kernel names are shortened (torch's are kilobytes long).
+
+    python profiles/summarize.py stats <kernel_stats.csv> <out.csv>
+    python profiles/summarize.py pmc   <fetch_counter_collection.csv> <write_counter_collection.csv> \
+                                       <kernel-substring> <rows_per_launch> <row_read_bytes> <out.json>
+
+PMC correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so
+read bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE * 1024 is taken as is.
+"""
+import csv
+import json
+import sys
+
+
+def short(name: str, n: int = 110) -> str:
+    name = name.replace("(anonymous namespace)::", "")
+    return name if len(name) <= n else name[:n] + "..."
+
+
+def stats(src, dst):
+    rows = list(csv.DictReader(open(src)))
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+
+def pmc(fetch_csv, write_csv, needle, rows_per_launch, row_read_bytes, dst):
+    def collect(path, counter):
+        vals, durs = [], []
+        for r in csv.DictReader(open(path)):
+            if needle in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+                durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        return vals, durs
+
+    fv, fd = collect(fetch_csv, "FETCH_SIZE")
+    wv, _ = collect(write_csv, "WRITE_SIZE")
+    fetch_kib = sum(fv) / len(fv)
+    write_kib = sum(wv) / len(wv)
+    read_bytes = fetch_kib * 1024 * 2
+    write_bytes = write_kib * 1024
+    out = {
+        "kernel": needle, "rows_per_launch": rows_per_launch, "launches_sampled": len(fv),
+        "FETCH_SIZE_KiB_mean": fetch_kib, "WRITE_SIZE_KiB_mean": write_kib,
+        "read_bytes_per_launch": read_bytes,
+        "read_bytes_note": "FETCH_SIZE*1024*2 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream)",
+        "write_bytes_per_launch": write_bytes,
+        "traffic_bytes_per_launch": read_bytes + write_bytes,
+        "algorithmic_read_bytes_per_launch": rows_per_launch * row_read_bytes,
+        "algorithmic_write_bytes_per_launch": rows_per_launch * 4,
+        "traffic_over_algorithmic": (read_bytes + write_bytes) / (rows_per_launch * (row_read_bytes + 4)),
+        "mean_kernel_ns_in_fetch_pass": sum(fd) / len(fd),
+    }
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
