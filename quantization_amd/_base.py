@@ -19,7 +19,10 @@ class EncodedQueryBase:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            getattr(_lib.lib(), f"qamd_{self._prefix}_query_free")(self._h)
+            try:
+                getattr(_lib.lib(), f"qamd_{self._prefix}_query_free")(self._h)
+            except Exception:  # interpreter shutdown: module globals already torn down
+                pass
             self._h = None
 
 
@@ -88,5 +91,8 @@ class EncodedVectorsBase:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            self._fn("free")(self._h)
+            try:
+                self._fn("free")(self._h)
+            except Exception:  # interpreter shutdown
+                pass
             self._h = None

@@ -27,6 +27,7 @@ using namespace qamd;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kScanBlock = 512;
 constexpr uint64_t kRowPad = 1024;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -57,51 +58,51 @@ __device__ __forceinline__ float metric(uint32_t x, float dim_f, int is_dot, int
     return zx ? zeros_count - xor_product : xor_product - zeros_count;
 }
 
-// Rows of ds >= 16 bytes (row_chunks = ds/16).
+// Rows of ds >= 16 bytes (row_chunks = ds/16).  One wave per tile of (64/G)*UNROLL rows,
+// non-persistent grid (same reasoning and measurements as u8_scan_kernel in u8.hip).
 template <int G, int ITERS, int UNROLL, bool EXACT>
-__global__ __launch_bounds__(kBlock) void bin_scan_kernel(const uint4 *__restrict__ rows,
-                                                         const uint4 *__restrict__ qbits, float dim_f,
-                                                         int is_dot, int invert, uint32_t n_rows,
-                                                         uint32_t row_chunks, float *__restrict__ out) {
+__global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__restrict__ rows,
+                                                             const uint4 *__restrict__ qbits, float dim_f,
+                                                             int is_dot, int invert, uint32_t n_rows,
+                                                             uint32_t row_chunks, float *__restrict__ out) {
     constexpr int RW = 64 / G;
     constexpr int TILE = RW * UNROLL;
     const int lane = threadIdx.x & 63;
     const int sub = lane % G, rslot = lane / G;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kScanBlock + threadIdx.x) >> 6;
+    const uint64_t base = wave * TILE;
+    if (base >= n_rows) return;
     uint4 q[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         uint32_t c = sub + it * G;
         q[it] = c < row_chunks ? qbits[c] : make_uint4(0, 0, 0, 0);
     }
-    for (uint64_t base = (uint64_t)wave * TILE; base < n_rows; base += (uint64_t)n_waves * TILE) {
-        uint4 v[UNROLL][ITERS];
+    uint4 v[UNROLL][ITERS];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            const uint64_t row = base + u * RW + rslot;
-            const uint4 *p = rows + row * row_chunks;
+    for (int u = 0; u < UNROLL; u++) {
+        const uint64_t row = base + u * RW + rslot;
+        const uint4 *p = rows + row * row_chunks;
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) {
-                const uint32_t c = sub + it * G;
-                if (EXACT) {
-                    v[u][it] = ld_nt(p + c);
-                } else {  // masked lane: read the row's last chunk, xor against itself -> 0 bits
-                    const bool in = c < row_chunks;
-                    uint4 t = ld_nt(p + (in ? c : row_chunks - 1));
-                    v[u][it] = in ? t : q[it];
-                }
+        for (int it = 0; it < ITERS; it++) {
+            const uint32_t c = sub + it * G;
+            if (EXACT) {
+                v[u][it] = ld_nt(p + c);
+            } else {  // masked lane: read the row's last chunk, then xor against itself -> 0 bits
+                const bool in = c < row_chunks;
+                uint4 t = ld_nt(p + (in ? c : row_chunks - 1));
+                v[u][it] = in ? t : q[it];
             }
         }
+    }
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            uint32_t acc = 0;
+    for (int u = 0; u < UNROLL; u++) {
+        uint32_t acc = 0;
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) acc = xpop16(v[u][it], q[it], acc);
-            acc = group_sum<G>(acc);
-            const uint64_t row = base + u * RW + rslot;
-            if (sub == 0 && row < n_rows) out[row] = metric(acc, dim_f, is_dot, invert);
-        }
+        for (int it = 0; it < ITERS; it++) acc = xpop16(v[u][it], q[it], acc);
+        acc = group_sum<G>(acc);
+        const uint64_t row = base + u * RW + rslot;
+        if (sub == 0 && row < n_rows) out[row] = metric(acc, dim_f, is_dot, invert);
     }
 }
 
@@ -208,13 +209,14 @@ void launch_bin(const qamd_bin *h, const uint4 *qb, float *out, hipStream_t s) {
     constexpr int TILE = (64 / G) * UNROLL;
     const uint32_t rc = (uint32_t)(h->ds / 16);
     const int is_dot = h->vp.distance_type == QAMD_DOT;
-    int grid = grid_for((h->count + TILE - 1) / TILE, kBlock / 64, 8);
+    const uint64_t waves = (h->count + TILE - 1) / TILE;
+    const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
     if (rc == (uint32_t)(G * ITERS))
-        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, true>), dim3(grid), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, true>), dim3(grid), dim3(kScanBlock), 0, s,
                            h->rows.as<uint4>(), qb, (float)h->vp.dim, is_dot, h->vp.invert, (uint32_t)h->count,
                            rc, out);
     else
-        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, false>), dim3(grid), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, false>), dim3(grid), dim3(kScanBlock), 0, s,
                            h->rows.as<uint4>(), qb, (float)h->vp.dim, is_dot, h->vp.invert, (uint32_t)h->count,
                            rc, out);
 }

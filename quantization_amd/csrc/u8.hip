@@ -38,6 +38,7 @@ using namespace qamd;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kScanBlock = 512;  // scan workgroup (tuning sweep: 512 and 1024 tie, 256 is ~1% behind)
 constexpr uint64_t kRowPad = 1024;  // rows are padded so that every wave tile is in bounds
 constexpr uint64_t kQuantileSample = 100000;  // QUANTILE_SAMPLE_SIZE, quantile.rs:3
 
@@ -97,11 +98,15 @@ __device__ __forceinline__ uint32_t f32_to_u8(float v, float alpha, float offset
 }
 
 // ------------------------------------------------------------------------------ scan kernel
-// One wave iteration covers (64/G)*UNROLL consecutive rows.  ITERS = ceil(row_chunks / G).
+// One wave covers ONE tile of (64/G)*UNROLL consecutive rows and exits; the grid is one wave
+// per tile.  Measured on MI355X (10M x 768, tools/tune_u8.py): this non-persistent form
+// streams at 6.5-6.7 TB/s, a persistent grid-stride loop over the same body at 5.9-6.4 —
+// workgroups are dispatched in order, so the resident waves always cover one compact, moving
+// window of the store.  ITERS = ceil(row_chunks / G).
 // EXACT: row_chunks == G*ITERS, so no lane is ever past the row end.  Otherwise loads stay
 // unconditional (clamped address + select) so that they still issue back to back.
 template <int G, int ITERS, int UNROLL, bool IS_L1, bool EXACT>
-__global__ __launch_bounds__(kBlock) void u8_scan_kernel(
+__global__ __launch_bounds__(kScanBlock) void u8_scan_kernel(
     const uint4 *__restrict__ codes, const float *__restrict__ offsets,
     const uint4 *__restrict__ qcodes, const float *__restrict__ q_off_p, float multiplier,
     uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out) {
@@ -110,9 +115,28 @@ __global__ __launch_bounds__(kBlock) void u8_scan_kernel(
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
     const int rslot = lane / G;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kScanBlock + threadIdx.x) >> 6;
+    const uint64_t base = wave * TILE;
+    if (base >= n_rows) return;
 
+    uint4 v[UNROLL][ITERS];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        const uint64_t row = base + u * RW + rslot;
+        const uint4 *p = codes + row * row_chunks;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint32_t c = sub + it * G;
+            if (EXACT) {
+                v[u][it] = ld_nt(p + c);
+            } else {
+                const uint32_t cc = c < row_chunks ? c : row_chunks - 1;
+                uint4 t = ld_nt(p + cc);
+                const bool in = c < row_chunks;
+                v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+            }
+        }
+    }
     uint4 q[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
@@ -120,37 +144,16 @@ __global__ __launch_bounds__(kBlock) void u8_scan_kernel(
         q[it] = c < row_chunks ? qcodes[c] : make_uint4(0, 0, 0, 0);
     }
     const float q_off = *q_off_p;
-
-    for (uint64_t base = (uint64_t)wave * TILE; base < n_rows; base += (uint64_t)n_waves * TILE) {
-        uint4 v[UNROLL][ITERS];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            const uint64_t row = base + u * RW + rslot;
-            const uint4 *p = codes + row * row_chunks;
+    for (int u = 0; u < UNROLL; u++) {
+        uint32_t acc = 0;
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) {
-                const uint32_t c = sub + it * G;
-                if (EXACT) {
-                    v[u][it] = ld_nt(p + c);
-                } else {
-                    const uint32_t cc = c < row_chunks ? c : row_chunks - 1;
-                    uint4 t = ld_nt(p + cc);
-                    const bool in = c < row_chunks;
-                    v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int it = 0; it < ITERS; it++)
-                acc = IS_L1 ? sad16(v[u][it], q[it], acc) : dot16(v[u][it], q[it], acc);
-            acc = group_sum<G>(acc);
-            const uint64_t row = base + u * RW + rslot;
-            if (sub == 0 && row < n_rows)
-                out[row] = epilogue(multiplier, acc, q_off, offsets[row], 0.0f, EPI_POINT);
-        }
+        for (int it = 0; it < ITERS; it++)
+            acc = IS_L1 ? sad16(v[u][it], q[it], acc) : dot16(v[u][it], q[it], acc);
+        acc = group_sum<G>(acc);
+        const uint64_t row = base + u * RW + rslot;
+        if (sub == 0 && row < n_rows)
+            out[row] = epilogue(multiplier, acc, q_off, offsets[row], 0.0f, EPI_POINT);
     }
 }
 
@@ -516,14 +519,14 @@ template <bool IS_L1> struct ScanLaunch {
     template <int G, int ITERS, int UNROLL>
     static void go(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, hipStream_t s) {
         constexpr int TILE = (64 / G) * UNROLL;
-        uint64_t waves = (h->count + TILE - 1) / TILE;
-        int grid = grid_for(waves, kBlock / 64, 8);
+        const uint64_t waves = (h->count + TILE - 1) / TILE;  // one wave per tile
+        const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
         if (h->row_chunks == (uint32_t)(G * ITERS))
-            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, true>), dim3(grid), dim3(kBlock), 0,
+            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, true>), dim3(grid), dim3(kScanBlock), 0,
                                s, h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
                                (uint32_t)h->count, h->row_chunks, out);
         else
-            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, false>), dim3(grid), dim3(kBlock), 0,
+            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, false>), dim3(grid), dim3(kScanBlock), 0,
                                s, h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
                                (uint32_t)h->count, h->row_chunks, out);
     }
@@ -548,8 +551,8 @@ void launch_scan(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out,
         case 8: return L::template go<16, 8, 2>(h, qc, qo, out, s);
         default: break;
     }
-    uint64_t waves = (h->count + 3) / 4;
-    int grid = grid_for(waves, kBlock / 64, 8);
+    uint64_t waves = (h->count + 3) / 4;  // one wave per 4-row tile (non-persistent, see u8_scan_kernel)
+    unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
     hipLaunchKernelGGL((u8_scan_generic_kernel<IS_L1>), dim3(grid), dim3(kBlock), 0, s,
                        h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
                        (uint32_t)h->count, rc, out);
@@ -562,7 +565,7 @@ qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, 
     const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
     if (!is_l1 && h->lane_mode == 1) {
         uint64_t waves = (h->count + 3) / 4;
-        int grid = grid_for(waves, kBlock / 64, 8);
+        unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
         hipLaunchKernelGGL((u8_scan_avx2_lanes_kernel<true>), dim3(grid), dim3(kBlock), 0, s,
                            h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
                            (uint32_t)h->count, h->row_chunks, out_dev);
@@ -1038,3 +1041,13 @@ qamd_status qamd_u8_set_lane_mode(qamd_u8 *h, int mode) {
 }
 
 }  // extern "C"
+
+// Developer-only accessors for the tuning harness (tune.hip); not part of include/.
+extern "C" __attribute__((visibility("default"))) void qamd_dev_u8_ptrs(const qamd_u8 *h, const void **codes,
+                                                                        const void **offsets) {
+    *codes = h->codes.ptr;
+    *offsets = h->offsets.ptr;
+}
+extern "C" __attribute__((visibility("default"))) const void *qamd_dev_u8_query_ptr(const qamd_u8_query *q) {
+    return q->buf.ptr;
+}
