@@ -96,8 +96,8 @@ QAMD_API uint64_t qamd_u8_actual_dim(const qamd_vector_parameters *vp);
 
 /* EncodedVectorsU8::encode (:34-140).  data: count*dim f32, row-major (the reference's
  * `orig_data` iterator flattened).  quantile: NULL = None.  For count > 100 000 the
- * reference draws a random sample (quantile.rs:31-34); here the sample is the first
- * 100 000 rows of a fixed-seed permutation — same statistic, not the same bits.
+ * reference draws a random sample (quantile.rs:31-34); here the sample is 100 000 evenly
+ * strided rows — same statistic, not the same bits.
  * `alpha_offset` non-NULL overrides the interval search with {alpha, offset}
  * (conditional parity for that sampled case). */
 QAMD_API qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem,
