@@ -95,14 +95,19 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__res
             }
         }
     }
+    float mine = 0.0f;  // lane (rslot, sub = u % G) keeps row u's score: one coalesced nt store per G rows-groups
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
         uint32_t acc = 0;
 #pragma unroll
         for (int it = 0; it < ITERS; it++) acc = xpop16(v[u][it], q[it], acc);
         acc = group_sum<G>(acc);
-        const uint64_t row = base + u * RW + rslot;
-        if (sub == 0 && row < n_rows) out[row] = metric(acc, dim_f, is_dot, invert);
+        if (sub == (u % G)) mine = metric(acc, dim_f, is_dot, invert);
+        if ((u % G) == G - 1 || u == UNROLL - 1) {
+            const int first = (u / G) * G;
+            const uint64_t row = base + (uint64_t)(first + sub) * RW + rslot;
+            if (sub <= u - first && row < n_rows) __builtin_nontemporal_store(mine, out + row);
+        }
     }
 }
 
@@ -241,7 +246,7 @@ qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev
     if (rc == 1) launch_bin<1, 1, 4>(h, qb, out_dev, s);
     else if (rc == 2) launch_bin<2, 1, 4>(h, qb, out_dev, s);
     else if (rc <= 4) launch_bin<4, 1, 8>(h, qb, out_dev, s);
-    else if (rc <= 8) launch_bin<8, 1, 8>(h, qb, out_dev, s);
+    else if (rc <= 8) launch_bin<8, 1, 16>(h, qb, out_dev, s);
     else if (rc <= 16) launch_bin<16, 1, 8>(h, qb, out_dev, s);
     else if (rc <= 32) launch_bin<16, 2, 4>(h, qb, out_dev, s);
     else if (rc <= 48) launch_bin<16, 3, 4>(h, qb, out_dev, s);
@@ -510,3 +515,9 @@ qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k
 void qamd_bin_free(qamd_bin *h) { delete h; }
 
 }  // extern "C"
+
+// Developer-only accessors for the tuning harness (tune.hip); not part of include/.
+extern "C" __attribute__((visibility("default"))) const void *qamd_dev_bin_rows(const qamd_bin *h) { return h->rows.ptr; }
+extern "C" __attribute__((visibility("default"))) const void *qamd_dev_bin_query_ptr(const qamd_bin_query *q) {
+    return q->buf.ptr;
+}

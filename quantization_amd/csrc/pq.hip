@@ -112,6 +112,85 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_kernel(const uint32_t *__r
     }
 }
 
+// Fast path for the whole-store scan: m % 16 == 0 (rows are NV = m/16 aligned 16-byte pieces,
+// NV <= 8) and the LUT fits in LDS.  Differences to pq_scan_kernel, all measured to matter
+// (the first version was latency-bound at one 16-byte load in flight per lane):
+//  * the four lanes of a row load DIFFERENT pieces (lane k: pieces k, k+4) and hand the
+//    dwords round with DPP quad broadcasts, so a wave-load fetches 1 KiB of distinct bytes
+//    instead of 256 B read four times;
+//  * UNROLL row tiles are loaded before the first gather (UNROLL*ceil(NV/4) loads in flight
+//    per lane) and their gather/add chains interleave (UNROLL independent f32 chains).
+// Summation order per row is unchanged: lane k adds chunks k, k+4, ... in order.
+template <int J> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J | (J << 2) | (J << 4) | (J << 6), 0xF, 0xF, true);
+}
+template <int J> __device__ __forceinline__ uint4 quad_bcast4(const uint4 &v) {
+    return make_uint4(quad_bcast<J>(v.x), quad_bcast<J>(v.y), quad_bcast<J>(v.z), quad_bcast<J>(v.w));
+}
+
+template <int NV, int UNROLL>
+__global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *__restrict__ rows4,
+                                                                 const float *__restrict__ lut_g,
+                                                                 uint32_t n_rows, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];
+    {
+        constexpr uint32_t total4 = NV * 16 * (kCentroids / 4);
+        const float4 *src = reinterpret_cast<const float4 *>(lut_g);
+        float4 *dst = reinterpret_cast<float4 *>(lut_s);
+        for (uint32_t i = threadIdx.x; i < total4; i += kScanBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    constexpr int JN = (NV + 3) / 4;
+    constexpr int TILE = 16 * UNROLL;
+    const int lane = threadIdx.x & 63;
+    const int k = lane & 3, rslot = lane >> 2;
+    const uint64_t wave = (uint64_t)blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kScanBlock / 64);
+    const float *lut_k = lut_s + k * kCentroids;
+    const uint32_t shift = 8 * k;
+    for (uint64_t base = wave * TILE; base < n_rows; base += n_waves * TILE) {
+        uint4 mine[UNROLL][JN];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint4 *p = rows4 + (base + u * 16 + rslot) * NV;  // rows are zero-padded past n_rows
+#pragma unroll
+            for (int j = 0; j < JN; j++) {
+                const int piece = k + 4 * j;
+                mine[u][j] = ld_nt(p + (piece < NV ? piece : NV - 1));
+            }
+        }
+        float acc[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc[u] = 0.0f;
+#pragma unroll
+        for (int pc = 0; pc < NV; pc++) {
+            const float *l = lut_k + pc * 16 * kCentroids;  // piece pc = chunk groups 4pc .. 4pc+3
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint4 &held = mine[u][pc / 4];
+                uint4 w;
+                switch (pc & 3) {
+                    case 0: w = quad_bcast4<0>(held); break;
+                    case 1: w = quad_bcast4<1>(held); break;
+                    case 2: w = quad_bcast4<2>(held); break;
+                    default: w = quad_bcast4<3>(held); break;
+                }
+                acc[u] += l[(w.x >> shift) & 255u];
+                acc[u] += l[4 * kCentroids + ((w.y >> shift) & 255u)];
+                acc[u] += l[8 * kCentroids + ((w.z >> shift) & 255u)];
+                acc[u] += l[12 * kCentroids + ((w.w >> shift) & 255u)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const float a = acc[u] + __shfl_xor(acc[u], 2, 64);  // (l0 + l2) + (l1 + l3)  (:430-432)
+            const float s = a + __shfl_xor(a, 1, 64);
+            const uint64_t row = base + u * 16 + rslot;
+            if (k == 0 && row < n_rows) out[row] = s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ encode
 // encode_vector (:237-265): a thread owns one (row, chunk) and walks the 256 centroids in
 // index order with the reference's strict '<', so ties and NaNs resolve identically.  The
@@ -153,6 +232,58 @@ __global__ __launch_bounds__(kBlock) void pq_encode_kernel(const float *__restri
             }
         }
         rows[(row0 + r) * row_stride + c] = (uint8_t)min_i;
+    }
+}
+
+// Compile-time chunk size (dim % CS == 0): the sub-vector lives in registers, the inner loops
+// unroll fully and two centroids are evaluated per step (independent sum chains, compared in
+// index order with the same strict '<').  Identical arithmetic to pq_encode_kernel.
+template <int CS>
+__global__ __launch_bounds__(kBlock) void pq_encode_cs_kernel(const float *__restrict__ data, uint64_t n_rows,
+                                                             uint32_t dim, uint32_t m,
+                                                             const float *__restrict__ centroids,
+                                                             uint8_t *__restrict__ rows, uint32_t row_stride,
+                                                             uint64_t row0, uint32_t chunks_per_slice) {
+    __shared__ __attribute__((aligned(16))) float cen_s[kCentroids * CS];
+    const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = r < n_rows;
+    const float *src = data + (active ? r : 0) * dim;
+    const uint32_t c_begin = blockIdx.y * chunks_per_slice;
+    const uint32_t c_end = min(m, c_begin + chunks_per_slice);
+    for (uint32_t c = c_begin; c < c_end; c++) {
+        const uint32_t lo = c * CS;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kCentroids * CS; i += kBlock) {
+            const uint32_t kc = i / CS, j = i % CS;
+            cen_s[i] = centroids[(size_t)kc * dim + lo + j];
+        }
+        __syncthreads();
+        float a[CS];
+#pragma unroll
+        for (int j = 0; j < CS; j++) a[j] = src[lo + j];
+        float min_d = 3.40282347e+38f;
+        uint32_t min_i = 0;
+#pragma unroll 4
+        for (uint32_t kc = 0; kc < (uint32_t)kCentroids; kc += 2) {
+            const float *c0 = cen_s + kc * CS, *c1 = c0 + CS;
+            float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CS; j++) {
+                const float t0 = a[j] - c0[j];
+                const float t1 = a[j] - c1[j];
+                d0 += t0 * t0;
+                d1 += t1 * t1;
+            }
+            if (d0 < min_d) {
+                min_d = d0;
+                min_i = kc;
+            }
+            if (d1 < min_d) {
+                min_d = d1;
+                min_i = kc + 1;
+            }
+        }
+        if (active) rows[(row0 + r) * row_stride + c] = (uint8_t)min_i;
     }
 }
 
@@ -331,7 +462,26 @@ qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *
 #define QAMD_PQ_LAUNCH(LDSF, V16, GRID, SH)                                                                 \
     hipLaunchKernelGGL((pq_scan_kernel<LDSF, V16>), dim3(GRID), dim3(kScanBlock), SH, s, h->rows.as<uint32_t>(), \
                        lut_dev, ids_dev, n, (uint32_t)h->count, m, row_words, out_dev)
-    if (in_lds) {
+    if (in_lds && !ids_dev && m % 16 == 0 && m / 16 <= 8 && n == h->count) {
+        const int grid = (int)std::min<uint64_t>(cu, (n + 1023) / 1024);
+        const uint4 *rows4 = h->rows.as<uint4>();
+#define QAMD_PQ_FAST(NVV)                                                                                   \
+    case NVV: {                                                                                             \
+        static std::once_flag f;                                                                            \
+        std::call_once(f, [] {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
+        });                                                                                                 \
+        hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4>), dim3(grid), dim3(kScanBlock), lds, s, rows4, lut_dev, \
+                           (uint32_t)n, out_dev);                                                           \
+        break;                                                                                              \
+    }
+        switch (m / 16) {
+            QAMD_PQ_FAST(1) QAMD_PQ_FAST(2) QAMD_PQ_FAST(3) QAMD_PQ_FAST(4)
+            QAMD_PQ_FAST(5) QAMD_PQ_FAST(6) QAMD_PQ_FAST(7) QAMD_PQ_FAST(8)
+        }
+#undef QAMD_PQ_FAST
+    } else if (in_lds) {
         static std::once_flag once;  // opt in to > 64 KiB dynamic LDS once per kernel
         std::call_once(once, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, true>),
@@ -388,9 +538,23 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
         if (gx < want) slices = std::min<uint32_t>((uint32_t)h->m, (want + gx - 1) / gx);
         const uint32_t per = (uint32_t)((h->m + slices - 1) / slices);
         slices = (uint32_t)((h->m + per - 1) / per);
-        hipLaunchKernelGGL(pq_encode_kernel, dim3(gx, slices), dim3(kBlock), lds, s, src, nr, (uint32_t)dim,
-                           (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(), h->rows.as<uint8_t>(),
-                           (uint32_t)h->ds, r0, per);
+#define QAMD_PQ_ENC(CSV)                                                                                     \
+    case CSV:                                                                                               \
+        hipLaunchKernelGGL((pq_encode_cs_kernel<CSV>), dim3(gx, slices), dim3(kBlock), 0, s, src, nr, (uint32_t)dim, \
+                           (uint32_t)h->m, h->centroids.as<float>(), h->rows.as<uint8_t>(), (uint32_t)h->ds, r0, per); \
+        break;
+        bool fast = dim % h->chunk_size == 0;
+        if (fast) {
+            switch (h->chunk_size) {
+                QAMD_PQ_ENC(1) QAMD_PQ_ENC(2) QAMD_PQ_ENC(4) QAMD_PQ_ENC(8) QAMD_PQ_ENC(16) QAMD_PQ_ENC(32)
+                default: fast = false;
+            }
+        }
+#undef QAMD_PQ_ENC
+        if (!fast)
+            hipLaunchKernelGGL(pq_encode_kernel, dim3(gx, slices), dim3(kBlock), lds, s, src, nr, (uint32_t)dim,
+                               (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
+                               h->rows.as<uint8_t>(), (uint32_t)h->ds, r0, per);
         QAMD_HIP(hipGetLastError());
         if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
     }

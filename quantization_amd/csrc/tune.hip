@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t dot16(const uint4 &a, const uint4 &b, uint32
 
 // G = 16, ITERS = 3 (dim 768).  tiles_per_wave == 0: persistent grid-stride; else each wave
 // owns `tiles_per_wave` consecutive tiles.
-template <int UNROLL, bool NT, int BLOCK, int MINW>
+template <int UNROLL, bool NT, int BLOCK, int MINW, int NTS = 0>
 __global__ __launch_bounds__(BLOCK, MINW) void tune_scan(const uint4 *__restrict__ codes,
                                                         const float *__restrict__ offsets,
                                                         const uint4 *__restrict__ qcodes,
@@ -63,6 +63,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void tune_scan(const uint4 *__restrict
 #pragma unroll
             for (int it = 0; it < ITERS; it++) v[u][it] = ld<NT>(p + it * G);
         }
+        float mine = 0.0f;
+        const float my_off = (NTS >= 2 && sub < UNROLL) ? offsets[base + sub * RW + rslot] : 0.0f;
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             uint32_t acc = 0;
@@ -71,8 +73,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void tune_scan(const uint4 *__restrict
 #pragma unroll
             for (int m = 1; m < G; m <<= 1) acc += __shfl_xor(acc, m, 64);
             const uint64_t row = base + u * RW + rslot;
-            if (sub == 0 && row < n_rows)
-                out[row] = (multiplier * (float)(int32_t)acc + q_off) + offsets[row];
+            if (NTS < 2) {
+                if (sub == 0 && row < n_rows) {
+                    const float r = (multiplier * (float)(int32_t)acc + q_off) + offsets[row];
+                    if (NTS == 1) __builtin_nontemporal_store(r, out + row);
+                    else out[row] = r;
+                }
+            } else if (sub == u) {
+                mine = (multiplier * (float)(int32_t)acc + q_off) + my_off;
+            }
+        }
+        if (NTS >= 2 && sub < UNROLL) {  // one store instruction: RW*UNROLL consecutive rows
+            const uint64_t row = base + sub * RW + rslot;
+            if (row < n_rows) {
+                if (NTS == 3) __builtin_nontemporal_store(mine, out + row);
+                else out[row] = mine;
+            }
         }
     }
 }
@@ -108,31 +124,33 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_u8_sweep(
                                              multiplier, n_rows, (uint32_t)TPW, out_dev);                 \
                       }, {}});                                                                            \
     } while (0)
-    // round 2 of the sweep: non-persistent grids around the round-1 winner (tpw 1)
-    ADD(4, true, 256, 1, 1, 0);
-    ADD(4, true, 256, 1, 2, 0);
-    ADD(2, true, 256, 1, 1, 0);
-    ADD(2, true, 256, 1, 2, 0);
-    ADD(8, true, 256, 1, 1, 0);
-    ADD(8, true, 256, 1, 2, 0);
-    ADD(4, true, 64, 1, 1, 0);
-    ADD(4, true, 128, 1, 1, 0);
-    ADD(4, true, 512, 1, 1, 0);
-    ADD(4, true, 1024, 1, 1, 0);
-    ADD(8, true, 512, 1, 1, 0);
-    ADD(8, true, 1024, 1, 1, 0);
-    ADD(2, true, 1024, 1, 1, 0);
-    ADD(4, true, 256, 2, 1, 0);
-    ADD(8, true, 256, 2, 1, 0);
-    ADD(4, true, 1024, 1, 0, 2);
-    ADD(8, true, 1024, 1, 0, 2);
-    ADD(4, true, 1024, 1, 0, 1);
-    ADD(8, true, 1024, 1, 0, 1);
-    ADD(4, true, 256, 1, 0, 2);
-    ADD(4, true, 256, 1, 0, 3);
-    ADD(8, true, 256, 1, 0, 2);
-    ADD(8, true, 256, 1, 0, 3);
+#define ADDS(UN, NT, BL, MW, TPW, BPC, SM)                                                                     \
+    do {                                                                                                  \
+        constexpr int TILE = 4 * UN;                                                                      \
+        uint64_t waves_needed = ((uint64_t)n_rows + TILE - 1) / TILE;                                     \
+        int grid;                                                                                         \
+        if (TPW == 0) grid = cu * BPC;                                                                    \
+        else grid = (int)((waves_needed + (uint64_t)TPW * (BL / 64) - 1) / ((uint64_t)TPW * (BL / 64)));  \
+        char nm[128];                                                                                     \
+        snprintf(nm, sizeof nm, "store%d unroll%d nt%d block%d minw%d tpw%d bpc%d grid%d", SM, UN, NT, BL, MW, TPW, BPC, grid); \
+        vs.push_back({nm, [=](hipStream_t s) {                                                            \
+                          hipLaunchKernelGGL((tune_scan<UN, NT, BL, MW, SM>), dim3(grid), dim3(BL), 0, s, c, o, qc, qo, \
+                                             multiplier, n_rows, (uint32_t)TPW, out_dev);                 \
+                      }, {}});                                                                            \
+    } while (0)
+    // round 4: score-store shape, A/B interleaved.  store0 per-u plain, 2 transposed plain, 3 transposed nt
+    ADDS(4, true, 512, 1, 1, 0, 0);
+    ADDS(4, true, 512, 1, 1, 0, 2);
+    ADDS(4, true, 512, 1, 1, 0, 3);
+    ADDS(8, true, 512, 1, 1, 0, 0);
+    ADDS(8, true, 512, 1, 1, 0, 2);
+    ADDS(8, true, 512, 1, 1, 0, 3);
+    ADDS(16, true, 512, 1, 1, 0, 2);
+    ADDS(16, true, 512, 1, 1, 0, 3);
+    ADDS(2, true, 1024, 1, 1, 0, 0);
+    ADDS(2, true, 1024, 1, 1, 0, 2);
 #undef ADD
+#undef ADDS
     hipEvent_t e0, e1;
     QAMD_HIP(hipEventCreate(&e0));
     QAMD_HIP(hipEventCreate(&e1));
@@ -155,6 +173,111 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_u8_sweep(
         char line[256];
         snprintf(line, sizeof line, "%-58s median %.4f ms  min %.4f ms  %.0f GB/s\n", v.name.c_str(), med, mn,
                  (double)n_rows * 772.0 / (med * 1e-3) / 1e9);
+        rep += line;
+    }
+    snprintf(report, cap, "%s", rep.c_str());
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return QAMD_OK;
+}
+
+// ---------------------------------------------------------------- binary scan sweep (dim 1024)
+namespace {
+template <int UNROLL, int BLOCK, int STORE_MODE>
+__global__ __launch_bounds__(BLOCK) void tune_bin(const uint4 *__restrict__ rows, const uint4 *__restrict__ qbits,
+                                                 float dim_f, uint32_t n_rows, float *__restrict__ out) {
+    constexpr int G = 8, RW = 8, TILE = RW * UNROLL;
+    const int lane = threadIdx.x & 63, sub = lane % G, rslot = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint64_t base = wave * TILE;
+    if (base >= n_rows) return;
+    const uint4 q = qbits[sub];
+    uint4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + (base + u * RW + rslot) * 8 + sub));
+        v[u] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+    float mine = 0.0f;
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        uint32_t acc = __popc(v[u].x ^ q.x) + __popc(v[u].y ^ q.y) + __popc(v[u].z ^ q.z) + __popc(v[u].w ^ q.w);
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) acc += __shfl_xor(acc, m, 64);
+        const float x = (float)acc;
+        const float s = (dim_f - x) - x;
+        if (STORE_MODE == 0) {
+            const uint64_t row = base + u * RW + rslot;
+            if (sub == 0 && row < n_rows) out[row] = s;
+        } else if (STORE_MODE == 1) {
+            if (sub == (u & 7)) mine = s;
+            if ((u & 7) == 7) {  // 64 consecutive rows in one wave-store
+                const uint64_t row = base + (u - 7 + sub) * RW + rslot;
+                if (row < n_rows) out[row] = mine;
+            }
+        } else {
+            if (sub == (u & 7)) mine = s;
+            if ((u & 7) == 7) {
+                const uint64_t row = base + (u - 7 + sub) * RW + rslot;
+                if (row < n_rows) __builtin_nontemporal_store(mine, out + row);
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_bin_sweep(const void *rows, const void *qbits,
+                                                                                float dim_f, uint32_t n_rows,
+                                                                                float *out_dev, int rounds,
+                                                                                char *report, size_t cap) {
+    QAMD_TRY(ensure_device(current_device()));
+    const uint4 *r = static_cast<const uint4 *>(rows);
+    const uint4 *q = static_cast<const uint4 *>(qbits);
+    std::vector<Variant> vs;
+#define ADDB(UN, BL, SM)                                                                                   \
+    do {                                                                                                   \
+        uint64_t waves = ((uint64_t)n_rows + 8 * UN - 1) / (8 * UN);                                       \
+        unsigned grid = (unsigned)((waves + BL / 64 - 1) / (BL / 64));                                     \
+        char nm[128];                                                                                      \
+        snprintf(nm, sizeof nm, "bin unroll%d block%d store%d grid%u", UN, BL, SM, grid);                  \
+        vs.push_back({nm, [=](hipStream_t s) {                                                             \
+                          hipLaunchKernelGGL((tune_bin<UN, BL, SM>), dim3(grid), dim3(BL), 0, s, r, q, dim_f, n_rows, out_dev); \
+                      }, {}});                                                                             \
+    } while (0)
+    ADDB(8, 512, 0);
+    ADDB(8, 512, 1);
+    ADDB(8, 512, 2);
+    ADDB(8, 256, 1);
+    ADDB(8, 1024, 1);
+    ADDB(16, 512, 0);
+    ADDB(16, 512, 1);
+    ADDB(16, 512, 2);
+    ADDB(16, 256, 1);
+    ADDB(16, 1024, 1);
+    ADDB(32, 512, 1);
+    ADDB(32, 256, 1);
+#undef ADDB
+    hipEvent_t e0, e1;
+    QAMD_HIP(hipEventCreate(&e0));
+    QAMD_HIP(hipEventCreate(&e1));
+    for (int rd = 0; rd < rounds; rd++)
+        for (auto &v : vs) {
+            v.launch(nullptr);
+            QAMD_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < 5; i++) v.launch(nullptr);
+            QAMD_HIP(hipEventRecord(e1, nullptr));
+            QAMD_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            QAMD_HIP(hipEventElapsedTime(&ms, e0, e1));
+            v.ms.push_back(ms / 5);
+        }
+    std::string rep;
+    for (auto &v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const float med = v.ms[v.ms.size() / 2];
+        char line[256];
+        snprintf(line, sizeof line, "%-44s median %.4f ms  min %.4f ms  %.0f GB/s read (+4 B/row written)\n",
+                 v.name.c_str(), med, v.ms.front(), (double)n_rows * 128.0 / (med * 1e-3) / 1e9);
         rep += line;
     }
     snprintf(report, cap, "%s", rep.c_str());
