@@ -1,0 +1,163 @@
+"""BASELINE.json's full sizes on one MI355X, checked through size-independent properties
+(exact integer linearity and checksums, complement symmetry, kernel-vs-kernel agreement) plus
+oracle parity on sampled rows.  torch is plumbing: synthetic data in HBM and int64 checksums."""
+import numpy as np
+import pytest
+
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+qa = pytest.importorskip("quantization_amd")
+torch = pytest.importorskip("torch")
+D = qa.DistanceType
+
+
+def _free():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_c1_u8_dot_l2_10m_x_768(qo):
+    """configs[1]: 10M x 768 scalar u8, dot + L2."""
+    n, dim = 10_000_000, 768
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    # integer-valued data with alpha = 1, offset = 0: codes == values, multiplier == 1,
+    # every offset == 0, so Dot scores are the exact integer dot products (< 2^24).
+    data = torch.randint(0, 128, (n, dim), generator=g, device=dev, dtype=torch.int32).to(torch.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False), alpha_offset=(1.0, 0.0))
+    q1 = torch.randint(0, 64, (dim,), generator=g, device=dev).to(torch.float32)
+    q2 = torch.randint(0, 64, (dim,), generator=g, device=dev).to(torch.float32)
+    s1 = enc.score_all(enc.encode_query(q1), out=torch.empty(n, device=dev))
+    s2 = enc.score_all(enc.encode_query(q2), out=torch.empty(n, device=dev))
+    s12 = enc.score_all(enc.encode_query(q1 + q2), out=torch.empty(n, device=dev))
+    torch.cuda.synchronize()
+    assert torch.equal(s12, s1 + s2), "linearity in the query (exact integers)"
+    colsum = torch.zeros(dim, dtype=torch.float64, device=dev)
+    for lo in range(0, n, 1_000_000):  # checksum of checksums: sum_i dot_i == q . column sums
+        colsum += data[lo:lo + 1_000_000].sum(dim=0, dtype=torch.float64)
+    assert float(s1.sum(dtype=torch.float64)) == float((colsum * q1.double()).sum())
+    # sampled rows against the oracle (bit-exact), and scan kernel vs random-access kernel
+    ids = torch.randint(0, n, (4096,), generator=g, device=dev)
+    sample = data[ids].cpu().numpy()
+    rows, meta = qo.u8_encode_with(sample, qo.DOT, False, 1.0, 0.0)
+    codes, qoff = qo.u8_encode_query(meta, q1.cpu().numpy())
+    assert_bits_equal(s1[ids].cpu().numpy(), qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_AVX2), "sampled rows")
+    qobj = enc.encode_query(q1)
+    assert torch.equal(enc.score_ids(qobj, ids.to(torch.int32), out=torch.empty(4096, device=dev)), s1[ids])
+    ti, ts = enc.topk(qobj, 30)
+    best = torch.topk(s1, 30)
+    assert np.array_equal(np.sort(ts)[::-1], best.values.cpu().numpy())
+    del enc, s2, s12
+    _free()
+
+    # L2 on real-valued data: sampled oracle parity + agreement of the two kernels
+    data = torch.rand((n, dim), generator=g, device=dev)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L2, False))
+    md = enc.metadata
+    q = torch.rand(dim, generator=g, device=dev)
+    qobj = enc.encode_query(q)
+    s = enc.score_all(qobj, out=torch.empty(n, device=dev))
+    sample = data[ids].cpu().numpy()
+    rows, meta = qo.u8_encode_with(sample, qo.L2, False, float(md["alpha"]), float(md["offset"]))
+    codes, qoff = qo.u8_encode_query(meta, q.cpu().numpy())
+    torch.cuda.synchronize()
+    assert_bits_equal(s[ids].cpu().numpy(), qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_AVX2), "L2 sampled rows")
+    assert torch.equal(enc.score_ids(qobj, ids.to(torch.int32), out=torch.empty(4096, device=dev)), s[ids])
+    # the encode found the true global min/max
+    assert float(md["offset"]) == float(data.min()) and np.float32(md["alpha"]) == np.float32(
+        (np.float32(float(data.max())) - np.float32(float(data.min()))) / np.float32(127.0))
+    del enc, data
+    _free()
+
+
+def test_c2_pq_10m_x_768_m96(qo):
+    """configs[2]: 10M x 768, PQ m = 96 (chunk 8), ks = 256, LDS-resident LUT."""
+    n, dim, chunk = 10_000_000, 768, 8
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    cen = np.random.default_rng(7).random((256, dim), dtype=np.float32)
+    rows = torch.randint(0, 256, (n, 96), generator=g, device=dev, dtype=torch.uint8)
+    vp = qa.VectorParameters(dim, n, D.Dot, False)
+    enc = qa.EncodedVectorsPQ.from_storage(rows, vp, chunk, cen)
+    query = np.random.default_rng(8).random(dim, dtype=np.float32)
+    q = enc.encode_query(query)
+    lut = qo.pq_encode_query(query, chunk, cen, qo.DOT, False)
+    assert_bits_equal(q.lut, lut, "LUT")
+    s = enc.score_all(q, out=torch.empty(n, device=dev))
+    ids = torch.randint(0, n, (8192,), generator=g, device=dev)
+    torch.cuda.synchronize()
+    want = qo.pq_score_all(rows[ids].cpu().numpy(), lut, order=qo.ORDER_SSE)
+    assert_bits_equal(s[ids].cpu().numpy(), want, "sampled rows vs oracle (SSE order)")
+    # LDS fast kernel vs the random-access kernel on a permutation of every row
+    perm = torch.randperm(n, generator=g, device=dev).to(torch.int32)
+    sp = enc.score_ids(q, perm, out=torch.empty(n, device=dev))
+    assert torch.equal(sp, s[perm.long()]), "scan kernel and ids kernel disagree"
+    # encode side at a bounded size: GPU codes == oracle codes for real vectors
+    data = np.random.default_rng(9).random((20000, dim), dtype=np.float32)
+    e2 = qa.EncodedVectorsPQ.encode(data, qa.VectorParameters(dim, 20000, D.Dot, False), chunk, centroids=cen)
+    assert np.array_equal(e2.storage_bytes()[:2000], qo.pq_encode(data[:2000], chunk, cen))
+    del enc, rows
+    _free()
+
+
+def test_c3_binary_50m_x_1024(qo):
+    """configs[3]: 50M x 1024 binary / Hamming (one GPU holds all 6.4 GB)."""
+    n, dim = 50_000_000, 1024
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    rows = torch.randint(0, 256, (n, 128), generator=g, device=dev, dtype=torch.uint8)
+    vp = qa.VectorParameters(dim, n, D.Dot, False)
+    enc = qa.EncodedVectorsBin.from_storage(rows, vp)
+    qv = torch.randn(dim, generator=g, device=dev)
+    s = enc.score_all(enc.encode_query(qv), out=torch.empty(n, device=dev))
+    s_neg = enc.score_all(enc.encode_query(-qv), out=torch.empty(n, device=dev))
+    torch.cuda.synchronize()
+    assert torch.equal(s, -s_neg), "complement symmetry: score(q) == -score(~q), exactly"
+    zeros = enc.score_all(enc.encode_query(torch.full((dim,), -1.0, device=dev)), out=torch.empty(n, device=dev))
+    # q = all-zero bits: xor count = popcount(row); checksum against an independent bit count
+    total_bits = 0
+    lut8 = torch.tensor([bin(i).count("1") for i in range(256)], device=dev, dtype=torch.int64)
+    for lo in range(0, n, 5_000_000):
+        total_bits += int(lut8[rows[lo:lo + 5_000_000].long()].sum())
+    assert float(((dim - zeros.double()) / 2).sum()) == float(total_bits)
+    ids = torch.randint(0, n, (8192,), generator=g, device=dev)
+    qbits = enc.encode_query(qv).encoded_vector
+    want = qo.bin_score_all(rows[ids].cpu().numpy(), qbits, dim, qo.DOT, False, use_ref=qo.ref() is not None)
+    assert_bits_equal(s[ids].cpu().numpy(), want, "sampled rows vs oracle / reference popcount")
+    ti, ts = enc.topk(enc.encode_query(qv), 30)
+    assert np.array_equal(ts, torch.topk(s, 30).values.cpu().numpy())
+    assert np.all(s[torch.from_numpy(ti.astype(np.int64)).to(dev)].cpu().numpy() == ts)
+    del enc, rows
+    _free()
+
+
+def test_c4_shard_u8_1536_topk(qo):
+    """One of configs[4]'s eight shards: 12.5M x 1536 u8 with top-k (actual_dim > 1040: sums
+    can pass 2^24, the default mode is the exact integer rounded once)."""
+    n, dim = 12_500_000, 1536
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    data = torch.rand((n, dim), generator=g, device=dev)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    md = enc.metadata
+    q = torch.rand(dim, generator=g, device=dev)
+    qobj = enc.encode_query(q)
+    s = enc.score_all(qobj, out=torch.empty(n, device=dev))
+    ids = torch.randint(0, n, (2048,), generator=g, device=dev)
+    rows, meta = qo.u8_encode_with(data[ids].cpu().numpy(), qo.DOT, False, float(md["alpha"]), float(md["offset"]))
+    codes, qoff = qo.u8_encode_query(meta, q.cpu().numpy())
+    torch.cuda.synchronize()
+    assert_bits_equal(s[ids].cpu().numpy(), qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_SIMPLE), "sampled rows")
+    ti, ts = enc.topk(qobj, 100)
+    order = torch.sort(s, descending=True, stable=True)
+    assert np.array_equal(ts, order.values[:100].cpu().numpy())
+    assert np.array_equal(ti.astype(np.int64), order.indices[:100].cpu().numpy())
+    del enc, data
+    _free()
