@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "topk.hpp"
+#include "topk_device.hpp"
 
 #pragma clang fp contract(off)
 
@@ -60,11 +61,12 @@ __device__ __forceinline__ float metric(uint32_t x, float dim_f, int is_dot, int
 
 // Rows of ds >= 16 bytes (row_chunks = ds/16).  One wave per tile of (64/G)*UNROLL rows,
 // non-persistent grid (same reasoning and measurements as u8_scan_kernel in u8.hip).
-template <int G, int ITERS, int UNROLL, bool EXACT>
+template <int G, int ITERS, int UNROLL, bool EXACT, bool FILTER>
 __global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__restrict__ rows,
                                                              const uint4 *__restrict__ qbits, float dim_f,
                                                              int is_dot, int invert, uint32_t n_rows,
-                                                             uint32_t row_chunks, float *__restrict__ out) {
+                                                             uint32_t row_chunks, float *__restrict__ out,
+                                                             TopkFilter filt) {
     constexpr int RW = 64 / G;
     constexpr int TILE = RW * UNROLL;
     const int lane = threadIdx.x & 63;
@@ -96,6 +98,8 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__res
         }
     }
     float mine = 0.0f;  // lane (rslot, sub = u % G) keeps row u's score: one coalesced nt store per G rows-groups
+    uint32_t pivot = 0;
+    if (FILTER) pivot = *filt.pivot_key;
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
         uint32_t acc = 0;
@@ -106,7 +110,10 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__res
         if ((u % G) == G - 1 || u == UNROLL - 1) {
             const int first = (u / G) * G;
             const uint64_t row = base + (uint64_t)(first + sub) * RW + rslot;
-            if (sub <= u - first && row < n_rows) __builtin_nontemporal_store(mine, out + row);
+            if (sub <= u - first && row < n_rows) {
+                if (FILTER) topk_offer(filt, pivot, mine, (uint32_t)row);
+                else __builtin_nontemporal_store(mine, out + row);
+            }
         }
     }
 }
@@ -210,20 +217,25 @@ qamd_status alloc_store(qamd_bin *h) {
 }
 
 template <int G, int ITERS, int UNROLL>
-void launch_bin(const qamd_bin *h, const uint4 *qb, float *out, hipStream_t s) {
+void launch_bin(const qamd_bin *h, const uint4 *qb, float *out, const TopkFilter *filt, hipStream_t s) {
     constexpr int TILE = (64 / G) * UNROLL;
     const uint32_t rc = (uint32_t)(h->ds / 16);
     const int is_dot = h->vp.distance_type == QAMD_DOT;
     const uint64_t waves = (h->count + TILE - 1) / TILE;
     const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
-    if (rc == (uint32_t)(G * ITERS))
-        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, true>), dim3(grid), dim3(kScanBlock), 0, s,
-                           h->rows.as<uint4>(), qb, (float)h->vp.dim, is_dot, h->vp.invert, (uint32_t)h->count,
-                           rc, out);
-    else
-        hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, false>), dim3(grid), dim3(kScanBlock), 0, s,
-                           h->rows.as<uint4>(), qb, (float)h->vp.dim, is_dot, h->vp.invert, (uint32_t)h->count,
-                           rc, out);
+    const bool exact = rc == (uint32_t)(G * ITERS);
+#define QAMD_BIN_GO(EX, FI)                                                                                  \
+    hipLaunchKernelGGL((bin_scan_kernel<G, ITERS, UNROLL, EX, FI>), dim3(grid), dim3(kScanBlock), 0, s,      \
+                       h->rows.as<uint4>(), qb, (float)h->vp.dim, is_dot, h->vp.invert, (uint32_t)h->count, rc, \
+                       out, filt ? *filt : TopkFilter{})
+    if (filt) {
+        if (exact) QAMD_BIN_GO(true, true);
+        else QAMD_BIN_GO(false, true);
+    } else {
+        if (exact) QAMD_BIN_GO(true, false);
+        else QAMD_BIN_GO(false, false);
+    }
+#undef QAMD_BIN_GO
 }
 
 qamd_status words_launch(const qamd_bin *h, const uint32_t *qbits, const uint32_t *ids_dev, uint64_t n,
@@ -237,20 +249,22 @@ qamd_status words_launch(const qamd_bin *h, const uint32_t *qbits, const uint32_
     return QAMD_OK;
 }
 
-qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev, hipStream_t s) {
+bool fused_capable(const qamd_bin *h) { return h->ds % 16 == 0 && h->ds / 16 <= 64; }
+
+qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev, hipStream_t s,
+                      const TopkFilter *filt = nullptr) {
     if (h->count == 0) return QAMD_OK;
     const uint32_t rc = (uint32_t)(h->ds / 16);
-    if (h->ds % 16 != 0 || rc > 64)
-        return words_launch(h, q->buf.as<uint32_t>(), nullptr, h->count, out_dev, s);
+    if (!fused_capable(h)) return words_launch(h, q->buf.as<uint32_t>(), nullptr, h->count, out_dev, s);
     const uint4 *qb = q->buf.as<uint4>();
-    if (rc == 1) launch_bin<1, 1, 4>(h, qb, out_dev, s);
-    else if (rc == 2) launch_bin<2, 1, 4>(h, qb, out_dev, s);
-    else if (rc <= 4) launch_bin<4, 1, 8>(h, qb, out_dev, s);
-    else if (rc <= 8) launch_bin<8, 1, 16>(h, qb, out_dev, s);
-    else if (rc <= 16) launch_bin<16, 1, 8>(h, qb, out_dev, s);
-    else if (rc <= 32) launch_bin<16, 2, 4>(h, qb, out_dev, s);
-    else if (rc <= 48) launch_bin<16, 3, 4>(h, qb, out_dev, s);
-    else launch_bin<16, 4, 2>(h, qb, out_dev, s);
+    if (rc == 1) launch_bin<1, 1, 4>(h, qb, out_dev, filt, s);
+    else if (rc == 2) launch_bin<2, 1, 4>(h, qb, out_dev, filt, s);
+    else if (rc <= 4) launch_bin<4, 1, 8>(h, qb, out_dev, filt, s);
+    else if (rc <= 8) launch_bin<8, 1, 16>(h, qb, out_dev, filt, s);
+    else if (rc <= 16) launch_bin<16, 1, 8>(h, qb, out_dev, filt, s);
+    else if (rc <= 32) launch_bin<16, 2, 4>(h, qb, out_dev, filt, s);
+    else if (rc <= 48) launch_bin<16, 3, 4>(h, qb, out_dev, filt, s);
+    else launch_bin<16, 4, 2>(h, qb, out_dev, filt, s);
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;
 }
@@ -504,12 +518,21 @@ qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
     QAMD_TRY(ensure_device(h->device));
     hipStream_t s = as_stream(stream);
-    float *scores = nullptr;
-    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
-    qamd_status st = scan_into(h, q, scores, s);
-    if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
-    (void)hipFreeAsync(scores, s);
-    return st;
+    if (!fused_capable(h)) {
+        float *scores = nullptr;
+        QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+        qamd_status st = scan_into(h, q, scores, s);
+        if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
+        (void)hipFreeAsync(scores, s);
+        return st;
+    }
+    FusedScan scan;
+    scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_into(h, q, scores, st); };
+    scan.scan_filter = [&](const TopkFilter &f, hipStream_t st) { return scan_into(h, q, nullptr, st, &f); };
+    scan.score_ids = [&](const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+        return words_launch(h, q->buf.as<uint32_t>(), ids, n_ids, out, st);
+    };
+    return fused_topk(h->count, k, largest, out_ids, out_scores, out_mem, s, scan);
 }
 
 void qamd_bin_free(qamd_bin *h) { delete h; }

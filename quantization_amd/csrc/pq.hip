@@ -23,6 +23,7 @@
 
 #include "common.hpp"
 #include "topk.hpp"
+#include "topk_device.hpp"
 
 #pragma clang fp contract(off)
 
@@ -128,10 +129,11 @@ template <int J> __device__ __forceinline__ uint4 quad_bcast4(const uint4 &v) {
     return make_uint4(quad_bcast<J>(v.x), quad_bcast<J>(v.y), quad_bcast<J>(v.z), quad_bcast<J>(v.w));
 }
 
-template <int NV, int UNROLL>
+template <int NV, int UNROLL, bool FILTER>
 __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *__restrict__ rows4,
                                                                  const float *__restrict__ lut_g,
-                                                                 uint32_t n_rows, float *__restrict__ out) {
+                                                                 uint32_t n_rows, float *__restrict__ out,
+                                                                 TopkFilter filt) {
     extern __shared__ __attribute__((aligned(16))) float lut_s[];
     {
         constexpr uint32_t total4 = NV * 16 * (kCentroids / 4);
@@ -148,6 +150,8 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
     const uint64_t n_waves = (uint64_t)gridDim.x * (kScanBlock / 64);
     const float *lut_k = lut_s + k * kCentroids;
     const uint32_t shift = 8 * k;
+    uint32_t pivot = 0;
+    if (FILTER) pivot = *filt.pivot_key;
     for (uint64_t base = wave * TILE; base < n_rows; base += n_waves * TILE) {
         uint4 mine[UNROLL][JN];
 #pragma unroll
@@ -186,7 +190,10 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
             const float a = acc[u] + __shfl_xor(acc[u], 2, 64);  // (l0 + l2) + (l1 + l3)  (:430-432)
             const float s = a + __shfl_xor(a, 1, 64);
             const uint64_t row = base + u * 16 + rslot;
-            if (k == 0 && row < n_rows) out[row] = s;
+            if (k == 0 && row < n_rows) {
+                if (FILTER) topk_offer(filt, pivot, s, (uint32_t)row);
+                else out[row] = s;
+            }
         }
     }
 }
@@ -451,8 +458,13 @@ qamd_status set_centroids(qamd_pq *h, const float *centroids_host, hipStream_t s
     return copy_in(h->centroids.ptr, h->centroids_host.data(), QAMD_MEM_HOST, n * sizeof(float), s);
 }
 
+bool fast_capable(const qamd_pq *h, uint64_t n) {
+    const size_t lds = (size_t)h->m * kCentroids * sizeof(float);
+    return lds <= kLdsBudget && n >= 4096 && h->m % 16 == 0 && h->m / 16 <= 8 && n == h->count;
+}
+
 qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *ids_dev, uint64_t n,
-                        float *out_dev, hipStream_t s) {
+                        float *out_dev, hipStream_t s, const TopkFilter *filt = nullptr) {
     if (n == 0) return QAMD_OK;
     const uint32_t m = (uint32_t)h->m, row_words = (uint32_t)(h->ds / 4);
     const size_t lds = (size_t)m * kCentroids * sizeof(float);
@@ -462,18 +474,24 @@ qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *
 #define QAMD_PQ_LAUNCH(LDSF, V16, GRID, SH)                                                                 \
     hipLaunchKernelGGL((pq_scan_kernel<LDSF, V16>), dim3(GRID), dim3(kScanBlock), SH, s, h->rows.as<uint32_t>(), \
                        lut_dev, ids_dev, n, (uint32_t)h->count, m, row_words, out_dev)
-    if (in_lds && !ids_dev && m % 16 == 0 && m / 16 <= 8 && n == h->count) {
+    if (!ids_dev && fast_capable(h, n)) {
         const int grid = (int)std::min<uint64_t>(cu, (n + 1023) / 1024);
         const uint4 *rows4 = h->rows.as<uint4>();
 #define QAMD_PQ_FAST(NVV)                                                                                   \
     case NVV: {                                                                                             \
         static std::once_flag f;                                                                            \
         std::call_once(f, [] {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4>),         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, false>),  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, true>),   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
         });                                                                                                 \
-        hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4>), dim3(grid), dim3(kScanBlock), lds, s, rows4, lut_dev, \
-                           (uint32_t)n, out_dev);                                                           \
+        if (filt)                                                                                           \
+            hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, true>), dim3(grid), dim3(kScanBlock), lds, s, rows4, \
+                               lut_dev, (uint32_t)n, out_dev, *filt);                                       \
+        else                                                                                                \
+            hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, false>), dim3(grid), dim3(kScanBlock), lds, s, rows4, \
+                               lut_dev, (uint32_t)n, out_dev, TopkFilter{});                                \
         break;                                                                                              \
     }
         switch (m / 16) {
@@ -943,12 +961,24 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
     QAMD_TRY(ensure_device(h->device));
     hipStream_t s = as_stream(stream);
-    float *scores = nullptr;
-    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
-    qamd_status st = scan_launch(h, q->lut.as<float>(), nullptr, h->count, scores, s);
-    if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
-    (void)hipFreeAsync(scores, s);
-    return st;
+    const float *lut = q->lut.as<float>();
+    if (!fast_capable(h, h->count)) {
+        float *scores = nullptr;
+        QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+        qamd_status st = scan_launch(h, lut, nullptr, h->count, scores, s);
+        if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
+        (void)hipFreeAsync(scores, s);
+        return st;
+    }
+    FusedScan scan;
+    scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_launch(h, lut, nullptr, h->count, scores, st); };
+    scan.scan_filter = [&](const TopkFilter &f, hipStream_t st) {
+        return scan_launch(h, lut, nullptr, h->count, nullptr, st, &f);
+    };
+    scan.score_ids = [&](const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+        return scan_launch(h, lut, ids, n_ids, out, st);
+    };
+    return fused_topk(h->count, k, largest, out_ids, out_scores, out_mem, s, scan);
 }
 
 void qamd_pq_free(qamd_pq *h) { delete h; }

@@ -1,5 +1,7 @@
 // Exact device top-k over an f32 score array (see topk.hip).
 #pragma once
+#include <functional>
+
 #include "common.hpp"
 
 namespace qamd {
@@ -16,5 +18,24 @@ qamd_status topk_f32(const float *scores_dev, uint64_t n, uint32_t k, bool large
 // Shared tail of the three *_topk entry points: scores already computed into scores_dev.
 qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int largest,
                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);
+
+// Fused scan + selection: the scan never materialises the score array.
+//   1. score kTopkSample (16384) pseudo-randomly chosen rows (random-access kernel),
+//   2. take the r-th best sample as pivot so that ~max(2048, 3k) rows are expected to pass,
+//   3. run the scan in FILTER mode: rows at least as good as the pivot are appended to a
+//      candidate buffer (8192 slots),
+//   4. sort the candidates in one workgroup and emit the k best (ties to the lower id).
+// Exact whenever k <= #candidates <= 8192; otherwise (heavy ties, e.g. binary scores, or an
+// unlucky pivot) the classic path runs: full score array + exact radix select.  The status
+// read-back makes this call synchronise `stream`.
+constexpr uint32_t kTopkSample = 16384;
+struct TopkFilter;
+struct FusedScan {
+    std::function<qamd_status(const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t)> score_ids;
+    std::function<qamd_status(const TopkFilter &, hipStream_t)> scan_filter;
+    std::function<qamd_status(float *scores_dev, hipStream_t)> scan_scores;
+};
+qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                       qamd_mem out_mem, hipStream_t stream, const FusedScan &scan);
 
 }  // namespace qamd

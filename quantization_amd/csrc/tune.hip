@@ -86,8 +86,15 @@ __global__ __launch_bounds__(BLOCK, MINW) void tune_scan(const uint4 *__restrict
         if (NTS >= 2 && sub < UNROLL) {  // one store instruction: RW*UNROLL consecutive rows
             const uint64_t row = base + sub * RW + rslot;
             if (row < n_rows) {
-                if (NTS == 3) __builtin_nontemporal_store(mine, out + row);
-                else out[row] = mine;
+                if (NTS == 3 || NTS == 5) __builtin_nontemporal_store(mine, out + row);
+                else if (NTS == 2) out[row] = mine;
+                if (NTS >= 4) {  // filter experiment: pivot in out[n_rows + 1] (u32), counter at out[n_rows + 64]
+                    const uint32_t piv = reinterpret_cast<const uint32_t *>(out)[n_rows + 1];
+                    uint32_t key = __float_as_uint(mine);
+                    key ^= (key >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+                    key = ~key;
+                    if (key <= piv) atomicAdd(reinterpret_cast<uint32_t *>(out) + n_rows + 64, 1u);
+                }
             }
         }
     }
@@ -138,17 +145,10 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_u8_sweep(
                                              multiplier, n_rows, (uint32_t)TPW, out_dev);                 \
                       }, {}});                                                                            \
     } while (0)
-    // round 4: score-store shape, A/B interleaved.  store0 per-u plain, 2 transposed plain, 3 transposed nt
-    ADDS(4, true, 512, 1, 1, 0, 0);
-    ADDS(4, true, 512, 1, 1, 0, 2);
+    // round 5: does dropping the score store (fused top-k filter mode) cost time?
     ADDS(4, true, 512, 1, 1, 0, 3);
-    ADDS(8, true, 512, 1, 1, 0, 0);
-    ADDS(8, true, 512, 1, 1, 0, 2);
-    ADDS(8, true, 512, 1, 1, 0, 3);
-    ADDS(16, true, 512, 1, 1, 0, 2);
-    ADDS(16, true, 512, 1, 1, 0, 3);
-    ADDS(2, true, 1024, 1, 1, 0, 0);
-    ADDS(2, true, 1024, 1, 1, 0, 2);
+    ADDS(4, true, 512, 1, 1, 0, 4);
+    ADDS(4, true, 512, 1, 1, 0, 5);
 #undef ADD
 #undef ADDS
     hipEvent_t e0, e1;

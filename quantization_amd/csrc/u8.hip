@@ -30,6 +30,7 @@
 
 #include "common.hpp"
 #include "topk.hpp"
+#include "topk_device.hpp"
 
 #pragma clang fp contract(off)
 
@@ -105,11 +106,13 @@ __device__ __forceinline__ uint32_t f32_to_u8(float v, float alpha, float offset
 // window of the store.  ITERS = ceil(row_chunks / G).
 // EXACT: row_chunks == G*ITERS, so no lane is ever past the row end.  Otherwise loads stay
 // unconditional (clamped address + select) so that they still issue back to back.
-template <int G, int ITERS, int UNROLL, bool IS_L1, bool EXACT>
+// FILTER: fused top-k mode — no score is written; rows at least as good as the pivot are
+// appended to the candidate buffer (topk_device.hpp).
+template <int G, int ITERS, int UNROLL, bool IS_L1, bool EXACT, bool FILTER>
 __global__ __launch_bounds__(kScanBlock) void u8_scan_kernel(
     const uint4 *__restrict__ codes, const float *__restrict__ offsets,
     const uint4 *__restrict__ qcodes, const float *__restrict__ q_off_p, float multiplier,
-    uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out) {
+    uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out, TopkFilter filt) {
     constexpr int RW = 64 / G;
     constexpr int TILE = RW * UNROLL;
     const int lane = threadIdx.x & 63;
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(kScanBlock) void u8_scan_kernel(
     for (int g = 0; g < NGROUPS; g++)  // offsets[] is padded like codes[]: no guard needed
         v_off[g] = offsets[base + (uint64_t)(g * G + sub) * RW + rslot];
     float mine = 0.0f;
+    uint32_t pivot = 0;
+    if (FILTER) pivot = *filt.pivot_key;
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
         uint32_t acc = 0;
@@ -167,7 +172,10 @@ __global__ __launch_bounds__(kScanBlock) void u8_scan_kernel(
             (void)dummy;
             const int first = (u / G) * G;
             const uint64_t row = base + (uint64_t)(first + sub) * RW + rslot;
-            if (sub <= u - first && row < n_rows) __builtin_nontemporal_store(mine, out + row);
+            if (sub <= u - first && row < n_rows) {
+                if (FILTER) topk_offer(filt, pivot, mine, (uint32_t)row);
+                else __builtin_nontemporal_store(mine, out + row);
+            }
         }
     }
 }
@@ -532,48 +540,67 @@ qamd_status alloc_store(qamd_u8 *h) {
 
 template <bool IS_L1> struct ScanLaunch {
     template <int G, int ITERS, int UNROLL>
-    static void go(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, hipStream_t s) {
+    static void go(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, const TopkFilter *filt,
+                   hipStream_t s) {
         constexpr int TILE = (64 / G) * UNROLL;
         const uint64_t waves = (h->count + TILE - 1) / TILE;  // one wave per tile
         const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
-        if (h->row_chunks == (uint32_t)(G * ITERS))
-            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, true>), dim3(grid), dim3(kScanBlock), 0,
-                               s, h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
-                               (uint32_t)h->count, h->row_chunks, out);
-        else
-            hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, false>), dim3(grid), dim3(kScanBlock), 0,
-                               s, h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
-                               (uint32_t)h->count, h->row_chunks, out);
+        const bool exact = h->row_chunks == (uint32_t)(G * ITERS);
+#define QAMD_U8_GO(EX, FI)                                                                                  \
+    hipLaunchKernelGGL((u8_scan_kernel<G, ITERS, UNROLL, IS_L1, EX, FI>), dim3(grid), dim3(kScanBlock), 0, s, \
+                       h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,            \
+                       (uint32_t)h->count, h->row_chunks, out, filt ? *filt : TopkFilter{})
+        if (filt) {
+            if (exact) QAMD_U8_GO(true, true);
+            else QAMD_U8_GO(false, true);
+        } else {
+            if (exact) QAMD_U8_GO(true, false);
+            else QAMD_U8_GO(false, false);
+        }
+#undef QAMD_U8_GO
     }
 };
 
+// Returns false when the store's row size has no templated kernel (caller uses the generic one).
 template <bool IS_L1>
-void launch_scan(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, hipStream_t s) {
+bool launch_scan(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, const TopkFilter *filt,
+                 hipStream_t s) {
     using L = ScanLaunch<IS_L1>;
     const uint32_t rc = h->row_chunks;
-    if (rc == 1) return L::template go<1, 1, 4>(h, qc, qo, out, s);
-    if (rc == 2) return L::template go<2, 1, 4>(h, qc, qo, out, s);
-    if (rc <= 4) return L::template go<4, 1, 8>(h, qc, qo, out, s);
-    if (rc <= 8) return L::template go<8, 1, 8>(h, qc, qo, out, s);
+    if (rc == 1) return L::template go<1, 1, 4>(h, qc, qo, out, filt, s), true;
+    if (rc == 2) return L::template go<2, 1, 4>(h, qc, qo, out, filt, s), true;
+    if (rc <= 4) return L::template go<4, 1, 8>(h, qc, qo, out, filt, s), true;
+    if (rc <= 8) return L::template go<8, 1, 8>(h, qc, qo, out, filt, s), true;
     switch ((rc + 15) / 16) {
-        case 1: return L::template go<16, 1, 8>(h, qc, qo, out, s);
-        case 2: return L::template go<16, 2, 4>(h, qc, qo, out, s);
-        case 3: return L::template go<16, 3, 4>(h, qc, qo, out, s);
-        case 4: return L::template go<16, 4, 2>(h, qc, qo, out, s);
-        case 5: return L::template go<16, 5, 2>(h, qc, qo, out, s);
-        case 6: return L::template go<16, 6, 2>(h, qc, qo, out, s);
-        case 7: return L::template go<16, 7, 2>(h, qc, qo, out, s);
-        case 8: return L::template go<16, 8, 2>(h, qc, qo, out, s);
+        case 1: return L::template go<16, 1, 8>(h, qc, qo, out, filt, s), true;
+        case 2: return L::template go<16, 2, 4>(h, qc, qo, out, filt, s), true;
+        case 3: return L::template go<16, 3, 4>(h, qc, qo, out, filt, s), true;
+        case 4: return L::template go<16, 4, 2>(h, qc, qo, out, filt, s), true;
+        case 5: return L::template go<16, 5, 2>(h, qc, qo, out, filt, s), true;
+        case 6: return L::template go<16, 6, 2>(h, qc, qo, out, filt, s), true;
+        case 7: return L::template go<16, 7, 2>(h, qc, qo, out, filt, s), true;
+        case 8: return L::template go<16, 8, 2>(h, qc, qo, out, filt, s), true;
         default: break;
     }
+    return false;
+}
+
+template <bool IS_L1>
+void launch_scan_generic(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out, hipStream_t s) {
     uint64_t waves = (h->count + 3) / 4;  // one wave per 4-row tile (non-persistent, see u8_scan_kernel)
     unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
     hipLaunchKernelGGL((u8_scan_generic_kernel<IS_L1>), dim3(grid), dim3(kBlock), 0, s,
                        h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
-                       (uint32_t)h->count, rc, out);
+                       (uint32_t)h->count, h->row_chunks, out);
 }
 
-qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, hipStream_t s) {
+bool fused_capable(const qamd_u8 *h) {
+    const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+    return (is_l1 || h->lane_mode == 0) && h->row_chunks <= 128;
+}
+
+qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, hipStream_t s,
+                      const TopkFilter *filt = nullptr) {
     if (h->count == 0) return QAMD_OK;
     const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
     const float *qo = q->buf.as<float>();
@@ -585,9 +612,9 @@ qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, 
                            h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier,
                            (uint32_t)h->count, h->row_chunks, out_dev);
     } else if (is_l1) {
-        launch_scan<true>(h, qc, qo, out_dev, s);
+        if (!launch_scan<true>(h, qc, qo, out_dev, filt, s)) launch_scan_generic<true>(h, qc, qo, out_dev, s);
     } else {
-        launch_scan<false>(h, qc, qo, out_dev, s);
+        if (!launch_scan<false>(h, qc, qo, out_dev, filt, s)) launch_scan_generic<false>(h, qc, qo, out_dev, s);
     }
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;
@@ -1035,12 +1062,22 @@ qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, i
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
     QAMD_TRY(ensure_device(h->device));
     hipStream_t s = as_stream(stream);
-    float *scores = nullptr;
-    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
-    qamd_status st = scan_into(h, q, scores, s);
-    if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
-    (void)hipFreeAsync(scores, s);
-    return st;
+    const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
+    FusedScan scan;
+    scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_into(h, q, scores, st); };
+    scan.scan_filter = [&](const TopkFilter &f, hipStream_t st) { return scan_into(h, q, nullptr, st, &f); };
+    scan.score_ids = [&](const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+        return score_ids_dev(h, qc, q->buf.as<float>(), 0.0f, EPI_POINT, ids, n_ids, out, st);
+    };
+    if (!fused_capable(h)) {  // rare layouts: classic path only
+        float *scores = nullptr;
+        QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+        qamd_status st = scan_into(h, q, scores, s);
+        if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
+        (void)hipFreeAsync(scores, s);
+        return st;
+    }
+    return fused_topk(h->count, k, largest, out_ids, out_scores, out_mem, s, scan);
 }
 
 void qamd_u8_free(qamd_u8 *h) { delete h; }

@@ -17,7 +17,8 @@ data = torch.rand((n, dim), device=dev)
 enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, qa.DistanceType.Dot, False))
 del data
 q = enc.encode_query(torch.rand(dim, device=dev))
-out = torch.empty(n, dtype=torch.float32, device=dev)
+out = torch.zeros(n + 1024, dtype=torch.float32, device=dev)
+out.view(torch.int32)[n + 1] = 0x3A000000  # filter experiment pivot key (lets ~nothing through)
 ref = torch.empty(n, dtype=torch.float32, device=dev)
 enc.score_all(q, out=ref)
 codes, offs = C.c_void_p(), C.c_void_p()
@@ -31,4 +32,4 @@ st = L.qamd_dev_u8_sweep(codes, offs, qp, C.c_float(float(enc.metadata["multipli
 print("status", st, L.qamd_last_error())
 print(rep.value.decode())
 torch.cuda.synchronize()
-print("last variant output equals shipped kernel:", bool(torch.equal(out, ref)))
+print("last variant output equals shipped kernel:", bool(torch.equal(out[:n], ref)))
