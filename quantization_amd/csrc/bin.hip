@@ -45,9 +45,18 @@ __device__ __forceinline__ uint32_t xpop16(const uint4 &a, const uint4 &b, uint3
     return acc;
 }
 
+// Sum over the G (<= 16) adjacent lanes of a row group, result in every lane.  DPP only
+// (quad_perm xor-1 / xor-2, row_half_mirror, row_mirror): four VALU adds for G = 16, instead
+// of the ds_bpermute round trips __shfl_xor compiles to.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
 template <int G> __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
-#pragma unroll
-    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "row group is at most one DPP row");
+    if (G >= 2) v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (G >= 4) v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (G >= 8) v = dpp_add<0x141>(v);  // row_half_mirror
+    if (G >= 16) v = dpp_add<0x140>(v); // row_mirror
     return v;
 }
 
@@ -77,8 +86,14 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__res
     uint4 q[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        uint32_t c = sub + it * G;
-        q[it] = c < row_chunks ? qbits[c] : make_uint4(0, 0, 0, 0);
+        const uint32_t c = sub + it * G;
+        if (EXACT) {
+            q[it] = qbits[c];
+        } else {
+            const uint4 t = qbits[c < row_chunks ? c : row_chunks - 1];
+            const bool in = c < row_chunks;
+            q[it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+        }
     }
     uint4 v[UNROLL][ITERS];
 #pragma unroll

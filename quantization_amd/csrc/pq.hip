@@ -187,8 +187,11 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const float a = acc[u] + __shfl_xor(acc[u], 2, 64);  // (l0 + l2) + (l1 + l3)  (:430-432)
-            const float s = a + __shfl_xor(a, 1, 64);
+            // (l0 + l2) + (l1 + l3)  (:430-432): quad_perm DPP reads, no LDS round trip
+            const float a = acc[u] + __int_as_float(__builtin_amdgcn_update_dpp(
+                                         0, __float_as_int(acc[u]), 0x4E, 0xF, 0xF, false));  // lane ^ 2
+            const float s = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF,
+                                                                          false));  // lane ^ 1
             const uint64_t row = base + u * 16 + rslot;
             if (k == 0 && row < n_rows) {
                 if (FILTER) topk_offer(filt, pivot, s, (uint32_t)row);
