@@ -44,6 +44,10 @@ def parse_args():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queries", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; "
+                    "gloo only to rehearse the multi-rank code path, e.g. several ranks on one GPU)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="rehearsal only: put every rank on this one device (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -132,14 +136,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
+    torch.cuda.set_device(dev_index)
     L = _lib.lib()
-    if L.qamd_set_device(local_rank) != 0:
+    if L.qamd_set_device(dev_index) != 0:
         raise SystemExit(L.qamd_last_error().decode())
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     n, dim = args.rows_per_gpu, args.dim
     dtype = qa.DistanceType.Dot if args.distance == "dot" else qa.DistanceType.L2
@@ -210,7 +218,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -9,21 +9,19 @@ using namespace qamd;
 namespace {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4 *__restrict__ p, uint64_t n16,
+// Same launch shape as the scans: non-persistent, one 16 KiB tile per wave (four 16-byte nt
+// loads per lane), workgroups dispatched in address order.
+__global__ __launch_bounds__(512) void stream_read_kernel(const u32x4 *__restrict__ p, uint64_t n16,
                                                          uint32_t *__restrict__ scratch) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 512 + threadIdx.x) >> 6;
+    const uint64_t base = wave * 1024 + (threadIdx.x & 63);  // 1024 x 16 B per wave
     uint32_t acc = 0;
-    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        u32x4 a = __builtin_nontemporal_load(p + i);
-        u32x4 b = __builtin_nontemporal_load(p + i + stride);
-        u32x4 c = __builtin_nontemporal_load(p + i + 2 * stride);
-        u32x4 d = __builtin_nontemporal_load(p + i + 3 * stride);
-        acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
-    }
-    for (; i < n16; i += stride) {
-        u32x4 a = __builtin_nontemporal_load(p + i);
-        acc += a.x ^ a.y ^ a.z ^ a.w;
+    if (base + 15 * 64 < n16) {
+        u32x4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = __builtin_nontemporal_load(p + base + j * 64);
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc += v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
     }
     if (acc == 0x9E3779B9u) scratch[blockIdx.x & 16383] = acc;  // keeps the loads live, ~never stores
 }
@@ -33,8 +31,8 @@ extern "C" qamd_status qamd_stream_read(const void *dev_ptr, uint64_t bytes, voi
     if (!dev_ptr || !scratch) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     QAMD_TRY(ensure_device(current_device()));
     const uint64_t n16 = bytes / 16;
-    const int grid = device_info().cu_count * 8;
-    hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
+    const unsigned grid = (unsigned)((n16 / 1024 + 7) / 8);  // 8 waves per workgroup, one tile per wave
+    hipLaunchKernelGGL(stream_read_kernel, dim3(grid ? grid : 1), dim3(512), 0, as_stream(stream),
                        static_cast<const u32x4 *>(dev_ptr), n16, static_cast<uint32_t *>(scratch));
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;

@@ -30,6 +30,12 @@ def max_shard_rows(count: int, world: int) -> int:
     return max(shard_range(count, r, world)[1] - shard_range(count, r, world)[0] for r in range(world))
 
 
+def _needs_host_staging(dist, tensor) -> bool:
+    """gloo cannot gather CUDA tensors; stage through host memory then (rehearsal runs of the
+    multi-rank path on a single GPU).  With nccl (= RCCL) tensors stay in HBM."""
+    return getattr(tensor, "is_cuda", False) and dist.get_backend() == "gloo"
+
+
 class ScoreGather:
     """Double-buffered asynchronous gather of per-shard score vectors to rank `dst`.
 
@@ -62,6 +68,13 @@ class ScoreGather:
     def submit(self, step: int) -> None:
         s = step % 2
         if self.world == 1:  # single shard: the local scores ARE the global scores
+            return
+        if _needs_host_staging(self.dist, self.local[s]):
+            host = self.local[s].cpu()
+            hlist = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+            self.dist.gather(host, gather_list=hlist, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                self.gathered[s].copy_(self.torch.stack(hlist))
             return
         glist = list(self.gathered[s].unbind(0)) if self.rank == self.dst else None
         self.work[s] = self.dist.gather(self.local[s], gather_list=glist, dst=self.dst, group=self.group,
@@ -130,6 +143,11 @@ class ShardedTopK:
     def exchange(self, largest: bool = True):
         if self.world == 1:
             self.all[0].copy_(self.pack)
+        elif _needs_host_staging(self.dist, self.pack):
+            hp = self.pack.cpu()
+            ha = self.torch.empty((self.world, 2 * self.k), dtype=self.torch.int32)
+            self.dist.all_gather_into_tensor(ha.view(-1), hp, group=self.group)
+            self.all.copy_(ha)
         else:
             self.dist.all_gather_into_tensor(self.all.view(-1), self.pack, group=self.group)
         host = self.all.cpu().numpy()
