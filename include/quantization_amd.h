@@ -152,6 +152,25 @@ QAMD_API qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint
                                   qamd_mem out_mem, void *stream);
 QAMD_API void qamd_u8_free(qamd_u8 *h);
 
+/* Multi-query form: many queries against the store at once (the caller's OUTER loop over
+ * queries, demos/src/ann_benchmark.rs:245-260, with its per-query 30-entry heap,
+ * demos/src/ann_benchmark_data.rs:151-167).  On the GPU this is a dense u8 x u8 -> i32
+ * contraction on the matrix cores; every score is bit-identical to qamd_u8_score_all for the
+ * same query.  Dot and L2 only (the reference's dot kernel, encoded_vectors_u8.rs:339-341). */
+typedef struct qamd_u8_query_batch qamd_u8_query_batch; /* n x EncodedQueryU8 */
+/* queries: n_queries x qdim f32, row-major.  *batch_io is created when NULL, else re-used. */
+QAMD_API qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries,
+                                                uint64_t n_queries, uint64_t qdim, qamd_mem queries_mem,
+                                                void *stream, qamd_u8_query_batch **batch_io);
+QAMD_API void qamd_u8_query_batch_free(qamd_u8_query_batch *b);
+/* out[q * count + i] = score_point(query q, i): n_queries * count f32 (mind the size). */
+QAMD_API qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, float *out,
+                                         qamd_mem out_mem, void *stream);
+/* out_ids / out_scores: n_queries x k, per query as qamd_u8_topk.  Synchronises the stream. */
+QAMD_API qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, uint32_t k,
+                                        int largest, uint32_t *out_ids, float *out_scores,
+                                        qamd_mem out_mem, void *stream);
+
 /* Extension (no reference counterpart): how a pair sum >= 2^24 (only possible for
  * actual_dim > 1040) becomes f32.  0 (default): exact integer, rounded once — what the
  * reference's scalar path does (encoded_vectors_u8.rs:158).  1: the 8-lane f32 summation

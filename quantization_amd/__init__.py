@@ -9,7 +9,7 @@ from ._lib import build, lib  # noqa: F401
 from .encoded_vectors import DistanceType, EncodingError, VectorParameters  # noqa: F401
 from .encoded_vectors_binary import BitsStoreType, EncodedBinVector, EncodedVectorsBin  # noqa: F401
 from .encoded_vectors_pq import EncodedQueryPQ, EncodedVectorsPQ  # noqa: F401
-from .encoded_vectors_u8 import EncodedQueryU8, EncodedVectorsU8  # noqa: F401
+from .encoded_vectors_u8 import EncodedQueryBatchU8, EncodedQueryU8, EncodedVectorsU8  # noqa: F401
 
 
 
@@ -36,7 +36,7 @@ def topk_scores(scores, n: int, k: int, largest: bool = True, out_ids=None, out_
 __all__ = [
     "topk_scores",
     "DistanceType", "VectorParameters", "EncodingError",
-    "EncodedVectorsU8", "EncodedQueryU8",
+    "EncodedVectorsU8", "EncodedQueryU8", "EncodedQueryBatchU8",
     "EncodedVectorsPQ", "EncodedQueryPQ",
     "EncodedVectorsBin", "EncodedBinVector", "BitsStoreType",
     "build", "lib",

@@ -93,6 +93,10 @@ def lib() -> C.CDLL:
         "qamd_u8_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_u8_free": (None, [vp]),
         "qamd_u8_set_lane_mode": (i32, [vp, i32]),
+        "qamd_u8_encode_query_batch": (i32, [vp, vp, u64, u64, i32, vp, pp]),
+        "qamd_u8_query_batch_free": (None, [vp]),
+        "qamd_u8_score_batch": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_u8_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_u8_scan_bytes_per_row": (u64, [vp]),
         # binary
         "qamd_bin_quantized_vector_size": (u64, [VP, i32]),

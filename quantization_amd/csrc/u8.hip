@@ -31,6 +31,7 @@
 #include "common.hpp"
 #include "topk.hpp"
 #include "topk_device.hpp"
+#include "u8_internal.hpp"
 
 #pragma clang fp contract(off)
 
@@ -468,6 +469,56 @@ __global__ __launch_bounds__(64) void encode_query_kernel(const float *__restric
     }
 }
 
+// Batch form of encode_query_kernel: one wave per query, separate code / offset arrays
+// (the layout the multi-query MFMA path reads, u8_batch.hip).
+__global__ __launch_bounds__(64) void encode_queries_kernel(const float *__restrict__ queries, uint32_t qdim,
+                                                           uint32_t actual_dim, float alpha, float offset,
+                                                           int distance, int invert, uint8_t *__restrict__ codes_out,
+                                                           float *__restrict__ offsets_out) {
+    const int lane = threadIdx.x;
+    const float *query = queries + (size_t)blockIdx.x * qdim;
+    uint8_t *codes = codes_out + (size_t)blockIdx.x * actual_dim;
+    const float placeholder = (distance == QAMD_DOT) ? 0.0f : offset;
+    const uint32_t pad_code = f32_to_u8(placeholder, alpha, offset);
+    uint32_t s1 = 0, s2 = 0;
+    for (uint32_t j = lane; j < actual_dim; j += 64) {
+        uint32_t c = j < qdim ? f32_to_u8(query[j], alpha, offset) : pad_code;
+        codes[j] = (uint8_t)c;
+        s1 += c;
+        s2 += c * c;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane == 0) {
+        float off;
+        if (distance == QAMD_DOT) {
+            float s = (float)s1;
+            if (s1 >= (1u << 24)) {
+                s = 0.0f;
+                for (uint32_t j = 0; j < actual_dim; j++)
+                    s += (float)(j < qdim ? f32_to_u8(query[j], alpha, offset) : pad_code);
+            }
+            off = s * alpha * offset;
+        } else if (distance == QAMD_L1) {
+            off = 0.0f;
+        } else {
+            float s = (float)s2;
+            if (s2 >= (1u << 24)) {
+                s = 0.0f;
+                for (uint32_t j = 0; j < actual_dim; j++) {
+                    float c = (float)(j < qdim ? f32_to_u8(query[j], alpha, offset) : pad_code);
+                    s += c * c;
+                }
+            }
+            off = s * alpha * alpha;
+        }
+        offsets_out[blockIdx.x] = invert ? -off : off;
+    }
+}
+
 // Reference-format rows <-> device layout (encoded_storage.rs:27-31, row stride actual_dim+4).
 __global__ __launch_bounds__(kBlock) void split_rows_kernel(const uint32_t *__restrict__ rows32,
                                                            uint64_t n_rows, uint32_t row_dwords,
@@ -526,22 +577,7 @@ uint64_t actual_dim_of(uint64_t dim) { return dim + (16 - dim % 16) % 16; }  // 
 }  // namespace
 
 // ------------------------------------------------------------------------------ handles
-struct qamd_u8 {
-    int device = 0;
-    qamd_u8_metadata meta{};
-    uint64_t count = 0;
-    uint64_t padded_rows = 0;
-    uint32_t row_chunks = 0;  // actual_dim / 16
-    int lane_mode = 0;        // 0: integer sum rounded once; 1: avx2.c lane order
-    DevBuf codes;             // [padded_rows][actual_dim]
-    DevBuf offsets;           // [padded_rows] f32
-};
-
-struct qamd_u8_query {
-    int device = 0;
-    uint64_t actual_dim = 0;
-    DevBuf buf;  // [0..4) offset f32, [16..16+actual_dim) codes
-};
+// struct qamd_u8 / qamd_u8_query: u8_internal.hpp
 
 namespace {
 
@@ -1108,6 +1144,35 @@ qamd_status qamd_u8_set_lane_mode(qamd_u8 *h, int mode) {
 }
 
 }  // extern "C"
+
+namespace qamd {
+
+qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev, uint64_t n_queries, uint64_t qdim,
+                                     uint8_t *codes_dev, float *offsets_dev, hipStream_t stream) {
+    if (n_queries == 0) return QAMD_OK;
+    const qamd_vector_parameters &vp = h->meta.vector_parameters;
+    hipLaunchKernelGGL(encode_queries_kernel, dim3((unsigned)n_queries), dim3(64), 0, stream, queries_dev,
+                       (uint32_t)qdim, (uint32_t)actual_dim_of(qdim), h->meta.alpha, h->meta.offset,
+                       vp.distance_type, vp.invert, codes_dev, offsets_dev);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+// Exact single-query top-k for one member of a query batch (its per-query fallback).
+qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,
+                           int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream) {
+    qamd_u8_query q;
+    q.device = h->device;
+    q.actual_dim = h->meta.actual_dim;
+    QAMD_TRY(q.buf.alloc(16 + q.actual_dim + 16, true));
+    QAMD_HIP(hipMemcpyAsync(q.buf.ptr, offset_dev, 4, hipMemcpyDeviceToDevice, stream));
+    QAMD_HIP(hipMemcpyAsync(q.buf.as<uint8_t>() + 16, codes_dev, q.actual_dim, hipMemcpyDeviceToDevice, stream));
+    qamd_status st = qamd_u8_topk(h, &q, k, largest, out_ids, out_scores, out_mem, stream);
+    QAMD_HIP(hipStreamSynchronize(stream));  // q.buf is freed on return
+    return st;
+}
+
+}  // namespace qamd
 
 // Developer-only accessors for the tuning harness (tune.hip); not part of include/.
 extern "C" __attribute__((visibility("default"))) void qamd_dev_u8_ptrs(const qamd_u8 *h, const void **codes,

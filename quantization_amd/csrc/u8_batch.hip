@@ -1,0 +1,444 @@
+// Multi-query scoring of the scalar-u8 store on the matrix cores (gfx950 MFMA, int8).
+//
+// What it replaces: the reference scores queries one at a time — the caller loops over
+// queries and, inside, over rows (demos/src/ann_benchmark.rs:245-260), keeping a 30-entry heap
+// per query (demos/src/ann_benchmark_data.rs:151-167).  With Q queries in flight the same
+// work is a dense u8 x u8 -> i32 contraction  S[q][row] = sum_d Qc[q][d] * V[row][d]
+// (codes <= 127, so int8 is exact), i.e. GEMM-shaped: every byte of the store read from HBM is
+// used Q times, and at Q ~ 1024 the bound moves from HBM to the MFMA pipe (SURVEY 8f rank 1,
+// BASELINE config 4).  The f32 epilogue is the single-query one,
+// ((multiplier*s)+q.offset)+vector_offset (encoded_vectors_u8.rs:347), so every score is
+// bit-identical to qamd_u8_score_all for that query (integer sum rounded once).
+//
+// Kernel (u8_gemm_kernel): workgroup tile 128 queries x 128 rows, 4 waves (2 x 2), each wave
+// 64 x 64 = 2 x 2 tiles of v_mfma_i32_32x32x32_i8.  Both operands are K-contiguous in memory
+// (queries [Q][D], store rows [N][D]) and the MFMA K index is only a summation index, so lane
+// (r, h) simply takes bytes [32s + 16h, +16) of query/row r in k-step s: fragments are plain
+// 16-byte pieces, no transposition anywhere.  K is walked in 128-byte slabs staged through LDS
+// with whole-line coalesced global loads (8 lanes x 16 B per row), register-staged double
+// buffering (next slab's global loads fly during the MFMAs, one barrier per slab), rows padded
+// by 16 B in LDS (144-B pitch: ds_read_b128 of 16 rows hits 16 distinct 4-bank slots).
+// Workgroups that share a row tile run on one XCD back to back (blockIdx -> tile map), so the
+// row tile comes from HBM once and from that XCD's L2 for the other query tiles.
+//
+// Top-k per query is fused exactly as in topk.hip: pivot per query from 16384 sampled rows
+// (scored by this same kernel on a gathered sub-store), FILTER epilogue appending to per-query
+// candidate lists, one workgroup per query sorting its list; queries whose list over/underflows
+// are redone through the exact single-query path.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "topk.hpp"
+#include "topk_device.hpp"
+#include "u8_internal.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace qamd;
+
+namespace {
+
+constexpr int TQ = 128, TR = 128;  // workgroup tile: queries x rows
+constexpr int BK = 128;            // K slab in bytes
+constexpr int PITCH = BK + 16;     // LDS row pitch
+constexpr int kThreads = 256;
+constexpr uint32_t kBatchCap = kTopkCandCap;  // candidate slots per query
+constexpr uint32_t kCounterStride = 16;       // u32: one counter per 64-byte line
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct BatchFilter {
+    const uint32_t *pivots;          // [Qpad] order-preserving keys
+    uint32_t *counters;              // [Qpad * kCounterStride]
+    unsigned long long *candidates;  // [Qpad][kBatchCap]
+    int largest;
+};
+
+// S[q][row] for the tile; MODE 0: write scores out[q * out_pitch + row]; MODE 1: filter.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void u8_gemm_kernel(const uint8_t *__restrict__ codes,
+                                                          const float *__restrict__ v_offsets,
+                                                          const uint8_t *__restrict__ qcodes,
+                                                          const float *__restrict__ q_offsets, float multiplier,
+                                                          uint32_t n_rows, uint32_t n_queries, uint32_t ad,
+                                                          uint32_t q_tiles, float *__restrict__ out,
+                                                          uint64_t out_pitch, BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];  // [buffer][A|B][row][pitch], 72 KiB
+    uint8_t(*lds)[2][TQ * PITCH] = reinterpret_cast<uint8_t(*)[2][TQ * PITCH]>(lds_raw);
+    // XCD-aware tile map: blocks b, b+8, b+16, ... (one XCD under round-robin dispatch) walk the
+    // query tiles of ONE row tile; speed only, any placement is correct.
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, w = b >> 3;
+    const uint32_t q_tile = w % q_tiles;
+    const uint32_t r_tile = (w / q_tiles) * 8u + xcd;
+    const uint64_t row0 = (uint64_t)r_tile * TR;
+    if (row0 >= n_rows) return;
+    const uint32_t q0 = q_tile * TQ;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wq = wave >> 1, wr = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // staging role: thread -> (row t/8 + 32*i, 16-byte chunk t%8) of both operands
+    const int s_chunk = t & 7, s_row = t >> 3;
+    const uint8_t *gA = qcodes + (uint64_t)(q0 + s_row) * ad + s_chunk * 16;
+    const uint8_t *gB = codes + (row0 + s_row) * ad + s_chunk * 16;
+    const uint32_t n_slabs = (ad + BK - 1) / BK;
+
+    uint4 ra[4], rb[4];
+    auto load_slab = [&](uint32_t s) {
+        const uint32_t k = s * BK + s_chunk * 16;
+        const bool in = k < ad;  // ad is a multiple of 16: a chunk is entirely in or out
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ra[i] = in ? *reinterpret_cast<const uint4 *>(gA + (uint64_t)(32 * i) * ad + s * BK) : make_uint4(0, 0, 0, 0);
+            rb[i] = in ? *reinterpret_cast<const uint4 *>(gB + (uint64_t)(32 * i) * ad + s * BK) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<uint4 *>(&lds[buf][0][(s_row + 32 * i) * PITCH + s_chunk * 16]) = ra[i];
+            *reinterpret_cast<uint4 *>(&lds[buf][1][(s_row + 32 * i) * PITCH + s_chunk * 16]) = rb[i];
+        }
+    };
+
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (uint32_t s = 0; s < n_slabs; s++) {
+        const int cur = s & 1;
+        if (s + 1 < n_slabs) load_slab(s + 1);
+        const uint8_t *A = &lds[cur][0][(wq * 64 + r) * PITCH + h * 16];
+        const uint8_t *B = &lds[cur][1][(wr * 64 + r) * PITCH + h * 16];
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ks++) {
+            const v4i a0 = *reinterpret_cast<const v4i *>(A + ks * 32);
+            const v4i a1 = *reinterpret_cast<const v4i *>(A + 32 * PITCH + ks * 32);
+            const v4i b0 = *reinterpret_cast<const v4i *>(B + ks * 32);
+            const v4i b1 = *reinterpret_cast<const v4i *>(B + 32 * PITCH + ks * 32);
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < n_slabs) store_slab(cur ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2)
+    // + 4*(lane >> 5): query index on the registers, store row on the lanes (coalesced writes).
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uint64_t row = row0 + wr * 64 + j * 32 + r;
+        const float v_off = v_offsets[row];  // padded like codes[]
+        const bool row_ok = row < n_rows;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const uint32_t q = q0 + wq * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float sc = (multiplier * (float)acc[i][j][e] + q_offsets[q]) + v_off;
+                if (MODE == 0) {
+                    if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc;
+                } else if (row_ok && q < n_queries) {
+                    const uint32_t key = topk_ordered_bits(sc, filt.largest != 0);
+                    if (key <= filt.pivots[q]) {
+                        const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
+                        if (pos < kBatchCap)
+                            filt.candidates[(uint64_t)q * kBatchCap + pos] = ((unsigned long long)key << 32) | (uint32_t)row;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Gather `n` sampled rows (codes + offsets) into a dense sub-store for the pivot pass.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *__restrict__ codes,
+                                                         const float *__restrict__ offsets, uint32_t row_chunks,
+                                                         uint64_t n_rows, uint32_t n, uint4 *__restrict__ out_codes,
+                                                         float *__restrict__ out_offsets) {
+    const uint64_t total = (uint64_t)n * row_chunks;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t j = (uint32_t)(i / row_chunks), c = (uint32_t)(i % row_chunks);
+        const unsigned long long hsh = (unsigned long long)j * 0x9E3779B97F4A7C15ull;
+        const uint64_t src = ((hsh >> 32) * n_rows) >> 32;  // same golden-ratio scatter as topk.hip
+        out_codes[i] = codes[src * row_chunks + c];
+        if (c == 0) out_offsets[j] = offsets[src];
+    }
+}
+
+// Per-query pivot (grid = queries): r-th best of 1024 per-thread bests of the query's sample
+// scores (see pivot_kernel in topk.hip), and counter reset.
+__global__ __launch_bounds__(1024) void batch_pivot_kernel(const float *__restrict__ sample, uint32_t S,
+                                                          uint64_t pitch, uint32_t r, int largest,
+                                                          uint32_t *__restrict__ pivots,
+                                                          uint32_t *__restrict__ counters) {
+    __shared__ uint32_t best[1024];
+    const int t = threadIdx.x;
+    const float *mine_row = sample + (uint64_t)blockIdx.x * pitch;
+    uint32_t mine = 0xFFFFFFFFu;
+    for (uint32_t i = t; i < S; i += 1024) {
+        const uint32_t key = topk_ordered_bits(mine_row[i], largest != 0);
+        mine = key < mine ? key : mine;
+    }
+    best[t] = mine;
+    __syncthreads();
+    for (int size = 2; size <= 1024; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int partner = t ^ stride;
+            if (partner > t) {
+                const bool up = (t & size) == 0;
+                const uint32_t a = best[t], bb = best[partner];
+                if ((a > bb) == up) {
+                    best[t] = bb;
+                    best[partner] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        r = r < 1 ? 1 : (r > 1024 ? 1024 : r);
+        pivots[blockIdx.x] = best[r - 1];
+        counters[(uint64_t)blockIdx.x * kCounterStride] = 0;
+    }
+}
+
+// Per-query emit (grid = queries): sort the query's candidates, write its k best; status 1
+// when the list over- or under-flowed (that query is redone exactly by the caller).
+__global__ __launch_bounds__(1024) void batch_emit_kernel(const unsigned long long *__restrict__ cand,
+                                                         const uint32_t *__restrict__ counters, uint64_t n,
+                                                         uint32_t k, int largest, uint32_t *__restrict__ out_ids,
+                                                         float *__restrict__ out_scores,
+                                                         uint32_t *__restrict__ status) {
+    __shared__ unsigned long long s[kBatchCap];
+    const int t = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t pushed = counters[(uint64_t)q * kCounterStride];
+    const uint32_t k_eff = n < k ? (uint32_t)n : k;
+    if (pushed > kBatchCap || pushed < k_eff) {
+        if (t == 0) status[q] = 1;
+        return;
+    }
+    uint32_t N = 64;
+    while (N < pushed) N <<= 1;
+    const unsigned long long *mine = cand + (uint64_t)q * kBatchCap;
+    for (uint32_t i = t; i < N; i += 1024) s[i] = i < pushed ? mine[i] : ~0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= N; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = t; i < N / 2; i += 1024) {
+                const uint32_t a = 2 * i - (i & (stride - 1));
+                const uint32_t bb = a + stride;
+                const bool up = (a & size) == 0;
+                const unsigned long long x = s[a], y = s[bb];
+                if ((x > y) == up) {
+                    s[a] = y;
+                    s[bb] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = t; i < k; i += 1024) {
+        if (i < k_eff) {
+            out_ids[(uint64_t)q * k + i] = (uint32_t)(s[i] & 0xFFFFFFFFull);
+            out_scores[(uint64_t)q * k + i] = topk_score_of_key((uint32_t)(s[i] >> 32), largest != 0);
+        } else {
+            out_ids[(uint64_t)q * k + i] = 0xFFFFFFFFu;
+            out_scores[(uint64_t)q * k + i] = largest ? -__builtin_huge_valf() : __builtin_huge_valf();
+        }
+    }
+    if (t == 0) status[q] = 0;
+}
+
+}  // namespace
+
+struct qamd_u8_query_batch {
+    int device = 0;
+    uint64_t actual_dim = 0;
+    uint64_t n_queries = 0;
+    uint64_t q_pad = 0;  // round_up(n_queries, 128)
+    DevBuf codes;        // [q_pad][actual_dim], zero rows past n_queries
+    DevBuf offsets;      // [q_pad] f32
+};
+
+namespace {
+
+qamd_status check_batch(const qamd_u8 *h, const qamd_u8_query_batch *b) {
+    if (!h || !b) return fail(QAMD_ERR_ARGUMENTS, "null handle or query batch");
+    if (b->actual_dim != h->meta.actual_dim)
+        return fail(QAMD_ERR_ARGUMENTS, "queries have %llu codes, store rows have %llu",
+                    (unsigned long long)b->actual_dim, (unsigned long long)h->meta.actual_dim);
+    if (h->meta.vector_parameters.distance_type == QAMD_L1)
+        return fail(QAMD_ERR_ARGUMENTS, "the multi-query path covers Dot and L2 (the dot kernel); L1 has no MFMA form");
+    return QAMD_OK;
+}
+
+// Launch the GEMM over rows [0, n_rows) of (codes, offsets) for every query of the batch.
+template <int MODE>
+qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                        const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                        const BatchFilter &filt, hipStream_t s) {
+    if (n_rows == 0 || b->n_queries == 0) return QAMD_OK;
+    const uint32_t q_tiles = (uint32_t)(b->q_pad / TQ);
+    const uint64_t r_tiles = round_up((n_rows + TR - 1) / TR, 8);  // whole groups of 8 row tiles (one per XCD)
+    const uint64_t blocks = r_tiles * q_tiles;
+    if (blocks > 0x7FFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "batch too large for one launch");
+    constexpr size_t lds_bytes = 2 * 2 * TQ * PITCH;
+    static std::once_flag once;  // one flag per MODE instantiation
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
+    hipLaunchKernelGGL((u8_gemm_kernel<MODE>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, codes, v_offsets,
+                       b->codes.as<uint8_t>(), b->offsets.as<float>(), h->meta.multiplier, (uint32_t)n_rows,
+                       (uint32_t)b->n_queries, (uint32_t)h->meta.actual_dim, q_tiles, out, out_pitch, filt);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, uint64_t n_queries, uint64_t qdim,
+                                       qamd_mem queries_mem, void *stream, qamd_u8_query_batch **batch_io) {
+    if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    const uint64_t ad = qdim + (16 - qdim % 16) % 16;
+    qamd_u8_query_batch *b = *batch_io;
+    std::unique_ptr<qamd_u8_query_batch> fresh;
+    if (!b) {
+        fresh.reset(new qamd_u8_query_batch);
+        b = fresh.get();
+        b->device = h->device;
+    }
+    const uint64_t q_pad = round_up(std::max<uint64_t>(n_queries, 1), TQ);
+    if (b->actual_dim != ad || b->q_pad != q_pad || !b->codes.ptr) {
+        QAMD_TRY(b->codes.alloc(q_pad * std::max<uint64_t>(ad, 16), true));
+        QAMD_TRY(b->offsets.alloc(q_pad * sizeof(float), true));
+        b->actual_dim = ad;
+        b->q_pad = q_pad;
+    } else {
+        QAMD_HIP(hipMemsetAsync(b->codes.ptr, 0, b->codes.bytes, s));
+        QAMD_HIP(hipMemsetAsync(b->offsets.ptr, 0, b->offsets.bytes, s));
+    }
+    b->n_queries = n_queries;
+    if (n_queries) {
+        DevBuf tmp;
+        const float *qd = queries;
+        if (queries_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(tmp.alloc(n_queries * std::max<uint64_t>(qdim, 1) * 4));
+            QAMD_TRY(copy_in(tmp.ptr, queries, QAMD_MEM_HOST, n_queries * qdim * 4, s));
+            qd = tmp.as<float>();
+        }
+        QAMD_TRY(u8_encode_queries_device(h, qd, n_queries, qdim, b->codes.as<uint8_t>(), b->offsets.as<float>(), s));
+        if (queries_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
+    }
+    if (fresh) *batch_io = fresh.release();
+    return QAMD_OK;
+}
+
+void qamd_u8_query_batch_free(qamd_u8_query_batch *b) { delete b; }
+
+qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, float *out, qamd_mem out_mem,
+                                void *stream) {
+    QAMD_TRY(check_batch(h, b));
+    if (h->count == 0 || b->n_queries == 0) return QAMD_OK;
+    if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    const uint64_t total = b->n_queries * h->count;
+    DevBuf tmp;
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(tmp.alloc(total * 4));
+        out_dev = tmp.as<float>();
+    }
+    QAMD_TRY(launch_gemm<0>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), h->count, out_dev, h->count,
+                            BatchFilter{}, s));
+    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, total * 4, s));
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, uint32_t k, int largest,
+                               uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_batch(h, b));
+    if (k == 0 || b->n_queries == 0) return QAMD_OK;
+    if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
+    if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
+    QAMD_TRY(ensure_device(h->device));
+    hipStream_t s = as_stream(stream);
+    const uint64_t Q = b->n_queries, n = h->count;
+    const uint32_t S = kTopkSample;
+    const double target = std::max<double>(2048.0, 3.0 * k);
+    const uint32_t r = n ? (uint32_t)std::ceil((double)S * target / (double)n) : 0;
+    const bool fused = n >= (1u << 20) && r <= 64;
+
+    DevBuf ids_tmp, sc_tmp;
+    uint32_t *ids_dev = out_ids;
+    float *sc_dev = out_scores;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(ids_tmp.alloc(Q * k * 4));
+        QAMD_TRY(sc_tmp.alloc(Q * k * 4));
+        ids_dev = ids_tmp.as<uint32_t>();
+        sc_dev = sc_tmp.as<float>();
+    }
+    std::vector<uint32_t> status(Q, 1);
+    if (fused) {
+        const uint64_t ad = h->meta.actual_dim;
+        DevBuf s_codes, s_offs, s_scores, pivots, counters, cand, status_dev;
+        QAMD_TRY(s_codes.alloc((uint64_t)(S + TR) * ad, true));
+        QAMD_TRY(s_offs.alloc((uint64_t)(S + TR) * 4, true));
+        QAMD_TRY(s_scores.alloc(Q * (uint64_t)S * 4));
+        QAMD_TRY(pivots.alloc(b->q_pad * 4, true));
+        QAMD_TRY(counters.alloc(b->q_pad * kCounterStride * 4, true));
+        QAMD_TRY(cand.alloc(Q * (uint64_t)kBatchCap * 8));
+        QAMD_TRY(status_dev.alloc(Q * 4));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->codes.as<uint4>(),
+                           h->offsets.as<float>(), h->row_chunks, n, S, s_codes.as<uint4>(), s_offs.as<float>());
+        QAMD_TRY(launch_gemm<0>(h, b, s_codes.as<uint8_t>(), s_offs.as<float>(), S, s_scores.as<float>(), S,
+                                BatchFilter{}, s));
+        hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)Q), dim3(1024), 0, s, s_scores.as<float>(), S,
+                           (uint64_t)S, r, largest, pivots.as<uint32_t>(), counters.as<uint32_t>());
+        BatchFilter f{pivots.as<uint32_t>(), counters.as<uint32_t>(), cand.as<unsigned long long>(), largest};
+        QAMD_TRY(launch_gemm<1>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
+        hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand.as<unsigned long long>(),
+                           counters.as<uint32_t>(), n, k, largest, ids_dev, sc_dev, status_dev.as<uint32_t>());
+        QAMD_HIP(hipGetLastError());
+        QAMD_TRY(copy_out(status.data(), QAMD_MEM_HOST, status_dev.ptr, Q * 4, s));  // synchronises
+    }
+    // Queries not served by the fused pass (small stores, overflowed lists): exact single-query path.
+    for (uint64_t q = 0; q < Q; q++) {
+        if (!status[q]) continue;
+        QAMD_TRY(u8_topk_single(h, b->codes.as<uint8_t>() + q * b->actual_dim, b->offsets.as<float>() + q, k, largest,
+                                ids_dev + q * k, sc_dev + q * k, QAMD_MEM_DEVICE, s));
+    }
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(copy_out(out_ids, QAMD_MEM_HOST, ids_dev, Q * k * 4, s));
+        QAMD_TRY(copy_out(out_scores, QAMD_MEM_HOST, sc_dev, Q * k * 4, s));
+    } else {
+        QAMD_HIP(hipStreamSynchronize(s));  // scratch buffers are released on return
+    }
+    return QAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// Handle layouts of the scalar-u8 quantizer, shared by u8.hip (single-query path) and
+// u8_batch.hip (multi-query MFMA path).  Not part of the C ABI.
+#pragma once
+#include "common.hpp"
+
+struct qamd_u8 {
+    int device = 0;
+    qamd_u8_metadata meta{};
+    uint64_t count = 0;
+    uint64_t padded_rows = 0;  // round_up(count, 1024) + 1024 zero rows: tiles never need a load guard
+    uint32_t row_chunks = 0;   // actual_dim / 16
+    int lane_mode = 0;         // 0: integer sum rounded once; 1: avx2.c lane order
+    qamd::DevBuf codes;        // [padded_rows][actual_dim]
+    qamd::DevBuf offsets;      // [padded_rows] f32
+};
+
+struct qamd_u8_query {
+    int device = 0;
+    uint64_t actual_dim = 0;
+    qamd::DevBuf buf;  // [0..4) offset f32, [16..16+actual_dim) codes
+};
+
+// encode_query for one query per wave (device-resident f32 queries); defined in u8.hip.
+namespace qamd {
+qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev, uint64_t n_queries, uint64_t qdim,
+                                     uint8_t *codes_dev /* [n][actual_dim] */, float *offsets_dev /* [n] */,
+                                     hipStream_t stream);
+qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,
+                           int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);
+}  // namespace qamd

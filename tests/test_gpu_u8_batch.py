@@ -1,0 +1,83 @@
+"""Multi-query MFMA path (qamd_u8_*_batch): every score / neighbour list must be bit-identical
+to the single-query path, which is itself pinned to the oracle (test_gpu_u8.py)."""
+import numpy as np
+import pytest
+
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+qa = pytest.importorskip("quantization_amd")
+D = qa.DistanceType
+
+
+@pytest.mark.parametrize("n,dim,nq", [(1000, 768, 5), (300, 65, 130), (5000, 1536, 64), (129, 16, 3),
+                                      (700, 100, 257), (64, 2048, 2), (2500, 128, 1)])
+@pytest.mark.parametrize("dist,invert", [(D.Dot, False), (D.L2, False), (D.Dot, True)])
+def test_score_batch_equals_single_query_and_oracle(qo, n, dim, nq, dist, invert):
+    rng = np.random.default_rng(n + dim + nq)
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
+    batch = enc.encode_query_batch(queries)
+    got = enc.score_batch(batch)
+    assert got.shape == (nq, n)
+    rows, meta = qo.u8_encode(data, int(dist), invert)
+    for qi in sorted({0, nq // 2, nq - 1}):
+        codes, qoff = qo.u8_encode_query(meta, queries[qi])
+        want = qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_SIMPLE)
+        assert_bits_equal(got[qi], want, f"query {qi} vs oracle")
+    single = np.stack([enc.score_all(enc.encode_query(queries[qi])) for qi in range(min(nq, 8))])
+    assert_bits_equal(got[: single.shape[0]], single, "batch vs single-query path")
+
+
+def test_batch_l1_is_rejected():
+    data = np.zeros((10, 16), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(16, 10, D.L1, False))
+    b = enc.encode_query_batch(data[:2])
+    with pytest.raises(qa.EncodingError):
+        enc.score_batch(b)
+
+
+def test_device_queries_and_outputs(qo):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    n, dim, nq = 4000, 256, 40
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(torch.from_numpy(data).cuda(), qa.VectorParameters(dim, n, D.Dot, False))
+    batch = enc.encode_query_batch(torch.from_numpy(queries).cuda())
+    out = torch.empty((nq, n), dtype=torch.float32, device="cuda")
+    enc.score_batch(batch, out=out)
+    torch.cuda.synchronize()
+    host = enc.score_batch(enc.encode_query_batch(queries))
+    assert_bits_equal(out.cpu().numpy(), host, "device vs host queries")
+
+
+@pytest.mark.parametrize("largest", [True, False])
+def test_topk_batch_small_store_uses_exact_single_query_path(largest):
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 20000, 64, 9, 25
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    ids, sc = enc.topk_batch(enc.encode_query_batch(queries), k, largest=largest)
+    for qi in range(nq):
+        wi, ws = enc.topk(enc.encode_query(queries[qi]), k, largest=largest)
+        assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("k,largest", [(30, True), (200, False)])
+def test_topk_batch_fused_large_store(k, largest):
+    """n >= 2^20: per-query pivots from the sampled sub-store, FILTER epilogue, per-query sort."""
+    rng = np.random.default_rng(7)
+    n, dim, nq = 1_300_000, 64, 150
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L2, False))
+    ids, sc = enc.topk_batch(enc.encode_query_batch(queries), k, largest=largest)
+    for qi in (0, 1, 77, nq - 1):
+        scores = enc.score_all(enc.encode_query(queries[qi]))
+        order = np.lexsort((np.arange(n), -scores if largest else scores))[:k]
+        assert np.array_equal(ids[qi], order.astype(np.uint32)), qi
+        assert np.array_equal(sc[qi].view(np.uint32), scores[order].view(np.uint32))
