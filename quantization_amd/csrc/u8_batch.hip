@@ -27,6 +27,7 @@
 // are redone through the exact single-query path.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -42,10 +43,9 @@ using namespace qamd;
 
 namespace {
 
-constexpr int TQ = 128, TR = 128;  // workgroup tile: queries x rows
+constexpr int TQ = 256, TR = 256;  // largest workgroup tile (queries x rows): padding granularity
 constexpr int BK = 128;            // K slab in bytes
 constexpr int PITCH = BK + 16;     // LDS row pitch
-constexpr int kThreads = 256;
 constexpr uint32_t kBatchCap = kTopkCandCap;  // candidate slots per query
 constexpr uint32_t kCounterStride = 16;       // u32: one counter per 64-byte line
 
@@ -60,60 +60,75 @@ struct BatchFilter {
 };
 
 // S[q][row] for the tile; MODE 0: write scores out[q * out_pitch + row]; MODE 1: filter.
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void u8_gemm_kernel(const uint8_t *__restrict__ codes,
-                                                          const float *__restrict__ v_offsets,
-                                                          const uint8_t *__restrict__ qcodes,
-                                                          const float *__restrict__ q_offsets, float multiplier,
-                                                          uint32_t n_rows, uint32_t n_queries, uint32_t ad,
-                                                          uint32_t q_tiles, float *__restrict__ out,
-                                                          uint64_t out_pitch, BatchFilter filt) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];  // [buffer][A|B][row][pitch], 72 KiB
-    uint8_t(*lds)[2][TQ * PITCH] = reinterpret_cast<uint8_t(*)[2][TQ * PITCH]>(lds_raw);
+// Tile TQ queries x TR rows per workgroup, WQ x WR waves, each wave (MI*32) x (MJ*32) outputs.
+//   <128,128,2,2>: 4 waves, 72 KiB LDS  — small batches (padding to 128 queries)
+//   <256,256,2,4>: 8 waves, 144 KiB LDS — the guide's 256^2 shape: a 128^2 tile needs 32 KiB of
+//   operands per 512 MFMA cycles, more than one CU's share of L2 bandwidth (~55 B/clk), and
+//   measured 13 % of the int8 MFMA peak; at 256^2 the slab is 64 KiB per 2048 MFMA cycles.
+template <int MODE, int TQ_, int TR_, int WQ, int WR>
+__global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__restrict__ codes,
+                                                              const float *__restrict__ v_offsets,
+                                                              const uint8_t *__restrict__ qcodes,
+                                                              const float *__restrict__ q_offsets, float multiplier,
+                                                              uint32_t n_rows, uint32_t n_queries, uint32_t ad,
+                                                              uint32_t q_tiles, float *__restrict__ out,
+                                                              uint64_t out_pitch, BatchFilter filt) {
+    constexpr int T = 64 * WQ * WR;
+    constexpr int MI = TQ_ / WQ / 32, MJ = TR_ / WR / 32;
+    constexpr int ROWS_PER_PASS = T / 8;  // 8 lanes x 16 B cover one 128-byte slab row
+    constexpr int LA = TQ_ / ROWS_PER_PASS, LB = TR_ / ROWS_PER_PASS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    // layout: buffer b: A at b*(TQ+TR)*PITCH, B right after A
+    auto ldsA = [&](int buf) { return lds_raw + (size_t)buf * (TQ_ + TR_) * PITCH; };
+    auto ldsB = [&](int buf) { return lds_raw + (size_t)buf * (TQ_ + TR_) * PITCH + (size_t)TQ_ * PITCH; };
     // XCD-aware tile map: blocks b, b+8, b+16, ... (one XCD under round-robin dispatch) walk the
     // query tiles of ONE row tile; speed only, any placement is correct.
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u, w = b >> 3;
     const uint32_t q_tile = w % q_tiles;
     const uint32_t r_tile = (w / q_tiles) * 8u + xcd;
-    const uint64_t row0 = (uint64_t)r_tile * TR;
+    const uint64_t row0 = (uint64_t)r_tile * TR_;
     if (row0 >= n_rows) return;
-    const uint32_t q0 = q_tile * TQ;
+    const uint32_t q0 = q_tile * TQ_;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wq = wave >> 1, wr = wave & 1;
+    const int wq = wave / WR, wr = wave % WR;
     const int r = lane & 31, h = lane >> 5;
 
-    // staging role: thread -> (row t/8 + 32*i, 16-byte chunk t%8) of both operands
     const int s_chunk = t & 7, s_row = t >> 3;
     const uint8_t *gA = qcodes + (uint64_t)(q0 + s_row) * ad + s_chunk * 16;
     const uint8_t *gB = codes + (row0 + s_row) * ad + s_chunk * 16;
     const uint32_t n_slabs = (ad + BK - 1) / BK;
 
-    uint4 ra[4], rb[4];
+    uint4 ra[LA], rb[LB];
     auto load_slab = [&](uint32_t s) {
         const uint32_t k = s * BK + s_chunk * 16;
         const bool in = k < ad;  // ad is a multiple of 16: a chunk is entirely in or out
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            ra[i] = in ? *reinterpret_cast<const uint4 *>(gA + (uint64_t)(32 * i) * ad + s * BK) : make_uint4(0, 0, 0, 0);
-            rb[i] = in ? *reinterpret_cast<const uint4 *>(gB + (uint64_t)(32 * i) * ad + s * BK) : make_uint4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < LA; i++)
+            ra[i] = in ? *reinterpret_cast<const uint4 *>(gA + (uint64_t)(ROWS_PER_PASS * i) * ad + s * BK)
+                       : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LB; i++)
+            rb[i] = in ? *reinterpret_cast<const uint4 *>(gB + (uint64_t)(ROWS_PER_PASS * i) * ad + s * BK)
+                       : make_uint4(0, 0, 0, 0);
     };
     auto store_slab = [&](int buf) {
+        uint8_t *a = ldsA(buf), *bb = ldsB(buf);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            *reinterpret_cast<uint4 *>(&lds[buf][0][(s_row + 32 * i) * PITCH + s_chunk * 16]) = ra[i];
-            *reinterpret_cast<uint4 *>(&lds[buf][1][(s_row + 32 * i) * PITCH + s_chunk * 16]) = rb[i];
-        }
+        for (int i = 0; i < LA; i++)
+            *reinterpret_cast<uint4 *>(a + (s_row + ROWS_PER_PASS * i) * PITCH + s_chunk * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; i++)
+            *reinterpret_cast<uint4 *>(bb + (s_row + ROWS_PER_PASS * i) * PITCH + s_chunk * 16) = rb[i];
     };
 
-    v16i acc[2][2];
+    v16i acc[MI][MJ];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < MJ; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
 
@@ -123,18 +138,20 @@ __global__ __launch_bounds__(kThreads) void u8_gemm_kernel(const uint8_t *__rest
     for (uint32_t s = 0; s < n_slabs; s++) {
         const int cur = s & 1;
         if (s + 1 < n_slabs) load_slab(s + 1);
-        const uint8_t *A = &lds[cur][0][(wq * 64 + r) * PITCH + h * 16];
-        const uint8_t *B = &lds[cur][1][(wr * 64 + r) * PITCH + h * 16];
+        const uint8_t *A = ldsA(cur) + (wq * (MI * 32) + r) * PITCH + h * 16;
+        const uint8_t *B = ldsB(cur) + (wr * (MJ * 32) + r) * PITCH + h * 16;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ks++) {
-            const v4i a0 = *reinterpret_cast<const v4i *>(A + ks * 32);
-            const v4i a1 = *reinterpret_cast<const v4i *>(A + 32 * PITCH + ks * 32);
-            const v4i b0 = *reinterpret_cast<const v4i *>(B + ks * 32);
-            const v4i b1 = *reinterpret_cast<const v4i *>(B + 32 * PITCH + ks * 32);
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+            v4i a[MI], bf[MJ];
+#pragma unroll
+            for (int i = 0; i < MI; i++) a[i] = *reinterpret_cast<const v4i *>(A + i * 32 * PITCH + ks * 32);
+#pragma unroll
+            for (int j = 0; j < MJ; j++) bf[j] = *reinterpret_cast<const v4i *>(B + j * 32 * PITCH + ks * 32);
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < MJ; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (s + 1 < n_slabs) store_slab(cur ^ 1);
         __syncthreads();
@@ -142,25 +159,44 @@ __global__ __launch_bounds__(kThreads) void u8_gemm_kernel(const uint8_t *__rest
 
     // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2)
     // + 4*(lane >> 5): query index on the registers, store row on the lanes (coalesced writes).
+    // The tile's per-query constants (offset, pivot key) go through LDS once: read per element
+    // from global memory they were 256 loads per lane and dominated the whole kernel.
+    float *q_off_s = reinterpret_cast<float *>(lds_raw);            // [TQ_]   (operand buffers are dead now)
+    uint32_t *pivot_s = reinterpret_cast<uint32_t *>(lds_raw) + TQ_;  // [TQ_]
+    for (int i = t; i < TQ_; i += T) {
+        q_off_s[i] = q_offsets[q0 + i];
+        if (MODE == 1) pivot_s[i] = filt.pivots[q0 + i];
+    }
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const uint64_t row = row0 + wr * 64 + j * 32 + r;
+    for (int j = 0; j < MJ; j++) {
+        const uint64_t row = row0 + wr * (MJ * 32) + j * 32 + r;
         const float v_off = v_offsets[row];  // padded like codes[]
         const bool row_ok = row < n_rows;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < MI; i++) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const uint32_t q = q0 + wq * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float sc = (multiplier * (float)acc[i][j][e] + q_offsets[q]) + v_off;
-                if (MODE == 0) {
-                    if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc;
-                } else if (row_ok && q < n_queries) {
-                    const uint32_t key = topk_ordered_bits(sc, filt.largest != 0);
-                    if (key <= filt.pivots[q]) {
-                        const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
-                        if (pos < kBatchCap)
-                            filt.candidates[(uint64_t)q * kBatchCap + pos] = ((unsigned long long)key << 32) | (uint32_t)row;
+            for (int g = 0; g < 4; g++) {  // registers 4g .. 4g+3 are four consecutive queries
+                const uint32_t ql = wq * (MI * 32) + i * 32 + 8 * g + 4 * h;
+                const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
+                const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                uint4 pv4 = make_uint4(0, 0, 0, 0);
+                if (MODE == 1) pv4 = *reinterpret_cast<const uint4 *>(pivot_s + ql);
+                const uint32_t pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t q = q0 + ql + e;
+                    const float sc = (multiplier * (float)acc[i][j][4 * g + e] + qo[e]) + v_off;
+                    if (MODE == 0) {
+                        if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc;
+                    } else if (row_ok && q < n_queries) {
+                        const uint32_t key = topk_ordered_bits(sc, filt.largest != 0);
+                        if (key <= pv[e]) {
+                            const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
+                            if (pos < kBatchCap)
+                                filt.candidates[(uint64_t)q * kBatchCap + pos] =
+                                    ((unsigned long long)key << 32) | (uint32_t)row;
+                        }
                     }
                 }
             }
@@ -292,26 +328,43 @@ qamd_status check_batch(const qamd_u8 *h, const qamd_u8_query_batch *b) {
 }
 
 // Launch the GEMM over rows [0, n_rows) of (codes, offsets) for every query of the batch.
+template <int MODE, int TQ_, int TR_, int WQ, int WR>
+qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                            const BatchFilter &filt, hipStream_t s) {
+    const uint32_t q_tiles = (uint32_t)((b->n_queries + TQ_ - 1) / TQ_);  // q_pad (multiple of 256) covers them
+    const uint64_t r_tiles = round_up((n_rows + TR_ - 1) / TR_, 8);  // whole groups of 8 row tiles (one per XCD)
+    const uint64_t blocks = r_tiles * q_tiles;
+    if (blocks > 0x7FFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "batch too large for one launch");
+    constexpr size_t lds_bytes = (size_t)2 * (TQ_ + TR_) * PITCH;
+    static std::once_flag once;  // one flag per instantiation
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
+    hipLaunchKernelGGL((u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR>), dim3((unsigned)blocks), dim3(64 * WQ * WR), lds_bytes,
+                       s, codes, v_offsets, b->codes.as<uint8_t>(), b->offsets.as<float>(), h->meta.multiplier,
+                       (uint32_t)n_rows, (uint32_t)b->n_queries, (uint32_t)h->meta.actual_dim, q_tiles, out, out_pitch,
+                       filt);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
 template <int MODE>
 qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                         const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                         const BatchFilter &filt, hipStream_t s) {
     if (n_rows == 0 || b->n_queries == 0) return QAMD_OK;
-    const uint32_t q_tiles = (uint32_t)(b->q_pad / TQ);
-    const uint64_t r_tiles = round_up((n_rows + TR - 1) / TR, 8);  // whole groups of 8 row tiles (one per XCD)
-    const uint64_t blocks = r_tiles * q_tiles;
-    if (blocks > 0x7FFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "batch too large for one launch");
-    constexpr size_t lds_bytes = 2 * 2 * TQ * PITCH;
-    static std::once_flag once;  // one flag per MODE instantiation
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    });
-    hipLaunchKernelGGL((u8_gemm_kernel<MODE>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, codes, v_offsets,
-                       b->codes.as<uint8_t>(), b->offsets.as<float>(), h->meta.multiplier, (uint32_t)n_rows,
-                       (uint32_t)b->n_queries, (uint32_t)h->meta.actual_dim, q_tiles, out, out_pitch, filt);
-    QAMD_HIP(hipGetLastError());
-    return QAMD_OK;
+    // q_pad is a multiple of 256 and the row padding of every store covers a 256-row tile.
+    if (b->n_queries > 128) {
+        static const char *cfg = getenv("QAMD_GEMM_CFG");  // developer A/B switch
+        if (cfg && cfg[0] == '1')
+            return launch_gemm_cfg<MODE, 256, 256, 4, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        if (cfg && cfg[0] == '2')
+            return launch_gemm_cfg<MODE, 256, 128, 4, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        return launch_gemm_cfg<MODE, 256, 256, 2, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    }
+    return launch_gemm_cfg<MODE, 128, 128, 2, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
 }
 
 }  // namespace
@@ -406,7 +459,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     if (fused) {
         const uint64_t ad = h->meta.actual_dim;
         DevBuf s_codes, s_offs, s_scores, pivots, counters, cand, status_dev;
-        QAMD_TRY(s_codes.alloc((uint64_t)(S + TR) * ad, true));
+        QAMD_TRY(s_codes.alloc((uint64_t)(S + TR) * ad, true));  // + one tile of zero rows
         QAMD_TRY(s_offs.alloc((uint64_t)(S + TR) * 4, true));
         QAMD_TRY(s_scores.alloc(Q * (uint64_t)S * 4));
         QAMD_TRY(pivots.alloc(b->q_pad * 4, true));
@@ -425,6 +478,21 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
                            counters.as<uint32_t>(), n, k, largest, ids_dev, sc_dev, status_dev.as<uint32_t>());
         QAMD_HIP(hipGetLastError());
         QAMD_TRY(copy_out(status.data(), QAMD_MEM_HOST, status_dev.ptr, Q * 4, s));  // synchronises
+        if (getenv("QAMD_DEBUG_TOPK")) {
+            std::vector<uint32_t> cnt(b->q_pad * kCounterStride);
+            (void)hipMemcpy(cnt.data(), counters.ptr, cnt.size() * 4, hipMemcpyDeviceToHost);
+            uint32_t mx = 0, mn = ~0u, redo = 0;
+            uint64_t sum = 0;
+            for (uint64_t q = 0; q < Q; q++) {
+                const uint32_t c = cnt[q * kCounterStride];
+                mx = std::max(mx, c);
+                mn = std::min(mn, c);
+                sum += c;
+                redo += status[q];
+            }
+            fprintf(stderr, "[qamd topk_batch] Q=%llu r=%u candidates min/mean/max = %u/%llu/%u, %u queries redone\n",
+                    (unsigned long long)Q, r, mn, (unsigned long long)(sum / Q), mx, redo);
+        }
     }
     // Queries not served by the fused pass (small stores, overflowed lists): exact single-query path.
     for (uint64_t q = 0; q < Q; q++) {

@@ -39,7 +39,7 @@ def report(name, rows, bytes_per_row, med, mn, **kw):
                       "frac_of_8TBps": round(rows * bytes_per_row / med / 1e6 / 8000, 4), **kw}), flush=True)
 
 
-which = set(sys.argv[1:]) or {"u8", "bin", "pq", "topk", "ids", "encode"}
+which = set(sys.argv[1:]) or {"u8", "bin", "pq", "topk", "ids", "encode", "batch"}
 
 if "u8" in which or "topk" in which or "ids" in which:
     for dim, n in ((768, 10_000_000), (1536, 5_000_000), (128, 20_000_000), (1024, 8_000_000)):
@@ -126,3 +126,27 @@ if "encode" in which:
     med, mn = timeit(lambda: qa.EncodedVectorsPQ.encode(data[:n3], qa.VectorParameters(dim, n3, D.Dot, False), 8),
                      reps=2, warm=1)
     report("pq_encode incl. k-means training dim768 m96", n3, dim * 4 + 96, med, mn)
+
+if "batch" in which:
+    for dim, n in ((768, 10_000_000), (1536, 12_500_000)):
+        data = torch.rand((n, dim), device=dev)
+        enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+        del data
+        torch.cuda.empty_cache()
+        for nq in [int(x) for x in os.environ.get("BATCH_NQ", "64,256,1024").split(",")]:
+            queries = torch.rand((nq, dim), device=dev)
+            batch = enc.encode_query_batch(queries)
+            ids = torch.empty(nq * 30, dtype=torch.int32, device=dev)
+            sc = torch.empty(nq * 30, dtype=torch.float32, device=dev)
+            med, mn = timeit(lambda: enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc), reps=5, warm=1)
+            ops = 2.0 * nq * n * enc.metadata["actual_dim"]
+            print(json.dumps({"kernel": f"u8_topk_batch k30 dim{dim}", "rows": n, "queries": nq,
+                              "median_ms": round(med, 3), "min_ms": round(mn, 3),
+                              "query_rows_per_s": round(nq * n / med / 1e6, 2), "unit": "G (query,row) pairs/s",
+                              "int8_TOPs": round(ops / med / 1e9, 1),
+                              "frac_of_5000_TOPs_dense_i8_peak": round(ops / med / 1e9 / 5000, 4),
+                              "store_GBps_if_read_once": round(n * enc.scan_bytes_per_row() / med / 1e6, 1),
+                              "speedup_vs_single_query_loop_at_1.12ms": round(nq * 1.12 * (n / 1e7) * (dim / 768) / med, 1)}),
+                  flush=True)
+        del enc
+        torch.cuda.empty_cache()
