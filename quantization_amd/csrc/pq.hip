@@ -129,20 +129,39 @@ template <int J> __device__ __forceinline__ uint4 quad_bcast4(const uint4 &v) {
     return make_uint4(quad_bcast<J>(v.x), quad_bcast<J>(v.y), quad_bcast<J>(v.z), quad_bcast<J>(v.w));
 }
 
-template <int NV, int UNROLL, bool FILTER>
+// One launch handles a SLICE of NVS 16-byte pieces of every row ([piece0, piece0 + NVS), i.e.
+// chunks [16*piece0, ...)) with that slice's LUT in LDS.  A LUT larger than the CU's LDS
+// (m > 144; the reference bench uses m = 512) is scanned slice after slice: lane k's running
+// sum — the reference's SSE lane sum, order unchanged — is parked per row in `partial`
+// between launches (first slice: starts at 0; last slice: combine + tail + output).
+// groups_total = m / 4: chunk groups past it (row padding) are skipped, so any m works.
+// SIMPLE: the whole row is one slice of full pieces (m % 16 == 0, m <= 144): first == last == 1
+// and no padding checks, all resolved at compile time (the m = 96 / m = 16 cases).
+template <int NVS, int UNROLL, bool FILTER, bool SIMPLE>
 __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *__restrict__ rows4,
+                                                                 uint32_t row_pieces_, uint32_t piece0_,
                                                                  const float *__restrict__ lut_g,
+                                                                 uint32_t groups_total_, uint32_t m_, int first_,
+                                                                 int last_, float *__restrict__ partial,
                                                                  uint32_t n_rows, float *__restrict__ out,
                                                                  TopkFilter filt) {
     extern __shared__ __attribute__((aligned(16))) float lut_s[];
+    const uint32_t row_pieces = SIMPLE ? (uint32_t)NVS : row_pieces_;
+    const uint32_t piece0 = SIMPLE ? 0u : piece0_;
+    const uint32_t m = SIMPLE ? (uint32_t)NVS * 16u : m_;
+    const uint32_t groups_total = SIMPLE ? (uint32_t)NVS * 4u : groups_total_;
+    const bool first = SIMPLE ? true : first_ != 0;
+    const bool last = SIMPLE ? true : last_ != 0;
+    const uint32_t chunk0 = piece0 * 16;
     {
-        constexpr uint32_t total4 = NV * 16 * (kCentroids / 4);
-        const float4 *src = reinterpret_cast<const float4 *>(lut_g);
+        const uint32_t chunks_here = min(m - chunk0, (uint32_t)NVS * 16u);
+        const uint32_t total4 = chunks_here * (kCentroids / 4);
+        const float4 *src = reinterpret_cast<const float4 *>(lut_g + (size_t)chunk0 * kCentroids);
         float4 *dst = reinterpret_cast<float4 *>(lut_s);
         for (uint32_t i = threadIdx.x; i < total4; i += kScanBlock) dst[i] = src[i];
         __syncthreads();
     }
-    constexpr int JN = (NV + 3) / 4;
+    constexpr int JN = (NVS + 3) / 4;
     constexpr int TILE = 16 * UNROLL;
     const int lane = threadIdx.x & 63;
     const int k = lane & 3, rslot = lane >> 2;
@@ -150,25 +169,27 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
     const uint64_t n_waves = (uint64_t)gridDim.x * (kScanBlock / 64);
     const float *lut_k = lut_s + k * kCentroids;
     const uint32_t shift = 8 * k;
+    const uint32_t group0 = piece0 * 4;
     uint32_t pivot = 0;
     if (FILTER) pivot = *filt.pivot_key;
     for (uint64_t base = wave * TILE; base < n_rows; base += n_waves * TILE) {
         uint4 mine[UNROLL][JN];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const uint4 *p = rows4 + (base + u * 16 + rslot) * NV;  // rows are zero-padded past n_rows
+            const uint4 *p = rows4 + (base + u * 16 + rslot) * row_pieces + piece0;  // rows are zero-padded
 #pragma unroll
             for (int j = 0; j < JN; j++) {
                 const int piece = k + 4 * j;
-                mine[u][j] = ld_nt(p + (piece < NV ? piece : NV - 1));
+                mine[u][j] = ld_nt(p + (piece < NVS ? piece : NVS - 1));
             }
         }
         float acc[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) acc[u] = 0.0f;
+        for (int u = 0; u < UNROLL; u++) acc[u] = first ? 0.0f : partial[(base + u * 16 + rslot) * 4 + k];
 #pragma unroll
-        for (int pc = 0; pc < NV; pc++) {
+        for (int pc = 0; pc < NVS; pc++) {
             const float *l = lut_k + pc * 16 * kCentroids;  // piece pc = chunk groups 4pc .. 4pc+3
+            const uint32_t g = group0 + 4 * pc;
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
                 const uint4 &held = mine[u][pc / 4];
@@ -179,23 +200,40 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
                     case 2: w = quad_bcast4<2>(held); break;
                     default: w = quad_bcast4<3>(held); break;
                 }
-                acc[u] += l[(w.x >> shift) & 255u];
-                acc[u] += l[4 * kCentroids + ((w.y >> shift) & 255u)];
-                acc[u] += l[8 * kCentroids + ((w.z >> shift) & 255u)];
-                acc[u] += l[12 * kCentroids + ((w.w >> shift) & 255u)];
+                if (SIMPLE || g + 3 < groups_total) {  // wave-uniform: a whole piece of real chunks (the common case)
+                    acc[u] += l[(w.x >> shift) & 255u];
+                    acc[u] += l[4 * kCentroids + ((w.y >> shift) & 255u)];
+                    acc[u] += l[8 * kCentroids + ((w.z >> shift) & 255u)];
+                    acc[u] += l[12 * kCentroids + ((w.w >> shift) & 255u)];
+                } else {  // the row's last, partly padded piece
+                    if (g + 0 < groups_total) acc[u] += l[(w.x >> shift) & 255u];
+                    if (g + 1 < groups_total) acc[u] += l[4 * kCentroids + ((w.y >> shift) & 255u)];
+                    if (g + 2 < groups_total) acc[u] += l[8 * kCentroids + ((w.z >> shift) & 255u)];
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
+            const uint64_t row = base + u * 16 + rslot;
+            if (!last) {
+                partial[row * 4 + k] = acc[u];  // padded like rows
+                continue;
+            }
             // (l0 + l2) + (l1 + l3)  (:430-432): quad_perm DPP reads, no LDS round trip
             const float a = acc[u] + __int_as_float(__builtin_amdgcn_update_dpp(
                                          0, __float_as_int(acc[u]), 0x4E, 0xF, 0xF, false));  // lane ^ 2
-            const float s = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF,
-                                                                          false));  // lane ^ 1
-            const uint64_t row = base + u * 16 + rslot;
+            float sc = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF,
+                                                                       false));  // lane ^ 1
             if (k == 0 && row < n_rows) {
-                if (FILTER) topk_offer(filt, pivot, s, (uint32_t)row);
-                else out[row] = s;
+                if (groups_total * 4 < m) {  // tail chunks (:434-438); their LUT rows are in this slice
+                    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(rows4 + row * row_pieces);
+                    for (uint32_t c = groups_total * 4; c < m; c++) {
+                        const uint32_t code = (p32[c >> 2] >> (8 * (c & 3))) & 255u;
+                        sc += lut_s[(size_t)(c - chunk0) * kCentroids + code];
+                    }
+                }
+                if (FILTER) topk_offer(filt, pivot, sc, (uint32_t)row);
+                else out[row] = sc;
             }
         }
     }
@@ -449,7 +487,8 @@ namespace {
 
 qamd_status alloc_store(qamd_pq *h) {
     h->m = chunks_of(h->vp.dim, h->chunk_size);
-    h->ds = round_up(std::max<uint64_t>(h->m, 1), 4);
+    // rows of 16-byte pieces (the scan's load unit); tiny rows keep whole dwords
+    h->ds = h->m >= 16 ? round_up(h->m, 16) : round_up(std::max<uint64_t>(h->m, 1), 4);
     const uint64_t padded = round_up(h->count, kRowPad) + kRowPad;
     return h->rows.alloc(padded * h->ds, true);
 }
@@ -462,8 +501,58 @@ qamd_status set_centroids(qamd_pq *h, const float *centroids_host, hipStream_t s
 }
 
 bool fast_capable(const qamd_pq *h, uint64_t n) {
-    const size_t lds = (size_t)h->m * kCentroids * sizeof(float);
-    return lds <= kLdsBudget && n >= 4096 && h->m % 16 == 0 && h->m / 16 <= 8 && n == h->count;
+    return n >= 4096 && h->m >= 16 && n == h->count;
+}
+
+// Slices of at most 9 pieces (144 chunks, 144 KiB of LUT) per launch, balanced.
+constexpr uint32_t kMaxSlicePieces = 9;
+
+template <bool FILTER>
+qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, const TopkFilter *filt,
+                        hipStream_t s) {
+    const uint32_t m = (uint32_t)h->m, pieces = (uint32_t)(h->ds / 16);
+    const uint32_t n_slices = (pieces + kMaxSlicePieces - 1) / kMaxSlicePieces;
+    const uint32_t per = (pieces + n_slices - 1) / n_slices;
+    const uint64_t n = h->count;
+    const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
+    float *partial = nullptr;
+    if (n_slices > 1) {
+        const uint64_t padded = round_up(n, kRowPad) + kRowPad;
+        QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&partial), padded * 16, s));
+    }
+    for (uint32_t sl = 0; sl < n_slices; sl++) {
+        const uint32_t piece0 = sl * per, nvs = std::min(per, pieces - piece0);
+        const int first = sl == 0, last = sl + 1 == n_slices;
+        const bool simple = n_slices == 1 && m % 16 == 0;
+        const size_t lds = (size_t)std::min<uint32_t>(nvs * 16, m - piece0 * 16) * kCentroids * sizeof(float);
+#define QAMD_PQ_FAST(NVV)                                                                                   \
+    case NVV: {                                                                                             \
+        static std::once_flag f;                                                                            \
+        std::call_once(f, [] {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, true>),  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, false>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
+        });                                                                                                 \
+        if (simple)                                                                                         \
+            hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, FILTER, true>), dim3(grid), dim3(kScanBlock), lds, s, \
+                               h->rows.as<uint4>(), pieces, piece0, lut_dev, m / 4, m, first, last, partial, \
+                               (uint32_t)n, out_dev, filt ? *filt : TopkFilter{});                          \
+        else                                                                                                \
+            hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, FILTER, false>), dim3(grid), dim3(kScanBlock), lds, s, \
+                               h->rows.as<uint4>(), pieces, piece0, lut_dev, m / 4, m, first, last, partial, \
+                               (uint32_t)n, out_dev, filt ? *filt : TopkFilter{});                          \
+        break;                                                                                              \
+    }
+        switch (nvs) {
+            QAMD_PQ_FAST(1) QAMD_PQ_FAST(2) QAMD_PQ_FAST(3) QAMD_PQ_FAST(4) QAMD_PQ_FAST(5)
+            QAMD_PQ_FAST(6) QAMD_PQ_FAST(7) QAMD_PQ_FAST(8) QAMD_PQ_FAST(9)
+        }
+#undef QAMD_PQ_FAST
+    }
+    if (partial) (void)hipFreeAsync(partial, s);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
 }
 
 qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *ids_dev, uint64_t n,
@@ -478,30 +567,7 @@ qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *
     hipLaunchKernelGGL((pq_scan_kernel<LDSF, V16>), dim3(GRID), dim3(kScanBlock), SH, s, h->rows.as<uint32_t>(), \
                        lut_dev, ids_dev, n, (uint32_t)h->count, m, row_words, out_dev)
     if (!ids_dev && fast_capable(h, n)) {
-        const int grid = (int)std::min<uint64_t>(cu, (n + 1023) / 1024);
-        const uint4 *rows4 = h->rows.as<uint4>();
-#define QAMD_PQ_FAST(NVV)                                                                                   \
-    case NVV: {                                                                                             \
-        static std::once_flag f;                                                                            \
-        std::call_once(f, [] {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, false>),  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, true>),   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
-        });                                                                                                 \
-        if (filt)                                                                                           \
-            hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, true>), dim3(grid), dim3(kScanBlock), lds, s, rows4, \
-                               lut_dev, (uint32_t)n, out_dev, *filt);                                       \
-        else                                                                                                \
-            hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, false>), dim3(grid), dim3(kScanBlock), lds, s, rows4, \
-                               lut_dev, (uint32_t)n, out_dev, TopkFilter{});                                \
-        break;                                                                                              \
-    }
-        switch (m / 16) {
-            QAMD_PQ_FAST(1) QAMD_PQ_FAST(2) QAMD_PQ_FAST(3) QAMD_PQ_FAST(4)
-            QAMD_PQ_FAST(5) QAMD_PQ_FAST(6) QAMD_PQ_FAST(7) QAMD_PQ_FAST(8)
-        }
-#undef QAMD_PQ_FAST
+        return filt ? launch_fast<true>(h, lut_dev, out_dev, filt, s) : launch_fast<false>(h, lut_dev, out_dev, filt, s);
     } else if (in_lds) {
         static std::once_flag once;  // opt in to > 64 KiB dynamic LDS once per kernel
         std::call_once(once, [] {

@@ -134,3 +134,25 @@ def test_pq_save_load_empty_and_stop(qo, tmp_path):
     with pytest.raises(qa.EncodingError) as e:
         qa.EncodedVectorsPQ.encode(data, vp, chunk, centroids=cen, stop_condition=lambda: True)
     assert e.value.stopped
+
+
+@pytest.mark.parametrize("dim,chunk", [(1024, 2), (65, 1), (200, 1), (100, 3), (768, 4), (130, 2), (4096, 8)])
+def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
+    """n >= 4096 takes the LDS fast kernel for every m >= 16: m % 16 != 0 (padded last piece,
+    m % 4 tail) and LUTs larger than LDS scanned in slices (m = 512 is the reference bench's own
+    configuration, demos/benches/pq.rs:12-46)."""
+    n = 6000
+    rng = np.random.default_rng(dim * 7 + chunk)
+    m = qo.pq_chunks(dim, chunk)
+    cen = rng.random((256, dim), dtype=np.float32)
+    rows = rng.integers(0, 256, size=(n, m), dtype=np.uint8)
+    query = rng.random(dim, dtype=np.float32)
+    for dist, invert in ((D.Dot, False), (D.L2, True)):
+        enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, dist, invert), chunk, cen)
+        assert np.array_equal(enc.storage_bytes(), rows)
+        lut = qo.pq_encode_query(query, chunk, cen, int(dist), invert)
+        want = qo.pq_score_all(rows, lut, order=qo.ORDER_SSE)
+        q = enc.encode_query(query)
+        assert_bits_equal(enc.score_all(q), want, f"m={m}")
+        ids = np.array([0, n - 1, 17], dtype=np.uint32)
+        assert_bits_equal(enc.score_ids(q, ids), want[ids], "ids kernel")
