@@ -218,7 +218,7 @@ struct qamd_bin {
 
 struct qamd_bin_query {
     int device = 0;
-    uint64_t nb = 0, ds = 0;
+    uint64_t nb = 0, ds = 0, qdim_cap = 0;
     DevBuf buf;  // ds bytes (+ padding)
 };
 
@@ -432,22 +432,23 @@ qamd_status qamd_bin_encode_query(const qamd_bin *h, const float *query, uint64_
         q = fresh.get();
         q->device = h->device;
     }
-    if (q->ds != ds || !q->buf.ptr) {
-        QAMD_TRY(q->buf.alloc(round_up(ds, 16) + 16, true));
+    if (q->ds != ds || q->qdim_cap < qdim || !q->buf.ptr) {
+        QAMD_TRY(q->buf.alloc(round_up(ds, 16) + 16 + qdim * 4 + 16, true));  // bits | f32 staging
+        q->qdim_cap = qdim;
         q->nb = nb;
         q->ds = ds;
     }
-    if (query_mem == QAMD_MEM_DEVICE) {
-        if (qdim) {
-            hipLaunchKernelGGL(bin_encode_kernel, dim3(1), dim3(kBlock), 0, s, query, (uint64_t)1, (uint32_t)qdim,
-                               (uint32_t)(ds / 4), q->buf.as<uint32_t>(), (uint64_t)0);
-            QAMD_HIP(hipGetLastError());
+    // Always packed on the device (one implementation); a host query is uploaded first.
+    if (qdim) {
+        const float *q_dev = query;
+        if (query_mem == QAMD_MEM_HOST) {
+            float *stage = reinterpret_cast<float *>(q->buf.as<uint8_t>() + round_up(ds, 16) + 16);
+            QAMD_TRY(copy_in(stage, query, QAMD_MEM_HOST, qdim * 4, s));
+            q_dev = stage;
         }
-    } else {
-        std::vector<uint8_t> bits(ds, 0);  // :193-208
-        for (uint64_t i = 0; i < qdim; i++)
-            if (query[i] > 0.0f) bits[i / 8] |= (uint8_t)(1u << (i % 8));
-        QAMD_TRY(copy_in(q->buf.ptr, bits.data(), QAMD_MEM_HOST, ds, s));
+        hipLaunchKernelGGL(bin_encode_kernel, dim3(1), dim3(kBlock), 0, s, q_dev, (uint64_t)1, (uint32_t)qdim,
+                           (uint32_t)(ds / 4), q->buf.as<uint32_t>(), (uint64_t)0);
+        QAMD_HIP(hipGetLastError());
     }
     if (fresh) *query_io = fresh.release();
     return QAMD_OK;

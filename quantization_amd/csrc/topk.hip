@@ -174,6 +174,34 @@ qamd_status topk_f32(const float *scores_dev, uint64_t n, uint32_t k, bool large
     return QAMD_OK;
 }
 
+// k-th smallest (or largest) VALUE of an f32 array, k 1-based: the four score-bit passes of
+// the radix select (ties do not matter for a value).  Used by the u8 encoder's quantile
+// interval (quantile.rs:52-61, two select_nth_unstable calls in the reference).
+qamd_status select_kth_f32(const float *vals_dev, uint64_t n, uint64_t k, bool largest, float *out_host,
+                           hipStream_t stream) {
+    if (n == 0 || k == 0 || k > n || n > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "select_kth: bad k or n");
+    SelState *st = nullptr;
+    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&st), sizeof(SelState), stream));
+    hipLaunchKernelGGL(init_kernel, dim3(1), dim3(256), 0, stream, st, (uint32_t)k);
+    uint64_t want = (n + kBlock * 8 - 1) / (kBlock * 8);
+    uint64_t cap = (uint64_t)device_info().cu_count * 8;
+    int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    for (int shift = 56; shift >= 32; shift -= 8) {
+        hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(kBlock), 0, stream, vals_dev, n, shift, largest, st);
+        hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(256), 0, stream, st, shift);
+    }
+    unsigned long long prefix = 0;
+    qamd_status r = hipGetLastError() == hipSuccess ? QAMD_OK : fail(QAMD_ERR_DEVICE, "select_kth launch failed");
+    if (r == QAMD_OK) r = copy_out(&prefix, QAMD_MEM_HOST, &st->prefix, 8, stream);
+    (void)hipFreeAsync(st, stream);
+    if (r != QAMD_OK) return r;
+    uint32_t u = (uint32_t)(prefix >> 32);  // invert ordered_bits()
+    if (largest) u = ~u;
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    memcpy(out_host, &u, 4);
+    return QAMD_OK;
+}
+
 // ------------------------------------------------------------------------ fused scan + top-k
 namespace {
 

@@ -15,6 +15,10 @@ qamd_status topk_f32(const float *scores_dev, uint64_t n, uint32_t k, bool large
                      uint32_t *out_ids_dev, float *out_scores_dev, void *workspace_dev,
                      hipStream_t stream);
 
+// k-th smallest / largest value (k 1-based) of a device f32 array; synchronises `stream`.
+qamd_status select_kth_f32(const float *vals_dev, uint64_t n, uint64_t k, bool largest, float *out_host,
+                           hipStream_t stream);
+
 // Shared tail of the three *_topk entry points: scores already computed into scores_dev.
 qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int largest,
                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);

@@ -557,16 +557,7 @@ int grid_for(uint64_t work_items, uint64_t per_block, int blocks_per_cu) {
     return (int)(want > cap ? cap : want);
 }
 
-// ------------------------------------------------------------------------------ host mirror
-// encoded_vectors_u8.rs:234-237 on the host (used by encode_query for host queries).
-inline uint8_t host_f32_to_u8(float v, float alpha, float offset) {
-    float x = (v - offset) / alpha;
-    if (x < 0.0f) x = 0.0f;
-    if (x > 127.0f) x = 127.0f;
-    if (x != x) return 0;
-    return (uint8_t)x;
-}
-
+// ------------------------------------------------------------------------------ host side
 float host_multiplier(float alpha, int distance, int invert) {  // :119-128
     float m = distance == QAMD_DOT ? alpha * alpha : distance == QAMD_L1 ? alpha : -2.0f * alpha * alpha;
     return invert ? -m : m;
@@ -695,27 +686,58 @@ qamd_status score_ids_dev(const qamd_u8 *h, const uint4 *qc, const float *qo, fl
     return QAMD_OK;
 }
 
-// find_quantile_interval (quantile.rs:21-71) on the host over a bounded sample.
-bool quantile_interval(std::vector<float> &sample, uint64_t slice_size, float quantile, float &mn,
-                       float &mx) {
-    const uint64_t len = sample.size();
-    if (len < 4) return false;
-    uint64_t cut = std::min<uint64_t>((len - 1) / 2, (uint64_t)((float)slice_size * (1.0f - quantile) / 2.0f));
-    cut = std::max<uint64_t>(cut, 1);
-    auto cmp = [](float a, float b) { return a < b; };
-    std::nth_element(sample.begin(), sample.begin() + (len - cut), sample.end(), cmp);
-    // left part [0, len-cut); second selection at `cut` keeps (cut, len-cut)
-    std::nth_element(sample.begin(), sample.begin() + cut, sample.begin() + (len - cut), cmp);
-    const uint64_t lo = cut + 1, hi = len - cut;
-    if (hi <= lo || hi - lo < 2) return false;
-    mn = 3.40282347e+38f;
-    mx = -3.40282347e+38f;
-    for (uint64_t i = lo; i < hi; i++) {
-        float v = sample[i];
-        if (v < mn) mn = v;
-        if (v > mx) mx = v;
+// Gather `n_out` evenly strided rows of a device-resident [count][dim] array (quantile sample).
+__global__ __launch_bounds__(kBlock) void gather_strided_rows_kernel(const float *__restrict__ data, uint64_t count,
+                                                                    uint32_t dim, uint64_t n_out,
+                                                                    float *__restrict__ out) {
+    const uint64_t total = n_out * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t k = i / dim, j = i - k * dim;
+        const uint64_t r = (uint64_t)((unsigned __int128)k * count / n_out);
+        out[i] = data[r * dim + j];
     }
-    return true;
+}
+
+// find_quantile_interval (quantile.rs:21-71).  The reference keeps, after two
+// select_nth_unstable calls, the values of sorted rank (cut, len - cut) exclusive and returns
+// their min and max: sorted[cut + 1] and sorted[len - cut - 1], i.e. the (cut+2)-th smallest
+// and the (cut+1)-th largest value — two exact radix selects on the GPU.
+// count <= 100 000: the sample is every vector (exactly the reference).  Larger stores: an
+// evenly strided subset (the reference draws a random one; statistic, not bits).
+qamd_status quantile_interval_device(const float *data, qamd_mem data_mem, uint64_t count, uint64_t dim,
+                                     float quantile, hipStream_t s, bool &found, float &mn, float &mx) {
+    found = false;
+    const uint64_t slice = std::min<uint64_t>(count, kQuantileSample);
+    const uint64_t len = slice * dim;
+    if (len < 4) return QAMD_OK;  // :48-50
+    uint64_t cut = std::min<uint64_t>((len - 1) / 2, (uint64_t)((float)slice * (1.0f - quantile) / 2.0f));  // :52-55
+    cut = std::max<uint64_t>(cut, 1);
+    const uint64_t lo = cut + 1, hi = len - cut;
+    if (hi <= lo || hi - lo < 2) return QAMD_OK;  // :63-65
+    DevBuf sample;
+    const float *vals = data;
+    if (data_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(sample.alloc(len * 4));
+        if (slice == count) {
+            QAMD_TRY(copy_in(sample.ptr, data, QAMD_MEM_HOST, len * 4, s));
+        } else {
+            std::vector<float> rows(len);  // row gather only: no arithmetic on the host
+            for (uint64_t k = 0; k < slice; k++)
+                memcpy(&rows[k * dim], data + (uint64_t)((unsigned __int128)k * count / slice) * dim, dim * 4);
+            QAMD_TRY(copy_in(sample.ptr, rows.data(), QAMD_MEM_HOST, len * 4, s));
+        }
+        vals = sample.as<float>();
+    } else if (slice != count) {
+        QAMD_TRY(sample.alloc(len * 4));
+        hipLaunchKernelGGL(gather_strided_rows_kernel, dim3(grid_for(len, kBlock * 4, 8)), dim3(kBlock), 0, s, data,
+                           count, (uint32_t)dim, slice, sample.as<float>());
+        QAMD_HIP(hipGetLastError());
+        vals = sample.as<float>();
+    }
+    QAMD_TRY(select_kth_f32(vals, len, cut + 2, false, &mn, s));
+    QAMD_TRY(select_kth_f32(vals, len, cut + 1, true, &mx, s));
+    found = true;
+    return QAMD_OK;
 }
 
 }  // namespace
@@ -789,22 +811,11 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
         alpha = (mx - mn) / 127.0f;  // :228-232
         offset = mn;
         // PASS 1b (:58-71): quantile interval on <= 100 000 sampled vectors.
-        if (quantile && !(count < 127 || *quantile >= 1.0f)) {
-            const uint64_t slice = std::min<uint64_t>(count, kQuantileSample);
-            std::vector<float> sample(slice * dim);
-            // count <= 100 000: every vector (exactly the reference).  Larger stores: an
-            // evenly strided subset (the reference draws a random one; statistic, not bits).
-            std::vector<float> rowbuf;
-            for (uint64_t k = 0; k < slice; k++) {
-                const uint64_t r = slice == count ? k : (uint64_t)((unsigned __int128)k * count / slice);
-                if (data_mem == QAMD_MEM_HOST)
-                    memcpy(&sample[k * dim], data + r * dim, dim * 4);
-                else
-                    QAMD_HIP(hipMemcpyAsync(&sample[k * dim], data + r * dim, dim * 4, hipMemcpyDeviceToHost, s));
-            }
-            if (data_mem == QAMD_MEM_DEVICE) QAMD_HIP(hipStreamSynchronize(s));
-            float qmn, qmx;
-            if (quantile_interval(sample, slice, *quantile, qmn, qmx)) {
+        if (quantile && !(count < 127 || *quantile >= 1.0f)) {  // :27-29
+            bool found = false;
+            float qmn = 0.0f, qmx = 0.0f;
+            QAMD_TRY(quantile_interval_device(data, data_mem, count, dim, *quantile, s, found, qmn, qmx));
+            if (found) {
                 alpha = (qmx - qmn) / 127.0f;
                 offset = qmn;
             }
@@ -987,41 +998,22 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
         q->device = h->device;
     }
     if (q->actual_dim != ad || !q->buf.ptr) {
-        QAMD_TRY(q->buf.alloc(16 + ad + 16, true));
+        QAMD_TRY(q->buf.alloc(16 + round_up(ad, 16) + ad * 4 + 16, true));  // offset | codes | f32 staging
         q->actual_dim = ad;
     }
     const qamd_vector_parameters &vp = h->meta.vector_parameters;
-    if (query_mem == QAMD_MEM_DEVICE) {
-        hipLaunchKernelGGL(encode_query_kernel, dim3(1), dim3(64), 0, s, query, (uint32_t)qdim, (uint32_t)ad,
-                           h->meta.alpha, h->meta.offset, vp.distance_type, vp.invert, q->buf.as<uint8_t>());
-        QAMD_HIP(hipGetLastError());
-    } else {
-        // Host mirror of :290-329, then one small upload.
-        std::vector<uint8_t> img(16 + ad, 0);
-        uint8_t *codes = img.data() + 16;
-        const float alpha = h->meta.alpha, offset = h->meta.offset;
-        for (uint64_t j = 0; j < qdim; j++) codes[j] = host_f32_to_u8(query[j], alpha, offset);
-        if (qdim % 16 != 0) {
-            const float placeholder = vp.distance_type == QAMD_DOT ? 0.0f : offset;
-            const uint8_t pc = host_f32_to_u8(placeholder, alpha, offset);
-            for (uint64_t j = qdim; j < ad; j++) codes[j] = pc;
-        }
-        float off;
-        if (vp.distance_type == QAMD_DOT) {
-            float sum = 0.0f;
-            for (uint64_t j = 0; j < ad; j++) sum += (float)codes[j];
-            off = sum * alpha * offset;
-        } else if (vp.distance_type == QAMD_L1) {
-            off = 0.0f;
-        } else {
-            float sum = 0.0f;
-            for (uint64_t j = 0; j < ad; j++) sum += (float)codes[j] * (float)codes[j];
-            off = sum * alpha * alpha;
-        }
-        if (vp.invert) off = -off;
-        memcpy(img.data(), &off, 4);
-        QAMD_TRY(copy_in(q->buf.ptr, img.data(), QAMD_MEM_HOST, img.size(), s));
+    // The query is always encoded on the device (one implementation, no CPU arithmetic in the
+    // product): a host query is uploaded first (qdim * 4 bytes; the buffer keeps room for it
+    // behind the codes).
+    const float *q_dev = query;
+    if (query_mem == QAMD_MEM_HOST && qdim) {
+        float *stage = reinterpret_cast<float *>(q->buf.as<uint8_t>() + 16 + round_up(ad, 16));
+        QAMD_TRY(copy_in(stage, query, QAMD_MEM_HOST, qdim * 4, s));
+        q_dev = stage;
     }
+    hipLaunchKernelGGL(encode_query_kernel, dim3(1), dim3(64), 0, s, q_dev, (uint32_t)qdim, (uint32_t)ad,
+                       h->meta.alpha, h->meta.offset, vp.distance_type, vp.invert, q->buf.as<uint8_t>());
+    QAMD_HIP(hipGetLastError());
     if (fresh) *query_io = fresh.release();
     return QAMD_OK;
 }

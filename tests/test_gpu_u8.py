@@ -284,3 +284,22 @@ def test_device_resident_inputs_and_outputs(qo):
     codes, qoff = qo.u8_encode_query(meta, data[5])
     torch.cuda.synchronize()
     assert_bits_equal(enc.score_all(q_dev), qo.u8_score_all(meta, rows, codes, qoff), "reused query")
+
+
+def test_quantile_sampled_case_is_conditionally_exact(qo):
+    """count > 100 000: the reference's interval comes from a RANDOM 100k-vector sample
+    (quantile.rs:31-34) — parity unpinned for (alpha, offset); everything after them is exact."""
+    torch = pytest.importorskip("torch")
+    n, dim = 150_000, 8
+    rng = np.random.default_rng(77)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    for src in (data, torch.from_numpy(data).cuda()):
+        enc = qa.EncodedVectorsU8.encode(src, qa.VectorParameters(dim, n, D.Dot, False), quantile=0.98)
+        md = enc.metadata
+        lo, hi = float(md["offset"]), float(md["offset"]) + 127.0 * float(md["alpha"])
+        # the reference cuts slice_size*(1-q)/2 VALUES (not vectors' worth) per side
+        # (quantile.rs:52-55): a (1-q)/(2*dim) = 0.125 % tail here, near -/+3.02 sigma
+        frac = (1.0 - 0.98) / (2 * dim)
+        assert abs(lo - np.quantile(data, frac)) < 0.05 and abs(hi - np.quantile(data, 1 - frac)) < 0.05, (lo, hi)
+        rows, meta = qo.u8_encode_with(data, qo.DOT, False, float(md["alpha"]), float(md["offset"]))
+        assert np.array_equal(enc.storage_bytes(), rows)
