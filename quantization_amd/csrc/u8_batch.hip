@@ -44,8 +44,6 @@ using namespace qamd;
 namespace {
 
 constexpr int TQ = 256, TR = 256;  // largest workgroup tile (queries x rows): padding granularity
-constexpr int BK = 128;            // K slab in bytes
-constexpr int PITCH = BK + 16;     // LDS row pitch
 constexpr uint32_t kBatchCap = kTopkCandCap;  // candidate slots per query
 constexpr uint32_t kCounterStride = 16;       // u32: one counter per 64-byte line
 
@@ -53,19 +51,20 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct BatchFilter {
-    const uint32_t *pivots;          // [Qpad] order-preserving keys
+    const float *pivot_scores;       // [Qpad] pivot as a score; +-inf for padding queries (nothing passes)
     uint32_t *counters;              // [Qpad * kCounterStride]
     unsigned long long *candidates;  // [Qpad][kBatchCap]
     int largest;
 };
 
-// S[q][row] for the tile; MODE 0: write scores out[q * out_pitch + row]; MODE 1: filter.
+// S[q][row] for the tile; MODE 0: write scores out[q * out_pitch + row]; MODE 1 / 2: filter for the
+// largest / smallest scores.
 // Tile TQ queries x TR rows per workgroup, WQ x WR waves, each wave (MI*32) x (MJ*32) outputs.
 //   <128,128,2,2>: 4 waves, 72 KiB LDS  — small batches (padding to 128 queries)
 //   <256,256,2,4>: 8 waves, 144 KiB LDS — the guide's 256^2 shape: a 128^2 tile needs 32 KiB of
 //   operands per 512 MFMA cycles, more than one CU's share of L2 bandwidth (~55 B/clk), and
 //   measured 13 % of the int8 MFMA peak; at 256^2 the slab is 64 KiB per 2048 MFMA cycles.
-template <int MODE, int TQ_, int TR_, int WQ, int WR>
+template <int MODE, int TQ_, int TR_, int WQ, int WR, int BK_>
 __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__restrict__ codes,
                                                               const float *__restrict__ v_offsets,
                                                               const uint8_t *__restrict__ qcodes,
@@ -75,7 +74,9 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
                                                               uint64_t out_pitch, BatchFilter filt) {
     constexpr int T = 64 * WQ * WR;
     constexpr int MI = TQ_ / WQ / 32, MJ = TR_ / WR / 32;
-    constexpr int ROWS_PER_PASS = T / 8;  // 8 lanes x 16 B cover one 128-byte slab row
+    constexpr int BK = BK_, PITCH = BK_ + 16;  // slab bytes per row; +16 B pad: conflict-free ds_read_b128
+    constexpr int CH = BK / 16;                // 16-byte chunks per slab row
+    constexpr int ROWS_PER_PASS = T / CH;      // CH lanes x 16 B cover one slab row
     constexpr int LA = TQ_ / ROWS_PER_PASS, LB = TR_ / ROWS_PER_PASS;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     // layout: buffer b: A at b*(TQ+TR)*PITCH, B right after A
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
     const int wq = wave / WR, wr = wave % WR;
     const int r = lane & 31, h = lane >> 5;
 
-    const int s_chunk = t & 7, s_row = t >> 3;
+    const int s_chunk = t % CH, s_row = t / CH;
     const uint8_t *gA = qcodes + (uint64_t)(q0 + s_row) * ad + s_chunk * 16;
     const uint8_t *gB = codes + (row0 + s_row) * ad + s_chunk * 16;
     const uint32_t n_slabs = (ad + BK - 1) / BK;
@@ -161,18 +162,25 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
     // + 4*(lane >> 5): query index on the registers, store row on the lanes (coalesced writes).
     // The tile's per-query constants (offset, pivot key) go through LDS once: read per element
     // from global memory they were 256 loads per lane and dominated the whole kernel.
-    float *q_off_s = reinterpret_cast<float *>(lds_raw);            // [TQ_]   (operand buffers are dead now)
-    uint32_t *pivot_s = reinterpret_cast<uint32_t *>(lds_raw) + TQ_;  // [TQ_]
+    // The filter is a FLOAT compare against the pivot score (a superset of "key <= pivot key":
+    // only the rare passing element pays for the key, the atomic and the store) — the first
+    // version built the ordered key of all 128 results per lane and spent more instructions in
+    // this epilogue (5000) than in the MFMA loop.
+    float *q_off_s = reinterpret_cast<float *>(lds_raw);  // [TQ_]   (operand buffers are dead now)
+    float *pivot_s = reinterpret_cast<float *>(lds_raw) + TQ_;  // [TQ_]
     for (int i = t; i < TQ_; i += T) {
         q_off_s[i] = q_offsets[q0 + i];
-        if (MODE == 1) pivot_s[i] = filt.pivots[q0 + i];
+        if (MODE != 0) pivot_s[i] = filt.pivot_scores[q0 + i];
     }
     __syncthreads();
+    constexpr bool LARGEST = MODE == 1;
+    const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         const uint64_t row = row0 + wr * (MJ * 32) + j * 32 + r;
-        const float v_off = v_offsets[row];  // padded like codes[]
         const bool row_ok = row < n_rows;
+        // a padding row gets an offset that can never pass the filter
+        const float v_off = (MODE == 0 || row_ok) ? v_offsets[row] : never;  // v_offsets is padded like codes[]
 #pragma unroll
         for (int i = 0; i < MI; i++) {
 #pragma unroll
@@ -180,22 +188,32 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
                 const uint32_t ql = wq * (MI * 32) + i * 32 + 8 * g + 4 * h;
                 const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
                 const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
-                uint4 pv4 = make_uint4(0, 0, 0, 0);
-                if (MODE == 1) pv4 = *reinterpret_cast<const uint4 *>(pivot_s + ql);
-                const uint32_t pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                float sc[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const uint32_t q = q0 + ql + e;
-                    const float sc = (multiplier * (float)acc[i][j][4 * g + e] + qo[e]) + v_off;
-                    if (MODE == 0) {
-                        if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc;
-                    } else if (row_ok && q < n_queries) {
-                        const uint32_t key = topk_ordered_bits(sc, filt.largest != 0);
-                        if (key <= pv[e]) {
-                            const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
-                            if (pos < kBatchCap)
-                                filt.candidates[(uint64_t)q * kBatchCap + pos] =
-                                    ((unsigned long long)key << 32) | (uint32_t)row;
+                for (int e = 0; e < 4; e++) sc[e] = (multiplier * (float)acc[i][j][4 * g + e] + qo[e]) + v_off;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t q = q0 + ql + e;
+                        if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc[e];
+                    }
+                } else {
+                    const float4 pv4 = *reinterpret_cast<const float4 *>(pivot_s + ql);
+                    const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                    bool pass[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pass[e] = LARGEST ? !(sc[e] < pv[e]) : !(sc[e] > pv[e]);
+                    if (pass[0] | pass[1] | pass[2] | pass[3]) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (pass[e]) {
+                                const uint32_t q = q0 + ql + e;
+                                const uint32_t key = topk_ordered_bits(sc[e], LARGEST);
+                                const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
+                                if (pos < kBatchCap)
+                                    filt.candidates[(uint64_t)q * kBatchCap + pos] =
+                                        ((unsigned long long)key << 32) | (uint32_t)row;
+                            }
                         }
                     }
                 }
@@ -223,10 +241,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *__restric
 // scores (see pivot_kernel in topk.hip), and counter reset.
 __global__ __launch_bounds__(1024) void batch_pivot_kernel(const float *__restrict__ sample, uint32_t S,
                                                           uint64_t pitch, uint32_t r, int largest,
-                                                          uint32_t *__restrict__ pivots,
+                                                          uint32_t n_queries, float *__restrict__ pivot_scores,
                                                           uint32_t *__restrict__ counters) {
     __shared__ uint32_t best[1024];
     const int t = threadIdx.x;
+    if (blockIdx.x >= n_queries) {  // padding query of the last tile: nothing may pass
+        if (t == 0) pivot_scores[blockIdx.x] = largest ? __builtin_huge_valf() : -__builtin_huge_valf();
+        return;
+    }
     const float *mine_row = sample + (uint64_t)blockIdx.x * pitch;
     uint32_t mine = 0xFFFFFFFFu;
     for (uint32_t i = t; i < S; i += 1024) {
@@ -251,7 +273,7 @@ __global__ __launch_bounds__(1024) void batch_pivot_kernel(const float *__restri
     }
     if (t == 0) {
         r = r < 1 ? 1 : (r > 1024 ? 1024 : r);
-        pivots[blockIdx.x] = best[r - 1];
+        pivot_scores[blockIdx.x] = topk_score_of_key(best[r - 1], largest != 0);
         counters[(uint64_t)blockIdx.x * kCounterStride] = 0;
     }
 }
@@ -328,7 +350,7 @@ qamd_status check_batch(const qamd_u8 *h, const qamd_u8_query_batch *b) {
 }
 
 // Launch the GEMM over rows [0, n_rows) of (codes, offsets) for every query of the batch.
-template <int MODE, int TQ_, int TR_, int WQ, int WR>
+template <int MODE, int TQ_, int TR_, int WQ, int WR, int BK_>
 qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                             const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                             const BatchFilter &filt, hipStream_t s) {
@@ -336,13 +358,13 @@ qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, cons
     const uint64_t r_tiles = round_up((n_rows + TR_ - 1) / TR_, 8);  // whole groups of 8 row tiles (one per XCD)
     const uint64_t blocks = r_tiles * q_tiles;
     if (blocks > 0x7FFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "batch too large for one launch");
-    constexpr size_t lds_bytes = (size_t)2 * (TQ_ + TR_) * PITCH;
+    constexpr size_t lds_bytes = (size_t)2 * (TQ_ + TR_) * (BK_ + 16);
     static std::once_flag once;  // one flag per instantiation
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
-    hipLaunchKernelGGL((u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR>), dim3((unsigned)blocks), dim3(64 * WQ * WR), lds_bytes,
+    hipLaunchKernelGGL((u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>), dim3((unsigned)blocks), dim3(64 * WQ * WR), lds_bytes,
                        s, codes, v_offsets, b->codes.as<uint8_t>(), b->offsets.as<float>(), h->meta.multiplier,
                        (uint32_t)n_rows, (uint32_t)b->n_queries, (uint32_t)h->meta.actual_dim, q_tiles, out, out_pitch,
                        filt);
@@ -358,13 +380,13 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
     // q_pad is a multiple of 256 and the row padding of every store covers a 256-row tile.
     if (b->n_queries > 128) {
         static const char *cfg = getenv("QAMD_GEMM_CFG");  // developer A/B switch
-        if (cfg && cfg[0] == '1')
-            return launch_gemm_cfg<MODE, 256, 256, 4, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
-        if (cfg && cfg[0] == '2')
-            return launch_gemm_cfg<MODE, 256, 128, 4, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
-        return launch_gemm_cfg<MODE, 256, 256, 2, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        if (cfg && cfg[0] == '3')  // two 4-wave workgroups per CU (61 KiB LDS each), 128 q x 256 rows
+            return launch_gemm_cfg<MODE, 128, 256, 2, 2, 64>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        if (cfg && cfg[0] == '4')  // same, 256 q x 128 rows
+            return launch_gemm_cfg<MODE, 256, 128, 2, 2, 64>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        return launch_gemm_cfg<MODE, 256, 256, 2, 4, 128>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     }
-    return launch_gemm_cfg<MODE, 128, 128, 2, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    return launch_gemm_cfg<MODE, 128, 128, 2, 2, 128>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
 }
 
 }  // namespace
@@ -470,10 +492,13 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
                            h->offsets.as<float>(), h->row_chunks, n, S, s_codes.as<uint4>(), s_offs.as<float>());
         QAMD_TRY(launch_gemm<0>(h, b, s_codes.as<uint8_t>(), s_offs.as<float>(), S, s_scores.as<float>(), S,
                                 BatchFilter{}, s));
-        hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)Q), dim3(1024), 0, s, s_scores.as<float>(), S,
-                           (uint64_t)S, r, largest, pivots.as<uint32_t>(), counters.as<uint32_t>());
-        BatchFilter f{pivots.as<uint32_t>(), counters.as<uint32_t>(), cand.as<unsigned long long>(), largest};
-        QAMD_TRY(launch_gemm<1>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
+        hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores.as<float>(), S,
+                           (uint64_t)S, r, largest, (uint32_t)Q, pivots.as<float>(), counters.as<uint32_t>());
+        BatchFilter f{pivots.as<float>(), counters.as<uint32_t>(), cand.as<unsigned long long>(), largest};
+        if (largest)
+            QAMD_TRY(launch_gemm<1>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
+        else
+            QAMD_TRY(launch_gemm<2>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
         hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand.as<unsigned long long>(),
                            counters.as<uint32_t>(), n, k, largest, ids_dev, sc_dev, status_dev.as<uint32_t>());
         QAMD_HIP(hipGetLastError());
