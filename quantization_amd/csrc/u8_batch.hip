@@ -200,13 +200,17 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
                 } else {
                     const float4 pv4 = *reinterpret_cast<const float4 *>(pivot_s + ql);
                     const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
-                    bool pass[4];
+                    // margin d >= 0  <=>  the score is at least as good as the pivot (the sign of an
+                    // f32 difference is exact).  One max over the four margins and one compare decide
+                    // for the whole group; NaN scores never pass (v_max drops them).
+                    float d[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) pass[e] = LARGEST ? !(sc[e] < pv[e]) : !(sc[e] > pv[e]);
-                    if (pass[0] | pass[1] | pass[2] | pass[3]) {
+                    for (int e = 0; e < 4; e++) d[e] = LARGEST ? sc[e] - pv[e] : pv[e] - sc[e];
+                    const float dmax = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
+                    if (dmax >= 0.0f) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            if (pass[e]) {
+                            if (d[e] >= 0.0f) {
                                 const uint32_t q = q0 + ql + e;
                                 const uint32_t key = topk_ordered_bits(sc[e], LARGEST);
                                 const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
