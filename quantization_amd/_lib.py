@@ -143,9 +143,6 @@ def lib() -> C.CDLL:
     return L
 
 
-EXPORTED = None  # filled lazily by exported_symbols()
-
-
 def declared_symbols() -> list[str]:
     """Every QAMD_API function declared in include/quantization_amd.h."""
     import re

@@ -358,7 +358,6 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
         qamd_status stt = scan.score_ids(ids, S, sample, stream);
         if (stt == QAMD_OK) {
             hipLaunchKernelGGL(pivot_kernel, dim3(1), dim3(1024), 0, stream, sample, S, r, largest, st);
-            if (getenv("QAMD_DEBUG_TOPK_PIVOT0")) (void)hipMemsetAsync(&st->pivot_key, 0, 4, stream);
             TopkFilter f{&st->pivot_key, st->counters, cand, largest};
             stt = scan.scan_filter(f, stream);
         }
