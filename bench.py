@@ -167,8 +167,9 @@ def main():
     queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
     sample_rows = min(args.cpu_sample_rows, n)
     data_sample = data[:sample_rows].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    del data
-    torch.cuda.empty_cache()
+    del data  # stays in torch's caching allocator on purpose: returning the 30.7 GB block to the
+    # driver (empty_cache) measured 3.5 % SLOWER scans afterwards on the same box (1.171 vs 1.131 ms,
+    # tools/exp_ctx.py), whichever buffers the scores were then written to.
 
     bytes_per_row = enc.scan_bytes_per_row()
     qobj = enc.encode_query(queries[0])
@@ -222,7 +223,11 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
+    kern_all = [a.elapsed_time(b) for a, b in ev_pairs]
+    kern_ms = float(np.mean(kern_all)) if kern_all else float("nan")
+    if os.environ.get("QAMD_BENCH_TRACE") and rank == 0:  # developer: per-step kernel times
+        with open(os.environ["QAMD_BENCH_TRACE"], "w") as f:
+            f.write("\n".join(f"{x:.4f}" for x in kern_all))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
