@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """Compile libquantization_amd.so (hipcc, gfx950) when it is missing or stale — the .so is
+    git-ignored, so a fresh checkout has none.  hipcc cross-compiles without a GPU."""
+    from quantization_amd import _lib
+
+    return _lib.build()
+
+
 @pytest.fixture(scope="session")
 def qo():
     """The parity oracle (oracle/qoracle.c through ctypes)."""
