@@ -68,13 +68,16 @@ def test_topk_batch_small_store_uses_exact_single_query_path(largest):
 
 
 @pytest.mark.parametrize("k,largest", [(30, True), (200, False)])
-def test_topk_batch_fused_large_store(k, largest):
-    """n >= 2^20: per-query pivots from the sampled sub-store, FILTER epilogue, per-query sort."""
+@pytest.mark.parametrize("dist,invert,lo", [(D.L2, False, 0.0), (D.Dot, False, 0.0), (D.Dot, True, 5.0), (D.L2, True, -3.0)])
+def test_topk_batch_fused_large_store(k, largest, dist, invert, lo):
+    """n >= 2^20: per-query pivots from the sampled sub-store, integer pre-filter folded into the
+    accumulators (both directions: multiplier > 0 and < 0), exact f32 test, per-query sort.
+    `lo` shifts the data so that offset != 0 and vector_offset varies a lot inside a tile."""
     rng = np.random.default_rng(7)
     n, dim, nq = 1_300_000, 64, 150
-    data = rng.random((n, dim), dtype=np.float32)
-    queries = rng.random((nq, dim), dtype=np.float32)
-    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L2, False))
+    data = rng.random((n, dim), dtype=np.float32) + np.float32(lo)
+    queries = rng.random((nq, dim), dtype=np.float32) + np.float32(lo)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
     ids, sc = enc.topk_batch(enc.encode_query_batch(queries), k, largest=largest)
     for qi in (0, 1, 77, nq - 1):
         scores = enc.score_all(enc.encode_query(queries[qi]))
