@@ -37,6 +37,10 @@ def parse_args():
     ap.add_argument("--rows-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--distance", choices=["dot", "l2"], default="dot")
+    ap.add_argument("--quantizer", choices=["u8", "binary", "pq"], default="u8",
+                    help="u8 = the headline metric (BASELINE configs[1]); binary / pq run configs[3] / [2] "
+                         "through the same harness (e.g. --quantizer binary --dim 1024 --rows-per-gpu 6250000)")
+    ap.add_argument("--pq-chunk", type=int, default=8)
     ap.add_argument("--exchange", choices=["scores", "topk", "none"], default="scores",
                     help="per-query result exchange across ranks (N>1): gather of per-shard scores "
                          "to rank 0 (overlapped with the next scan), per-shard top-k + all-gather, or none")
@@ -156,22 +160,47 @@ def main():
     # ---- synthetic store, generated and encoded on the GPU (never timed) -------------------
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
-    data = torch.rand((n, dim), generator=gen, device=dev, dtype=torch.float32)
-    # one global (alpha, offset): data is U[0,1) on every rank, so use the analytic interval
-    # [0, 1) -> alpha = 1/127, offset = 0 rather than a cross-rank min/max reduction.
-    alpha_offset = (float(np.float32(1.0) / np.float32(127.0)), 0.0) if world > 1 else None
-    vp = qa.VectorParameters(dim, n, dtype, False)
-    enc = qa.EncodedVectorsU8.encode(data, vp, alpha_offset=alpha_offset)
     qgen = torch.Generator(device=dev)
     qgen.manual_seed(43)
-    queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
     sample_rows = min(args.cpu_sample_rows, n)
-    data_sample = data[:sample_rows].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    del data  # stays in torch's caching allocator on purpose: returning the 30.7 GB block to the
-    # driver (empty_cache) measured 3.5 % SLOWER scans afterwards on the same box (1.171 vs 1.131 ms,
-    # tools/exp_ctx.py), whichever buffers the scores were then written to.
+    data_sample = None
+    if args.quantizer == "u8":
+        data = torch.rand((n, dim), generator=gen, device=dev, dtype=torch.float32)
+        # one global (alpha, offset): data is U[0,1) on every rank, so use the analytic interval
+        # [0, 1) -> alpha = 1/127, offset = 0 rather than a cross-rank min/max reduction.
+        alpha_offset = (float(np.float32(1.0) / np.float32(127.0)), 0.0) if world > 1 else None
+        vp = qa.VectorParameters(dim, n, dtype, False)
+        enc = qa.EncodedVectorsU8.encode(data, vp, alpha_offset=alpha_offset)
+        queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            data_sample = data[:sample_rows].cpu().numpy()
+        del data  # stays in torch's caching allocator on purpose: returning the 30.7 GB block to the
+        # driver (empty_cache) measured 3.5 % SLOWER scans afterwards on the same box (1.171 vs 1.131 ms,
+        # tools/exp_ctx.py), whichever buffers the scores were then written to.
+        bytes_per_row = enc.scan_bytes_per_row()
+        kernel_name = "u8_scan_kernel"
+    elif args.quantizer == "binary":
+        # +-1 style data (demos/benches/binary.rs:10-21): random bit rows are exactly that, packed
+        vp = qa.VectorParameters(dim, n, dtype, False)
+        nb = qa.EncodedVectorsBin.get_quantized_vector_size_from_params(vp)
+        rows = torch.randint(0, 256, (n, nb), generator=gen, device=dev, dtype=torch.uint8)
+        enc = qa.EncodedVectorsBin.from_storage(rows, vp)
+        del rows
+        queries = torch.randn((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
+        bytes_per_row = nb
+        kernel_name = "bin_scan_kernel"
+    else:
+        vp = qa.VectorParameters(dim, n, dtype, False)
+        m = qa.EncodedVectorsPQ.get_quantized_vector_size(vp, args.pq_chunk)
+        rows = torch.randint(0, 256, (n, m), generator=gen, device=dev, dtype=torch.uint8)
+        cen = np.random.default_rng(7).random((256, dim), dtype=np.float32)
+        enc = qa.EncodedVectorsPQ.from_storage(rows, vp, args.pq_chunk, cen)
+        del rows
+        queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
+        bytes_per_row = m
+        kernel_name = "pq_scan_fast_kernel"
+    args.no_cpu_baseline = args.no_cpu_baseline or args.quantizer != "u8"
 
-    bytes_per_row = enc.scan_bytes_per_row()
     qobj = enc.encode_query(queries[0])
     gather = topk = None
     if args.exchange == "scores":
@@ -235,14 +264,15 @@ def main():
         achieved = bytes_per_row * n / (kern_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                    "kernel": "u8_scan_kernel", "kernel_ms": kern_ms,
+                    "kernel": kernel_name, "kernel_ms": kern_ms,
                     "algorithmic_bytes_per_row": bytes_per_row, "rows_per_launch": n}
         # measured traffic from the committed PMC profile of this exact workload, if present
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_u8_scan.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("rows_per_launch") == n and j.get("algorithmic_read_bytes_per_launch") == n * bytes_per_row:
+                if (args.quantizer == "u8" and j.get("rows_per_launch") == n
+                        and j.get("algorithmic_read_bytes_per_launch") == n * bytes_per_row):
                     roofline["traffic"] = j.get("traffic_bytes_per_launch")
                     roofline["traffic_source"] = "profiles/r01_pmc_u8_scan.json (rocprofv3 --pmc, FETCH_SIZE x2 per guide)"
             except Exception:
@@ -268,15 +298,20 @@ def main():
             roofline["stream_read_error"] = str(e)
 
         result = {
-            "metric": "scored vectors/sec, 10Mx768 u8 dot" if (n == 10_000_000 and dim == 768 and args.distance == "dot")
-            else f"scored vectors/sec, {n}x{dim} u8 {args.distance}",
+            "metric": "scored vectors/sec, 10Mx768 u8 dot"
+            if (n == 10_000_000 and dim == 768 and args.distance == "dot" and args.quantizer == "u8")
+            else f"scored vectors/sec, {n}x{dim} {args.quantizer} {args.distance}",
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{n} x {dim} f32 U[0,1) per GPU -> scalar u8 ({args.distance}); "
+            "dtype": {"u8": "u8", "binary": "u1 (xor+popcount, i32)", "pq": "f32 (LUT adds)"}[args.quantizer],
+            "data": "synthetic",
+            "config": {"workload": (f"{n} x {dim} f32 U[0,1) per GPU -> scalar u8 ({args.distance}); "
+                                    if args.quantizer == "u8" else
+                                    f"{n} x {dim} {args.quantizer} rows per GPU ({bytes_per_row} B/row, {args.distance}); ") +
                                    f"per step: encode_query + score_all over the shard"
                                    + (f" + {args.exchange} exchange" if world > 1 and args.exchange != "none" else ""),
-                       "rows_per_gpu": n, "dim": dim, "distance": args.distance, "exchange": args.exchange,
+                       "quantizer": args.quantizer, "rows_per_gpu": n, "dim": dim, "distance": args.distance,
+                       "exchange": args.exchange,
                        "total_rows": total_rows, "queries": args.queries},
             "roofline": roofline,
         }

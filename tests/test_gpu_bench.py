@@ -1,0 +1,51 @@
+"""bench.py end to end on the GPU box: the single-GPU line (all three quantizers) and the
+multi-rank code path rehearsed with two ranks on ONE GPU over gloo (RCCL needs one GPU per rank;
+the driver runs the real N=2,4,8 on an 8-GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out: str) -> dict:
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("extra", [[], ["--quantizer", "binary", "--dim", "1024"], ["--quantizer", "pq"],
+                                   ["--distance", "l2"]])
+def test_bench_single_gpu_line(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--rows-per-gpu", "300000",
+           "--cpu-sample-rows", "50000"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    j = _last_json(res.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["value"] > 0
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1.2
+    if not extra:
+        cb = j["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("reference", "port")
+        assert cb["gpu_matches_cpu_bits"] is True
+
+
+@pytest.mark.parametrize("exchange", ["scores", "topk"])
+def test_bench_two_ranks_one_gpu_gloo_rehearsal(exchange):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--rows-per-gpu", "200000", "--backend", "gloo", "--all-ranks-on-device", "0",
+           "--exchange", exchange]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["total_rows"] == 400000 and j["scaling"] == "weak"
+    assert "cpu_baseline" not in j
