@@ -12,7 +12,10 @@ D = qa.DistanceType
 
 
 @pytest.mark.parametrize("n,dim,nq", [(1000, 768, 5), (300, 65, 130), (5000, 1536, 64), (129, 16, 3),
-                                      (700, 100, 257), (64, 2048, 2), (2500, 128, 1)])
+                                      (700, 100, 257), (64, 2048, 2), (2500, 128, 1),
+                                      # small batches (padded to one 128-query MFMA tile)
+                                      (3000, 256, 9), (500, 1024, 16), (800, 1536, 7), (400, 512, 12),
+                                      (2000, 768, 16), (777, 768, 1), (900, 2048, 5)])
 @pytest.mark.parametrize("dist,invert", [(D.Dot, False), (D.L2, False), (D.Dot, True)])
 def test_score_batch_equals_single_query_and_oracle(qo, n, dim, nq, dist, invert):
     rng = np.random.default_rng(n + dim + nq)
@@ -84,3 +87,19 @@ def test_topk_batch_fused_large_store(k, largest, dist, invert, lo):
         order = np.lexsort((np.arange(n), -scores if largest else scores))[:k]
         assert np.array_equal(ids[qi], order.astype(np.uint32)), qi
         assert np.array_equal(sc[qi].view(np.uint32), scores[order].view(np.uint32))
+
+
+@pytest.mark.parametrize("nq,dim", [(6, 64), (6, 768), (13, 256)])
+def test_topk_batch_small_batch_scan(nq, dim):
+    """A handful of queries (padded to one 128-query MFMA tile) must equal the single-query result."""
+    rng = np.random.default_rng(nq * 100 + dim)
+    n = 1_100_000
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    for dist, largest in ((D.Dot, True), (D.L2, False)):
+        enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, False))
+        ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 40, largest=largest)
+        for qi in (0, nq - 1):
+            wi, ws = enc.topk(enc.encode_query(queries[qi]), 40, largest=largest)
+            assert np.array_equal(ids[qi], wi), (dist, qi)
+            assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32))

@@ -133,7 +133,7 @@ if "batch" in which:
         enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
         del data
         torch.cuda.empty_cache()
-        for nq in [int(x) for x in os.environ.get("BATCH_NQ", "64,256,1024").split(",")]:
+        for nq in [int(x) for x in os.environ.get("BATCH_NQ", "4,8,16,32,64,256,1024").split(",")]:
             queries = torch.rand((nq, dim), device=dev)
             batch = enc.encode_query_batch(queries)
             ids = torch.empty(nq * 30, dtype=torch.int32, device=dev)
