@@ -303,3 +303,36 @@ def test_quantile_sampled_case_is_conditionally_exact(qo):
         assert abs(lo - np.quantile(data, frac)) < 0.05 and abs(hi - np.quantile(data, 1 - frac)) < 0.05, (lo, hi)
         rows, meta = qo.u8_encode_with(data, qo.DOT, False, float(md["alpha"]), float(md["offset"]))
         assert np.array_equal(enc.storage_bytes(), rows)
+
+
+def test_cosine_is_normalised_dot(qo):
+    """The reference has no Cosine distance: callers L2-normalise vectors and queries
+    (cosine_preprocess, demos/src/ann_benchmark_data.rs:223-230) and use Dot
+    (demos/src/ann_benchmark.rs:114-116).  Bit-exact against the oracle; against the true cosine
+    within the reference's u8 tolerance scaled to unit vectors."""
+    rng = np.random.default_rng(13)
+    n, dim = 2000, 768
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    query = rng.standard_normal(dim).astype(np.float32)
+
+    def cosine_preprocess(v):  # ann_benchmark_data.rs:223-230, f32 arithmetic
+        length = np.float32(0.0)
+        for x in v:
+            length = np.float32(length + x * x)
+        if length < np.finfo(np.float32).eps:
+            return v
+        return (v / np.sqrt(length, dtype=np.float32)).astype(np.float32)
+
+    nd = np.stack([cosine_preprocess(v) for v in data[:64]] + [(v / np.linalg.norm(v)).astype(np.float32) for v in data[64:]])
+    nq = cosine_preprocess(query)
+    enc = qa.EncodedVectorsU8.encode(nd, qa.VectorParameters(dim, n, D.Dot, False))
+    rows, meta = qo.u8_encode(nd, qo.DOT, False)
+    assert np.array_equal(enc.storage_bytes(), rows)
+    codes, qoff = qo.u8_encode_query(meta, nq)
+    got = enc.score_all(enc.encode_query(nq))
+    assert_bits_equal(got, qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_AVX2), "cosine (normalised dot)")
+    true_cos = (data @ query) / (np.linalg.norm(data, axis=1) * np.linalg.norm(query))
+    # stated f32 tolerance: per-dimension quantisation step alpha ~ (max-min)/127 of unit vectors
+    assert np.max(np.abs(got - true_cos)) < 0.01
+    top = np.argsort(-got)[:10]
+    assert len(set(top) & set(np.argsort(-true_cos)[:20])) >= 8  # recall sanity, as ann_benchmark's same_10
