@@ -187,6 +187,41 @@ __global__ __launch_bounds__(kBlock) void bin_encode_kernel(const float *__restr
     }
 }
 
+// encode_vector, streaming form for stores whose rows are whole 128-bit words with no row
+// padding (dim % 128 == 0): the batch is one flat stream of floats -> bits.  One wave per
+// 16 KiB tile; wave-load j reads 64 consecutive float4 (nt), each lane turns its four signs
+// into a nibble at bit 4*(lane%8), a 3-step DPP add over the 8-lane group (disjoint fields, so
+// add == or) hands every lane of the group the finished dword, and lane 8g+t keeps the one of
+// wave-load t (and t+8): after 16 loads a lane owns two dwords and the wave writes 2 x 256 B.
+__global__ __launch_bounds__(kBlock) void bin_encode_flat_kernel(const float4 *__restrict__ d4, uint64_t n4,
+                                                                uint32_t *__restrict__ words /* n4/8 dwords */) {
+    const int lane = threadIdx.x & 63, t = lane & 7, g = lane >> 3;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t base = wave * 1024;
+    if (base >= n4) return;
+    float4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint64_t i = base + j * 64 + lane;
+        v[j] = i < n4 ? __builtin_bit_cast(float4, ld_nt(reinterpret_cast<const uint4 *>(d4) + i))
+                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    uint32_t keep[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t nib = (v[j].x > 0.0f ? 1u : 0u) | (v[j].y > 0.0f ? 2u : 0u) | (v[j].z > 0.0f ? 4u : 0u) |
+                       (v[j].w > 0.0f ? 8u : 0u);
+        const uint32_t dw = group_sum<8>(nib << (4 * t));
+        if ((j & 7) == t) keep[j >> 3] = dw;
+    }
+    const uint64_t n_words = n4 / 8;
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const uint64_t w = wave * 128 + hf * 64 + t * 8 + g;  // wave-load (hf*8 + t), group g
+        if (w < n_words) words[w] = keep[hf];
+    }
+}
+
 int grid_for(uint64_t work_items, uint64_t per_block, int blocks_per_cu) {
     uint64_t want = (work_items + per_block - 1) / per_block;
     uint64_t cap = (uint64_t)device_info().cu_count * blocks_per_cu;
@@ -328,7 +363,9 @@ qamd_status qamd_bin_encode(const float *data, qamd_mem data_mem, const qamd_vec
     QAMD_TRY(alloc_store(h.get()));
     const uint64_t dim = vp->dim, count = vp->count;
     if (count && dim) {
-        const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, (256ull << 20) / (dim * 4)));
+        // host rows are staged 256 MiB at a time; device rows are read in place, 8 GiB per launch
+        const uint64_t batch_bytes = data_mem == QAMD_MEM_HOST ? (256ull << 20) : (8ull << 30);
+        const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, batch_bytes / (dim * 4)));
         DevBuf stage;
         if (data_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(batch_rows * dim * 4));
         for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
@@ -339,9 +376,17 @@ qamd_status qamd_bin_encode(const float *data, qamd_mem data_mem, const qamd_vec
                 QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
                 src = stage.as<float>();
             }
-            int grid = grid_for(nr, kBlock / 64, 8);
-            hipLaunchKernelGGL(bin_encode_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
-                               (uint32_t)(h->ds / 4), h->rows.as<uint32_t>(), r0);
+            if (dim % 128 == 0 && h->ds * 8 == dim && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                const uint64_t n4 = nr * dim / 4;
+                const unsigned grid = (unsigned)((n4 + 1024 * (kBlock / 64) - 1) / (1024 * (kBlock / 64)));
+                hipLaunchKernelGGL(bin_encode_flat_kernel, dim3(grid), dim3(kBlock), 0, s,
+                                   reinterpret_cast<const float4 *>(src), n4,
+                                   h->rows.as<uint32_t>() + r0 * (h->ds / 4));
+            } else {
+                int grid = grid_for(nr, kBlock / 64, 8);
+                hipLaunchKernelGGL(bin_encode_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
+                                   (uint32_t)(h->ds / 4), h->rows.as<uint32_t>(), r0);
+            }
             QAMD_HIP(hipGetLastError());
             if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
         }

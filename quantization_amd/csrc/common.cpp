@@ -45,7 +45,21 @@ qamd_status DevBuf::alloc(size_t n, bool zero) {
     if (n == 0) n = 16;  // keep a valid pointer for empty stores
     QAMD_HIP(hipMalloc(&ptr, n));
     bytes = n;
-    if (zero) QAMD_HIP(hipMemset(ptr, 0, n));
+    if (zero) {
+        // hipMemset on device memory may return before the fill has run; callers go on to use the
+        // buffer on their own (possibly non-blocking) stream, so the fill is completed here.
+        QAMD_HIP(hipMemsetAsync(ptr, 0, n, nullptr));
+        QAMD_HIP(hipStreamSynchronize(nullptr));
+    }
+    return QAMD_OK;
+}
+
+qamd_status DevBuf::alloc_zero_tail(size_t n, size_t keep) {
+    QAMD_TRY(alloc(n, false));
+    if (keep < bytes) {
+        QAMD_HIP(hipMemsetAsync(static_cast<char *>(ptr) + keep, 0, bytes - keep, nullptr));
+        QAMD_HIP(hipStreamSynchronize(nullptr));
+    }
     return QAMD_OK;
 }
 

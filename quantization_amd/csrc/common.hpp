@@ -56,6 +56,8 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     qamd_status alloc(size_t n, bool zero = false);
+    // bytes [keep, n) are zeroed; [0, keep) is left for the caller to fill completely
+    qamd_status alloc_zero_tail(size_t n, size_t keep);
     void release();
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };

@@ -342,6 +342,148 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(const float *__restrict_
     }
 }
 
+// Pass 1, streaming form: one 16 KiB tile per wave (non-persistent, nt loads — the shape that
+// reads HBM fastest, see u8_scan_kernel), per-workgroup min/max folded into 64 sharded slots
+// with integer atomics on order-preserving keys, so that a whole store needs ONE read-back.
+// NaNs are skipped exactly like the reference's `value < min` / `value > max`.
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kMinmaxSlots = 64, kMinmaxSlotStride = 64;  // one slot pair per 256-byte line
+__global__ __launch_bounds__(kScanBlock) void minmax_stream_kernel(const float4 *__restrict__ d4, uint64_t n4,
+                                                                  uint32_t *__restrict__ slots) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * kScanBlock + threadIdx.x) >> 6;
+    const uint64_t base = wave * 1024 + (threadIdx.x & 63);
+    if (wave * 1024 >= n4) return;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+    const float qnan = __uint_as_float(0x7FC00000u);
+    float4 v[16];
+    if (wave * 1024 + 1024 <= n4) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = ld_nt(d4 + base + j * 64);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint64_t i = base + j * 64;
+            v[j] = i < n4 ? ld_nt(d4 + i) : make_float4(qnan, qnan, qnan, qnan);  // NaN: skipped by both folds
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        mn = v[j].x < mn ? v[j].x : mn; mx = v[j].x > mx ? v[j].x : mx;
+        mn = v[j].y < mn ? v[j].y : mn; mx = v[j].y > mx ? v[j].y : mx;
+        mn = v[j].z < mn ? v[j].z : mn; mx = v[j].z > mx ? v[j].z : mx;
+        mn = v[j].w < mn ? v[j].w : mn; mx = v[j].w > mx ? v[j].w : mx;
+    }
+    // wave fold: DPP inside each 16-lane row, then the four row results through readlane
+    float o;
+    o = dpp_f32<0xB1>(mn); mn = o < mn ? o : mn;   o = dpp_f32<0xB1>(mx); mx = o > mx ? o : mx;
+    o = dpp_f32<0x4E>(mn); mn = o < mn ? o : mn;   o = dpp_f32<0x4E>(mx); mx = o > mx ? o : mx;
+    o = dpp_f32<0x141>(mn); mn = o < mn ? o : mn;  o = dpp_f32<0x141>(mx); mx = o > mx ? o : mx;
+    o = dpp_f32<0x140>(mn); mn = o < mn ? o : mn;  o = dpp_f32<0x140>(mx); mx = o > mx ? o : mx;
+    float wmn = mn, wmx = mx;
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), r));
+        const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), r));
+        wmn = a < wmn ? a : wmn;
+        wmx = c > wmx ? c : wmx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // The slot only ever moves outwards, so a stale read can cost a redundant atomic but never
+        // lose an update; after the first few tiles almost no wave needs the atomic at all.
+        uint32_t *slot = slots + (wave & (kMinmaxSlots - 1)) * kMinmaxSlotStride;
+        const uint32_t kmn = f32_order_key(wmn), kmx = f32_order_key(wmx);
+        if (kmn < __builtin_nontemporal_load(slot)) atomicMin(slot, kmn);
+        if (kmx > __builtin_nontemporal_load(slot + 1)) atomicMax(slot + 1, kmx);
+    }
+}
+
+// Pass 2, streaming form (dim % 4 == 0, 16-byte aligned input): 16 lanes per row, 4 rows per
+// wave, one wave per tile.  Lane `sub` converts float4 #(sub + 16*it) of its row into one dword
+// of codes: every wave-load is 4 x 256 contiguous bytes and up to four are in flight per lane;
+// the row sums finish with DPP row adds.  Same arithmetic as quantize_kernel.
+template <int ITERS /* float4 per lane, 0 = any dim (loop of 4-deep batches) */>
+__global__ __launch_bounds__(kScanBlock) void quantize16_kernel(
+    const float *__restrict__ data, uint64_t n_rows, uint32_t dim, uint32_t actual_dim, float alpha,
+    float offset, int distance, int invert, uint32_t *__restrict__ codes32, float *__restrict__ offsets,
+    uint64_t row0) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, rslot = lane >> 4;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kScanBlock + threadIdx.x) >> 6;
+    if (wave * 4 >= n_rows) return;
+    const uint64_t r = wave * 4 + rslot;
+    const bool row_ok = r < n_rows;
+    const uint64_t rc = row_ok ? r : n_rows - 1;  // clamped: loads stay in bounds, stores are masked
+    const float *src = data + rc * dim;
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    const uint32_t dwords = actual_dim / 4, f4 = dim / 4;
+    uint32_t *dst = codes32 + (row0 + rc) * dwords;
+    const float placeholder = (distance == QAMD_DOT) ? 0.0f : offset;
+    const uint32_t pad_code = f32_to_u8(placeholder, alpha, offset);
+    const uint32_t pad_dword = pad_code * 0x01010101u;
+    uint32_t s1 = 0, s2 = 0;
+    constexpr int DEPTH = ITERS ? ITERS : 4;
+    for (uint32_t d0 = sub; d0 < dwords; d0 += 16 * DEPTH) {
+        float4 f[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const uint32_t d = d0 + 16 * j;
+            f[j] = d < f4 ? ld_nt(src4 + d) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const uint32_t d = d0 + 16 * j;
+            if (d >= dwords) break;
+            uint32_t packed;
+            if (d < f4) {
+                const uint32_t c0 = f32_to_u8(f[j].x, alpha, offset), c1 = f32_to_u8(f[j].y, alpha, offset),
+                               c2 = f32_to_u8(f[j].z, alpha, offset), c3 = f32_to_u8(f[j].w, alpha, offset);
+                packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+                s1 += c0 + c1 + c2 + c3;
+                s2 += c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+            } else {
+                packed = pad_dword;
+                s1 += 4 * pad_code;
+                s2 += 4 * pad_code * pad_code;
+            }
+            if (row_ok) __builtin_nontemporal_store(packed, dst + d);  // 16 lanes x 4 B = one 64-byte segment
+        }
+        if (ITERS) break;
+    }
+    s1 = group_sum<16>(s1);
+    s2 = group_sum<16>(s2);
+    if (sub == 0 && row_ok) {
+        float vo;
+        const float D = (float)actual_dim;
+        if (distance == QAMD_DOT) {
+            float sum = (float)s1;
+            if (s1 >= (1u << 24)) {
+                sum = 0.0f;
+                for (uint32_t j = 0; j < actual_dim; j++)
+                    sum += (float)(j < dim ? f32_to_u8(src[j], alpha, offset) : pad_code);
+            }
+            vo = D * offset * offset + sum * alpha * offset;
+        } else if (distance == QAMD_L1) {
+            vo = 0.0f;
+        } else {
+            float sum = (float)s2;
+            if (s2 >= (1u << 24)) {
+                sum = 0.0f;
+                for (uint32_t j = 0; j < actual_dim; j++) {
+                    const float c = (float)(j < dim ? f32_to_u8(src[j], alpha, offset) : pad_code);
+                    sum += c * c;
+                }
+            }
+            vo = D * offset * offset + sum * alpha * alpha;
+        }
+        offsets[row0 + r] = invert ? -vo : vo;
+    }
+}
+
 // Pass 2: one wave per row (encoded_vectors_u8.rs:73-118).  Lane l quantizes elements
 // 4l..4l+3 of each 256-element slab into one dword of codes; the row's code sums are exact
 // integers.  vector_offset is the reference's sequential f32 sum: identical to the integer
@@ -575,8 +717,9 @@ namespace {
 qamd_status alloc_store(qamd_u8 *h) {
     h->padded_rows = round_up(h->count, kRowPad) + kRowPad;
     h->row_chunks = (uint32_t)(h->meta.actual_dim / 16);
-    QAMD_TRY(h->codes.alloc(h->padded_rows * h->meta.actual_dim, true));
-    QAMD_TRY(h->offsets.alloc(h->padded_rows * sizeof(float), true));
+    // every builder (encode, from_rows, load) writes all `count` rows; only the padding is zeroed
+    QAMD_TRY(h->codes.alloc_zero_tail(h->padded_rows * h->meta.actual_dim, h->count * h->meta.actual_dim));
+    QAMD_TRY(h->offsets.alloc_zero_tail(h->padded_rows * sizeof(float), h->count * sizeof(float)));
     return QAMD_OK;
 }
 
@@ -773,19 +916,36 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
         return QAMD_OK;
     }
     const uint64_t dim = vp->dim, count = vp->count;
-    const uint64_t total = count * dim;
 
-    // Source rows: device-resident as they are, host rows staged in bounded batches.
-    const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, (256ull << 20) / (dim * 4 + 1)));
+    // Source rows: device-resident rows are processed in place (large batches: the stop
+    // callback is polled between them), host rows are staged in bounded 256 MiB batches.
+    const uint64_t batch_bytes = data_mem == QAMD_MEM_HOST ? (256ull << 20) : (8ull << 30);
+    const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, batch_bytes / (dim * 4 + 1)));
     DevBuf stage;
     if (data_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(batch_rows * dim * sizeof(float)));
+    auto batch_src = [&](uint64_t r0, uint64_t nr, const float *&src) -> qamd_status {
+        src = data + r0 * dim;
+        if (data_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
+            src = stage.as<float>();
+        }
+        return QAMD_OK;
+    };
 
     float alpha, offset;
     if (alpha_offset) {
         alpha = alpha_offset[0];
         offset = alpha_offset[1];
     } else {
-        // PASS 1 (:57): global min/max.
+        // PASS 1 (:57): global min/max, accumulated on the device across batches.
+        DevBuf slots;
+        QAMD_TRY(slots.alloc(kMinmaxSlots * kMinmaxSlotStride * sizeof(uint32_t)));
+        std::vector<uint32_t> init(kMinmaxSlots * kMinmaxSlotStride, 0u);
+        for (int b = 0; b < kMinmaxSlots; b++) {
+            init[b * kMinmaxSlotStride] = 0xFFFFFFFFu;  // min slot: largest key
+            init[b * kMinmaxSlotStride + 1] = 0u;       // max slot: smallest key
+        }
+        QAMD_TRY(copy_in(slots.ptr, init.data(), QAMD_MEM_HOST, init.size() * 4, s));
         const int mm_grid = device_info().cu_count * 4;
         DevBuf partial;
         QAMD_TRY(partial.alloc((size_t)mm_grid * 2 * sizeof(float)));
@@ -794,18 +954,52 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
         for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
             if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
             const uint64_t nr = std::min(batch_rows, count - r0);
-            const float *src = data + r0 * dim;
-            if (data_mem == QAMD_MEM_HOST) {
-                QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
-                src = stage.as<float>();
+            const float *src = nullptr;
+            QAMD_TRY(batch_src(r0, nr, src));
+            const uint64_t nvals = nr * dim;
+            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && nvals >= 4) {
+                const uint64_t n4 = nvals / 4;
+                const unsigned grid = (unsigned)((n4 + 1024 * (kScanBlock / 64) - 1) / (1024 * (kScanBlock / 64)));
+                hipLaunchKernelGGL(minmax_stream_kernel, dim3(grid), dim3(kScanBlock), 0, s,
+                                   reinterpret_cast<const float4 *>(src), n4, slots.as<uint32_t>());
+                if (nvals % 4) {  // the 1..3 trailing values
+                    hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(kBlock), 0, s, src + n4 * 4, nvals % 4,
+                                       partial.as<float>());
+                    QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, 8, s));
+                    if (hp[0] < mn) mn = hp[0];
+                    if (hp[1] > mx) mx = hp[1];
+                }
+            } else {  // unaligned input: grid-stride scalar form
+                hipLaunchKernelGGL(minmax_kernel, dim3(mm_grid), dim3(kBlock), 0, s, src, nvals, partial.as<float>());
+                QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, hp.size() * 4, s));
+                for (int b = 0; b < mm_grid; b++) {
+                    if (hp[2 * b] < mn) mn = hp[2 * b];
+                    if (hp[2 * b + 1] > mx) mx = hp[2 * b + 1];
+                }
             }
-            hipLaunchKernelGGL(minmax_kernel, dim3(mm_grid), dim3(kBlock), 0, s, src, nr * dim,
-                               partial.as<float>());
             QAMD_HIP(hipGetLastError());
-            QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, hp.size() * 4, s));
-            for (int b = 0; b < mm_grid; b++) {
-                if (hp[2 * b] < mn) mn = hp[2 * b];
-                if (hp[2 * b + 1] > mx) mx = hp[2 * b + 1];
+            if (data_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));  // staging buffer is reused
+        }
+        std::vector<uint32_t> all_slots(kMinmaxSlots * kMinmaxSlotStride), keys(128);
+        QAMD_TRY(copy_out(all_slots.data(), QAMD_MEM_HOST, slots.ptr, all_slots.size() * 4, s));
+        for (int b = 0; b < kMinmaxSlots; b++) {
+            keys[2 * b] = all_slots[b * kMinmaxSlotStride];
+            keys[2 * b + 1] = all_slots[b * kMinmaxSlotStride + 1];
+        }
+        auto key_to_f32 = [](uint32_t k) {
+            uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+            float f;
+            memcpy(&f, &u, 4);
+            return f;
+        };
+        for (int b = 0; b < 64; b++) {
+            if (keys[2 * b] != 0xFFFFFFFFu) {
+                const float v = key_to_f32(keys[2 * b]);
+                if (v < mn) mn = v;
+            }
+            if (keys[2 * b + 1] != 0u) {
+                const float v = key_to_f32(keys[2 * b + 1]);
+                if (v > mx) mx = v;
             }
         }
         alpha = (mx - mn) / 127.0f;  // :228-232
@@ -821,21 +1015,35 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
             }
         }
     }
-    (void)total;
 
     // PASS 2 (:73-118): quantize rows, stop_condition polled between batches.
     for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
         if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
         const uint64_t nr = std::min(batch_rows, count - r0);
-        const float *src = data + r0 * dim;
-        if (data_mem == QAMD_MEM_HOST) {
-            QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
-            src = stage.as<float>();
+        const float *src = nullptr;
+        QAMD_TRY(batch_src(r0, nr, src));
+        if (dim % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const uint64_t waves = (nr + 3) / 4;
+            const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
+            const uint32_t per_lane = (uint32_t)((h->meta.actual_dim / 4 + 15) / 16);  // float4 per lane
+#define QAMD_Q16(IT)                                                                                          \
+    hipLaunchKernelGGL(quantize16_kernel<IT>, dim3(grid), dim3(kScanBlock), 0, s, src, nr, (uint32_t)dim,     \
+                       (uint32_t)h->meta.actual_dim, alpha, offset, vp->distance_type, vp->invert,            \
+                       h->codes.as<uint32_t>(), h->offsets.as<float>(), r0)
+            if (per_lane <= 2) QAMD_Q16(2);
+            else if (per_lane <= 4) QAMD_Q16(4);
+            else if (per_lane <= 6) QAMD_Q16(6);
+            else if (per_lane <= 8) QAMD_Q16(8);
+            else if (per_lane <= 12) QAMD_Q16(12);
+            else if (per_lane <= 16) QAMD_Q16(16);
+            else QAMD_Q16(0);
+#undef QAMD_Q16
+        } else {
+            int grid = grid_for(nr, kBlock / 64, 8);
+            hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
+                               (uint32_t)h->meta.actual_dim, alpha, offset, vp->distance_type, vp->invert,
+                               h->codes.as<uint32_t>(), h->offsets.as<float>(), r0);
         }
-        int grid = grid_for(nr, kBlock / 64, 8);
-        hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
-                           (uint32_t)h->meta.actual_dim, alpha, offset, vp->distance_type, vp->invert,
-                           h->codes.as<uint32_t>(), h->offsets.as<float>(), r0);
         QAMD_HIP(hipGetLastError());
         if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
     }
