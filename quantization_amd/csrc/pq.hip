@@ -283,16 +283,28 @@ __global__ __launch_bounds__(kBlock) void pq_encode_kernel(const float *__restri
     }
 }
 
-// Compile-time chunk size (dim % CS == 0): the sub-vector lives in registers, the inner loops
-// unroll fully and two centroids are evaluated per step (independent sum chains, compared in
-// index order with the same strict '<').  Identical arithmetic to pq_encode_kernel.
+// Compile-time chunk size (dim % CS == 0).  One thread per row; its sub-vector lives in
+// registers.  Centroid values are the same for every lane, so they come through the SCALAR data
+// path: the table is re-laid once per encode as [chunk][pair][j] = (c_2p[j], c_2p+1[j]) and the
+// pair loop reads it with wave-uniform addresses (s_load_dwordx16 into SGPRs, no LDS, no
+// barrier).  Two centroids are evaluated per step as the two halves of packed-f32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32, the SGPR pair as one operand).  Each half is the same IEEE
+// sub, mul, add chain as pq_encode_kernel (no contraction), compared in index order with the
+// same strict '<'.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(kBlock) void pq_pair_table_kernel(const float *__restrict__ centroids, uint32_t dim,
+                                                              uint32_t cs, uint32_t m, float *__restrict__ table) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // over m * 256 * cs
+    if (i >= m * kCentroids * cs) return;
+    const uint32_t half = i & 1, j = (i >> 1) % cs, pr = (i / (2 * cs)) % (kCentroids / 2), c = i / (kCentroids * cs);
+    table[i] = centroids[(size_t)(2 * pr + half) * dim + c * cs + j];
+}
 template <int CS>
 __global__ __launch_bounds__(kBlock) void pq_encode_cs_kernel(const float *__restrict__ data, uint64_t n_rows,
                                                              uint32_t dim, uint32_t m,
-                                                             const float *__restrict__ centroids,
+                                                             const f32x2 *__restrict__ pair_table,
                                                              uint8_t *__restrict__ rows, uint32_t row_stride,
                                                              uint64_t row0, uint32_t chunks_per_slice) {
-    __shared__ __attribute__((aligned(16))) float cen_s[kCentroids * CS];
     const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = r < n_rows;
     const float *src = data + (active ? r : 0) * dim;
@@ -300,36 +312,41 @@ __global__ __launch_bounds__(kBlock) void pq_encode_cs_kernel(const float *__res
     const uint32_t c_end = min(m, c_begin + chunks_per_slice);
     for (uint32_t c = c_begin; c < c_end; c++) {
         const uint32_t lo = c * CS;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kCentroids * CS; i += kBlock) {
-            const uint32_t kc = i / CS, j = i % CS;
-            cen_s[i] = centroids[(size_t)kc * dim + lo + j];
-        }
-        __syncthreads();
         float a[CS];
 #pragma unroll
         for (int j = 0; j < CS; j++) a[j] = src[lo + j];
+        // U pairs (32 floats; 64 for CS = 32) per step, software-pipelined one step ahead: SMEM
+        // returns out of order, so every wait is lgkmcnt(0) -- issuing the next step's s_load
+        // before this step's arithmetic is what hides its latency.
+        constexpr int U = CS >= 16 ? 1 : 16 / CS;
+        constexpr int STEPS = kCentroids / 2 / U;
+        struct Step { f32x2 v[U * CS]; };
+        const Step *steps = reinterpret_cast<const Step *>(pair_table + (size_t)c * (kCentroids / 2) * CS);
         float min_d = 3.40282347e+38f;
         uint32_t min_i = 0;
-#pragma unroll 4
-        for (uint32_t kc = 0; kc < (uint32_t)kCentroids; kc += 2) {
-            const float *c0 = cen_s + kc * CS, *c1 = c0 + CS;
-            float d0 = 0.0f, d1 = 0.0f;
+        Step cur = steps[0];
+        for (uint32_t st = 0; st < (uint32_t)STEPS; st++) {
+            const Step nxt = steps[st + 1 < (uint32_t)STEPS ? st + 1 : st];
 #pragma unroll
-            for (int j = 0; j < CS; j++) {
-                const float t0 = a[j] - c0[j];
-                const float t1 = a[j] - c1[j];
-                d0 += t0 * t0;
-                d1 += t1 * t1;
+            for (int u = 0; u < U; u++) {
+                f32x2 d = {0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < CS; j++) {
+                    const f32x2 aa = {a[j], a[j]};
+                    const f32x2 t = aa - cur.v[u * CS + j];
+                    d += t * t;
+                }
+                const uint32_t pr = st * U + u;
+                if (d.x < min_d) {
+                    min_d = d.x;
+                    min_i = 2 * pr;
+                }
+                if (d.y < min_d) {
+                    min_d = d.y;
+                    min_i = 2 * pr + 1;
+                }
             }
-            if (d0 < min_d) {
-                min_d = d0;
-                min_i = kc;
-            }
-            if (d1 < min_d) {
-                min_d = d1;
-                min_i = kc + 1;
-            }
+            cur = nxt;
         }
         if (active) rows[(row0 + r) * row_stride + c] = (uint8_t)min_i;
     }
@@ -600,7 +617,9 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
                         hipStream_t s) {
     const uint64_t dim = h->vp.dim, count = h->count;
     if (count == 0 || dim == 0) return QAMD_OK;
-    const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, (256ull << 20) / (dim * 4)));
+    // host rows are staged 256 MiB at a time; device rows are read in place, 8 GiB per launch
+    const uint64_t batch_bytes = data_mem == QAMD_MEM_HOST ? (256ull << 20) : (8ull << 30);
+    const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, batch_bytes / (dim * 4)));
     DevBuf stage;
     if (data_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(batch_rows * dim * 4));
     const size_t lds = (size_t)kCentroids * h->chunk_size * sizeof(float);
@@ -610,6 +629,17 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_encode_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     });
+    const bool cs_fast = dim % h->chunk_size == 0 && (h->chunk_size == 1 || h->chunk_size == 2 || h->chunk_size == 4 ||
+                                                      h->chunk_size == 8 || h->chunk_size == 16 || h->chunk_size == 32);
+    DevBuf pair_table;  // [chunk][centroid pair][j][2], read through the scalar cache
+    if (cs_fast) {
+        const uint32_t n = (uint32_t)(h->m * kCentroids * h->chunk_size);
+        QAMD_TRY(pair_table.alloc((size_t)n * 4));
+        hipLaunchKernelGGL(pq_pair_table_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                           h->centroids.as<float>(), (uint32_t)dim, (uint32_t)h->chunk_size, (uint32_t)h->m,
+                           pair_table.as<float>());
+        QAMD_HIP(hipGetLastError());
+    }
     for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
         if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :198-200
         const uint64_t nr = std::min(batch_rows, count - r0);
@@ -628,9 +658,9 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
 #define QAMD_PQ_ENC(CSV)                                                                                     \
     case CSV:                                                                                               \
         hipLaunchKernelGGL((pq_encode_cs_kernel<CSV>), dim3(gx, slices), dim3(kBlock), 0, s, src, nr, (uint32_t)dim, \
-                           (uint32_t)h->m, h->centroids.as<float>(), h->rows.as<uint8_t>(), (uint32_t)h->ds, r0, per); \
+                           (uint32_t)h->m, pair_table.as<f32x2>(), h->rows.as<uint8_t>(), (uint32_t)h->ds, r0, per); \
         break;
-        bool fast = dim % h->chunk_size == 0;
+        bool fast = cs_fast;
         if (fast) {
             switch (h->chunk_size) {
                 QAMD_PQ_ENC(1) QAMD_PQ_ENC(2) QAMD_PQ_ENC(4) QAMD_PQ_ENC(8) QAMD_PQ_ENC(16) QAMD_PQ_ENC(32)
