@@ -616,10 +616,10 @@ __global__ __launch_bounds__(64) void encode_query_kernel(const float *__restric
 __global__ __launch_bounds__(64) void encode_queries_kernel(const float *__restrict__ queries, uint32_t qdim,
                                                            uint32_t actual_dim, float alpha, float offset,
                                                            int distance, int invert, uint8_t *__restrict__ codes_out,
-                                                           float *__restrict__ offsets_out) {
+                                                           uint32_t code_pitch, float *__restrict__ offsets_out) {
     const int lane = threadIdx.x;
     const float *query = queries + (size_t)blockIdx.x * qdim;
-    uint8_t *codes = codes_out + (size_t)blockIdx.x * actual_dim;
+    uint8_t *codes = codes_out + (size_t)blockIdx.x * code_pitch;
     const float placeholder = (distance == QAMD_DOT) ? 0.0f : offset;
     const uint32_t pad_code = f32_to_u8(placeholder, alpha, offset);
     uint32_t s1 = 0, s2 = 0;
@@ -1348,12 +1348,12 @@ qamd_status qamd_u8_set_lane_mode(qamd_u8 *h, int mode) {
 namespace qamd {
 
 qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev, uint64_t n_queries, uint64_t qdim,
-                                     uint8_t *codes_dev, float *offsets_dev, hipStream_t stream) {
+                                     uint8_t *codes_dev, uint64_t code_pitch, float *offsets_dev, hipStream_t stream) {
     if (n_queries == 0) return QAMD_OK;
     const qamd_vector_parameters &vp = h->meta.vector_parameters;
     hipLaunchKernelGGL(encode_queries_kernel, dim3((unsigned)n_queries), dim3(64), 0, stream, queries_dev,
                        (uint32_t)qdim, (uint32_t)actual_dim_of(qdim), h->meta.alpha, h->meta.offset,
-                       vp.distance_type, vp.invert, codes_dev, offsets_dev);
+                       vp.distance_type, vp.invert, codes_dev, (uint32_t)code_pitch, offsets_dev);
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;
 }

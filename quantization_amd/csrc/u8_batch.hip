@@ -57,6 +57,11 @@ struct BatchFilter {
     int largest;
 };
 
+// Developer timeline (tools/gemm_timeline.py): when set, lane 0 of every wave of the first 4096
+// workgroups stores s_memtime at the phase boundaries, 16 slots per wave.
+__device__ unsigned long long *g_gemm_stamps = nullptr;
+constexpr uint32_t kStampBlocks = 4096;
+
 // S[q][row] for the tile; MODE 0: write scores out[q * out_pitch + row]; MODE 1 / 2: filter for the
 // largest / smallest scores.
 // Tile TQ queries x TR rows per workgroup, WQ x WR waves, each wave (MI*32) x (MJ*32) outputs.
@@ -67,7 +72,7 @@ struct BatchFilter {
 template <int MODE, int TQ_, int TR_, int WQ, int WR, int BK_>
 __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__restrict__ codes,
                                                               const float *__restrict__ v_offsets,
-                                                              const uint8_t *__restrict__ qcodes,
+                                                              const uint8_t *__restrict__ qcodes, uint32_t q_pitch,
                                                               const float *__restrict__ q_offsets, float multiplier,
                                                               uint32_t n_rows, uint32_t n_queries, uint32_t ad,
                                                               uint32_t q_tiles, float *__restrict__ out,
@@ -97,8 +102,15 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
     const int wq = wave / WR, wr = wave % WR;
     const int r = lane & 31, h = lane >> 5;
 
+    unsigned long long *stamps = g_gemm_stamps;
+    if (stamps) stamps = (blockIdx.x < kStampBlocks && lane == 0) ? stamps + ((uint64_t)blockIdx.x * (T / 64) + wave) * 16 : nullptr;
+    auto stamp = [&](int slot) {
+        if (stamps) stamps[slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
     const int s_chunk = t % CH, s_row = t / CH;
-    const uint8_t *gA = qcodes + (uint64_t)(q0 + s_row) * ad + s_chunk * 16;
+    const uint8_t *gA = qcodes + (uint64_t)(q0 + s_row) * q_pitch + s_chunk * 16;
     const uint8_t *gB = codes + (row0 + s_row) * ad + s_chunk * 16;
     const uint32_t n_slabs = (ad + BK - 1) / BK;
 
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
         const bool in = k < ad;  // ad is a multiple of 16: a chunk is entirely in or out
 #pragma unroll
         for (int i = 0; i < LA; i++)
-            ra[i] = in ? *reinterpret_cast<const uint4 *>(gA + (uint64_t)(ROWS_PER_PASS * i) * ad + s * BK)
+            ra[i] = in ? *reinterpret_cast<const uint4 *>(gA + (uint64_t)(ROWS_PER_PASS * i) * q_pitch + s * BK)
                        : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < LB; i++)
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
     load_slab(0);
     store_slab(0);
     __syncthreads();
+    stamp(1);
     for (uint32_t s = 0; s < n_slabs; s++) {
         const int cur = s & 1;
         if (s + 1 < n_slabs) load_slab(s + 1);
@@ -154,9 +167,11 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
                 for (int j = 0; j < MJ; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        if (s < 8) stamp(2 + s);  // MFMAs of slab s issued
         if (s + 1 < n_slabs) store_slab(cur ^ 1);
         __syncthreads();
     }
+    stamp(10);
 
     // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2)
     // + 4*(lane >> 5): query index on the registers, store row on the lanes (coalesced writes).
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
         if (MODE != 0) pivot_s[i] = filt.pivot_scores[q0 + i];
     }
     __syncthreads();
+    stamp(11);
     constexpr bool LARGEST = MODE == 1;
     const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
 #pragma unroll
@@ -224,6 +240,261 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
             }
         }
     }
+    stamp(12);
+}
+
+// ------------------------------------------------------------------------------------------
+// Ping-pong kernel (batches of more than 128 queries).  Same arithmetic and epilogue as
+// u8_gemm_kernel; what changes is how the matrix pipe is kept fed:
+//   * persistent workgroups (one per CU, 8 waves): a workgroup keeps one query tile (256 queries)
+//     and walks row tiles xcd + 8*(row_lane + row_lanes*i); the q_tiles workgroups of one
+//     (XCD, row_lane) walk the same row tiles, so a row tile comes from HBM once per XCD.
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers and
+//     no ds_write pass; K is a continuous stream of 64-byte K-tiles (across output tiles too, so
+//     the next tile's first K-tiles are in flight during the epilogue) through a ring of four
+//     32 KiB slots, three K-tiles ahead, retired with COUNTED vmcnt waits.
+//   * LDS image is lane-linear per DMA instruction (16 rows x 64 B); the 16-byte chunk index is
+//     XOR-swizzled with (row>>2)&3 on the SOURCE address and on the fragment read, which makes
+//     every ds_read_b128 lane group hit 16 distinct 16-byte slots.
+//   * the two wave groups (waves 0-3: queries 0-127, waves 4-7: queries 128-255; one wave of each
+//     per SIMD) run half a phase apart: while one group issues its 8 MFMAs (256 cycles) the other
+//     reads its fragments and issues DMA.  Raw s_barrier at every half-phase boundary.
+// Time is counted in slots (one barrier each).  Group g runs phase p of K-tile u in slots
+// 4u+2p+g (reads + DMA issue) and 4u+2p+g+1 (MFMAs).  Hazards, by slot number:
+//   RAW  K-tile u+1 is first read in slot 4u+4; every wave retires its DMA of K-tile u+1 with a
+//        counted vmcnt at the end of its phase-0 MFMA slot of K-tile u (slots 4u+1 / 4u+2).
+//   WAR  B of K-tile u+3 (ring slot of K-tile u-1) is issued in slots 4u / 4u+1; the last reads of
+//        K-tile u-1's B were issued in slot 4u-3 and waited for in slot 4u-2.  A of K-tile u+3 is
+//        issued in slots 4u+2 / 4u+3; the last reads of K-tile u-1's A were issued in slot 4u-1
+//        and waited for in slot 4u.  (Issuing the DMA inside the MFMA slot instead was measured:
+//        the main loop got 10 % slower.)
+constexpr int PP_KT = 64;                      // K-tile bytes per row
+constexpr int PP_UNIT = 256 * PP_KT;           // one operand of one K-tile: 16 KiB
+constexpr int PP_SLOT = 2 * PP_UNIT;           // B then A
+constexpr int PP_RING = 4;
+constexpr size_t PP_LDS = (size_t)PP_RING * PP_SLOT + 2 * 256 * sizeof(float);
+
+#define PP_BARRIER()                          \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+
+__device__ __forceinline__ void pp_glds16(const uint8_t *src, uint8_t *lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void pp_wait_vm(uint32_t n) {  // n is wave-uniform, one of 0 2 4 6 8
+    if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restrict__ codes,
+                                                        const float *__restrict__ v_offsets,
+                                                        const uint8_t *__restrict__ qcodes, uint32_t q_pitch,
+                                                        const float *__restrict__ q_offsets, float multiplier,
+                                                        uint32_t n_rows, uint32_t n_queries, uint32_t ad,
+                                                        uint32_t q_tiles, uint32_t row_lanes,
+                                                        float *__restrict__ out, uint64_t out_pitch,
+                                                        BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = wave >> 2, wr = wave & 3, r = lane & 31, h = lane >> 5;
+    const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+    if (j >= row_lanes * q_tiles) return;
+    const uint32_t q_tile = j % q_tiles, row_lane = j / q_tiles;
+    const uint32_t q0 = q_tile * 256;
+    const uint32_t n_rtiles = (n_rows + 255) / 256;
+    const uint32_t first = xcd + 8 * row_lane, step = 8 * row_lanes;
+    if (first >= n_rtiles) return;
+    const uint32_t my_tiles = __builtin_amdgcn_readfirstlane((n_rtiles - first + step - 1) / step);
+    const uint32_t nkt = __builtin_amdgcn_readfirstlane((ad + PP_KT - 1) / PP_KT);
+    const uint32_t total = my_tiles * nkt;  // K-tiles in this workgroup's stream
+
+    unsigned long long *stamps = g_gemm_stamps;
+    if (stamps) stamps = (blockIdx.x < kStampBlocks && lane == 0) ? stamps + ((uint64_t)blockIdx.x * 8 + wave) * 16 : nullptr;
+    auto stamp = [&](int slot) {
+        if (stamps) stamps[slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    // The workgroup's query tile never changes: its per-query constants are staged once.
+    float *q_off_s = reinterpret_cast<float *>(lds_raw + (size_t)PP_RING * PP_SLOT);  // [256]
+    float *pivot_s = q_off_s + 256;                                                   // [256]
+    if (t < 256) {
+        q_off_s[t] = q_offsets[q0 + t];
+        if (MODE != 0) pivot_s[t] = filt.pivot_scores[q0 + t];
+    }
+    __syncthreads();
+
+    // DMA addressing: instruction `idx` of an operand covers rows idx*128 + wave*16 + lane/4;
+    // lane writes LDS (row, position lane%4) and fetches chunk (lane%4) ^ ((row>>2)&3).
+    const uint32_t dma_row = wave * 16 + (lane >> 2);
+    const uint32_t dma_chunk = (((uint32_t)lane & 3u) ^ ((uint32_t)lane >> 4)) * 16;
+    uint32_t pf_tile = first, pf_kt = 0, pf_u = 0;
+    auto issue_B = [&]() {
+        const uint8_t *src = codes + ((uint64_t)pf_tile * 256 + dma_row) * ad + pf_kt * PP_KT + dma_chunk;
+        uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + wave * 1024;
+        pp_glds16(src, dst);
+        pp_glds16(src + (uint64_t)128 * ad, dst + 128 * PP_KT);
+    };
+    auto issue_A = [&]() {  // second half of a K-tile's DMA: advances the prefetch position
+        const uint8_t *src = qcodes + ((uint64_t)q0 + dma_row) * q_pitch + pf_kt * PP_KT + dma_chunk;
+        uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + PP_UNIT + wave * 1024;
+        pp_glds16(src, dst);
+        pp_glds16(src + (uint64_t)128 * q_pitch, dst + 128 * PP_KT);
+        pf_u++;
+        if (++pf_kt == nkt) {
+            pf_kt = 0;
+            pf_tile += step;
+        }
+    };
+    // fragment read offsets: chunk 2*ks + h of row r (+ multiples of 16 rows), swizzled
+    const uint32_t swz = ((uint32_t)r >> 2) & 3u;
+    const uint32_t off0 = (((uint32_t)h) ^ swz) * 16, off1 = ((2u + (uint32_t)h) ^ swz) * 16;
+    const uint32_t fragA = PP_UNIT + (g * 128 + r) * PP_KT, fragB = (wr * 64 + r) * PP_KT;
+
+    // prologue: K-tiles 0..2 in flight, K-tile 0 retired
+    for (int k = 0; k < 3; k++)
+        if (pf_u < total) {
+            issue_B();
+            issue_A();
+        }
+    pp_wait_vm((total > 1 ? 4u : 0u) + (total > 2 ? 4u : 0u));
+    PP_BARRIER();
+    stamp(1);
+    if (g == 1) PP_BARRIER();  // group 1 runs one slot behind
+
+    constexpr bool LARGEST = MODE == 1;
+    const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
+    uint32_t tile = first, u = 0;
+    for (uint32_t ti = 0; ti < my_tiles; ti++, tile += step) {
+    v16i acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jj][e] = 0;
+    for (uint32_t kt = 0; kt < nkt; kt++, u++) {
+        const uint8_t *slot = lds_raw + (u & 3u) * PP_SLOT;
+        const uint8_t *pA = slot + fragA, *pB = slot + fragB;
+        // ---- phase 0: query fragments 0,1 and both row fragments
+        v4i a[2][2], bf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            bf[i][0] = *reinterpret_cast<const v4i *>(pB + i * 32 * PP_KT + off0);
+            bf[i][1] = *reinterpret_cast<const v4i *>(pB + i * 32 * PP_KT + off1);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            a[i][0] = *reinterpret_cast<const v4i *>(pA + i * 32 * PP_KT + off0);
+            a[i][1] = *reinterpret_cast<const v4i *>(pA + i * 32 * PP_KT + off1);
+        }
+        const bool more = u + 3 < total;
+        if (more) issue_B();
+        PP_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ks], bf[jj][ks], acc[i][jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        pp_wait_vm((u + 2 < total ? 4u : 0u) + (more ? 2u : 0u));  // retires K-tile u+1
+        PP_BARRIER();
+        // ---- phase 1: query fragments 2,3 against the row fragments already in registers
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            a[i][0] = *reinterpret_cast<const v4i *>(pA + (2 + i) * 32 * PP_KT + off0);
+            a[i][1] = *reinterpret_cast<const v4i *>(pA + (2 + i) * 32 * PP_KT + off1);
+        }
+        if (more) issue_A();
+        PP_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[2 + i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ks], bf[jj][ks], acc[2 + i][jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BARRIER();
+    }
+
+        // ---- tile finished.  Both groups run the epilogue together (group 0 waits one slot for
+        // group 1's last MFMAs; group 1 falls one slot behind again afterwards).
+        if (g == 0) PP_BARRIER();
+        if (ti < 8) stamp(2 + (int)ti);  // tile's MFMAs issued (first 8 tiles)
+        const uint64_t row0 = (uint64_t)tile * 256;
+        // opaque per tile: keeps the 128 per-query output addresses from being hoisted out of the
+        // K loop as loop invariants (256 registers' worth, i.e. spilled)
+        // (same for everything else the epilogue derives from the lane / wave id: with 128
+        // accumulators live, every hoisted invariant is a spill in the K loop)
+        uint32_t q0_e = q0, wave_e = (uint32_t)wave, lane_e = (uint32_t)lane;
+        asm volatile("" : "+s"(q0_e), "+s"(wave_e), "+v"(lane_e));
+        const uint32_t g_e = wave_e >> 2, wr_e = wave_e & 3u, r_e = lane_e & 31u, h_e = lane_e >> 5;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const uint64_t row = row0 + wr_e * 64 + jj * 32 + r_e;
+            const bool row_ok = row < n_rows;
+            const float v_off = (MODE == 0 || row_ok) ? v_offsets[row] : never;  // padded like codes[]
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time: no load clustering across tiles
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {  // registers 4gq .. 4gq+3 are four consecutive queries
+                    const uint32_t ql = g_e * 128 + i * 32 + 8 * gq + 4 * h_e;
+                    const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
+                    const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                    float sc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) sc[e] = (multiplier * (float)acc[i][jj][4 * gq + e] + qo[e]) + v_off;
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const uint32_t q = q0_e + ql + e;
+                            if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc[e];
+                        }
+                    } else {
+                        const float4 pv4 = *reinterpret_cast<const float4 *>(pivot_s + ql);
+                        const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                        float d[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) d[e] = LARGEST ? sc[e] - pv[e] : pv[e] - sc[e];
+                        const float dmax = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
+                        if (dmax >= 0.0f) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                if (d[e] >= 0.0f) {
+                                    const uint32_t q = q0_e + ql + e;
+                                    const uint32_t key = topk_ordered_bits(sc[e], LARGEST);
+                                    const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
+                                    if (pos < kBatchCap)
+                                        filt.candidates[(uint64_t)q * kBatchCap + pos] =
+                                            ((unsigned long long)key << 32) | (uint32_t)row;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (ti < 8) stamp(10);  // overwritten per tile: last epilogue end among the first 8
+        if (g == 1 && ti + 1 < my_tiles) PP_BARRIER();  // fall one slot behind again
+    }
+    stamp(12);
 }
 
 // Gather `n` sampled rows (codes + offsets) into a dense sub-store for the pivot pass.
@@ -336,8 +607,9 @@ struct qamd_u8_query_batch {
     int device = 0;
     uint64_t actual_dim = 0;
     uint64_t n_queries = 0;
-    uint64_t q_pad = 0;  // round_up(n_queries, 128)
-    DevBuf codes;        // [q_pad][actual_dim], zero rows past n_queries
+    uint64_t q_pad = 0;  // round_up(n_queries, 256)
+    uint64_t pitch = 0;  // round_up(actual_dim, 64): whole 64-byte K-tiles, zero padded
+    DevBuf codes;        // [q_pad][pitch], zero rows past n_queries
     DevBuf offsets;      // [q_pad] f32
 };
 
@@ -369,10 +641,43 @@ qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, cons
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
     hipLaunchKernelGGL((u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>), dim3((unsigned)blocks), dim3(64 * WQ * WR), lds_bytes,
-                       s, codes, v_offsets, b->codes.as<uint8_t>(), b->offsets.as<float>(), h->meta.multiplier,
+                       s, codes, v_offsets, b->codes.as<uint8_t>(), (uint32_t)b->pitch, b->offsets.as<float>(), h->meta.multiplier,
                        (uint32_t)n_rows, (uint32_t)b->n_queries, (uint32_t)h->meta.actual_dim, q_tiles, out, out_pitch,
                        filt);
     QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+// Ping-pong kernel launch: one persistent workgroup per CU; at most 32 query tiles per launch
+// (8192 queries), larger batches go in slices of 8192.
+template <int MODE>
+qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                           const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                           const BatchFilter &filt, hipStream_t s) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
+    });
+    const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
+    const uint64_t all_q_tiles = (b->n_queries + 255) / 256;
+    for (uint64_t qt0 = 0; qt0 < all_q_tiles; qt0 += cus_per_xcd) {
+        const uint32_t q_tiles = (uint32_t)std::min<uint64_t>(cus_per_xcd, all_q_tiles - qt0);
+        const uint32_t row_lanes = cus_per_xcd / q_tiles;
+        const uint64_t q_base = qt0 * 256;
+        BatchFilter f = filt;
+        if (MODE != 0) {
+            f.pivot_scores += q_base;
+            f.counters += q_base * kCounterStride;
+            f.candidates += q_base * kBatchCap;
+        }
+        hipLaunchKernelGGL((u8_gemm_pp_kernel<MODE>), dim3(8 * row_lanes * q_tiles), dim3(512), PP_LDS, s, codes,
+                           v_offsets, b->codes.as<uint8_t>() + q_base * b->pitch, (uint32_t)b->pitch,
+                           b->offsets.as<float>() + q_base, h->meta.multiplier, (uint32_t)n_rows,
+                           (uint32_t)(b->n_queries - q_base), (uint32_t)h->meta.actual_dim, q_tiles, row_lanes,
+                           MODE == 0 ? out + q_base * out_pitch : out, out_pitch, f);
+        QAMD_HIP(hipGetLastError());
+    }
     return QAMD_OK;
 }
 
@@ -384,10 +689,13 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
     // q_pad is a multiple of 256 and the row padding of every store covers a 256-row tile.
     if (b->n_queries > 128) {
         static const char *cfg = getenv("QAMD_GEMM_CFG");  // developer A/B switch
+        if (!cfg || cfg[0] == 'p') return launch_gemm_pp<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
         if (cfg && cfg[0] == '3')  // two 4-wave workgroups per CU (61 KiB LDS each), 128 q x 256 rows
             return launch_gemm_cfg<MODE, 128, 256, 2, 2, 64>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
         if (cfg && cfg[0] == '4')  // same, 256 q x 128 rows
             return launch_gemm_cfg<MODE, 256, 128, 2, 2, 64>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        if (cfg && cfg[0] == '5')  // one wave per SIMD, 128 x 128 outputs per wave (256 accumulator registers)
+            return launch_gemm_cfg<MODE, 256, 256, 2, 2, 128>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
         return launch_gemm_cfg<MODE, 256, 256, 2, 4, 128>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     }
     return launch_gemm_cfg<MODE, 128, 128, 2, 2, 128>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
@@ -396,6 +704,12 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
 }  // namespace
 
 extern "C" {
+
+// Developer hook: device buffer of kStampBlocks * 8 * 16 u64 (or null to switch the timeline off).
+QAMD_API qamd_status qamd_dev_gemm_stamps(void *dev_buffer) {
+    QAMD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &dev_buffer, sizeof(void *)));
+    return QAMD_OK;
+}
 
 qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, uint64_t n_queries, uint64_t qdim,
                                        qamd_mem queries_mem, void *stream, qamd_u8_query_batch **batch_io) {
@@ -411,8 +725,10 @@ qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, u
         b->device = h->device;
     }
     const uint64_t q_pad = round_up(std::max<uint64_t>(n_queries, 1), TQ);
+    const uint64_t pitch = round_up(std::max<uint64_t>(ad, 16), 64);
     if (b->actual_dim != ad || b->q_pad != q_pad || !b->codes.ptr) {
-        QAMD_TRY(b->codes.alloc(q_pad * std::max<uint64_t>(ad, 16), true));
+        b->pitch = pitch;
+        QAMD_TRY(b->codes.alloc(q_pad * pitch, true));
         QAMD_TRY(b->offsets.alloc(q_pad * sizeof(float), true));
         b->actual_dim = ad;
         b->q_pad = q_pad;
@@ -429,7 +745,7 @@ qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, u
             QAMD_TRY(copy_in(tmp.ptr, queries, QAMD_MEM_HOST, n_queries * qdim * 4, s));
             qd = tmp.as<float>();
         }
-        QAMD_TRY(u8_encode_queries_device(h, qd, n_queries, qdim, b->codes.as<uint8_t>(), b->offsets.as<float>(), s));
+        QAMD_TRY(u8_encode_queries_device(h, qd, n_queries, qdim, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), s));
         if (queries_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
     }
     if (fresh) *batch_io = fresh.release();
@@ -526,7 +842,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     // Queries not served by the fused pass (small stores, overflowed lists): exact single-query path.
     for (uint64_t q = 0; q < Q; q++) {
         if (!status[q]) continue;
-        QAMD_TRY(u8_topk_single(h, b->codes.as<uint8_t>() + q * b->actual_dim, b->offsets.as<float>() + q, k, largest,
+        QAMD_TRY(u8_topk_single(h, b->codes.as<uint8_t>() + q * b->pitch, b->offsets.as<float>() + q, k, largest,
                                 ids_dev + q * k, sc_dev + q * k, QAMD_MEM_DEVICE, s));
     }
     if (out_mem == QAMD_MEM_HOST) {

@@ -23,7 +23,8 @@ struct qamd_u8_query {
 // encode_query for one query per wave (device-resident f32 queries); defined in u8.hip.
 namespace qamd {
 qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev, uint64_t n_queries, uint64_t qdim,
-                                     uint8_t *codes_dev /* [n][actual_dim] */, float *offsets_dev /* [n] */,
+                                     uint8_t *codes_dev /* [n][code_pitch], actual_dim written */, uint64_t code_pitch,
+                                     float *offsets_dev /* [n] */,
                                      hipStream_t stream);
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,
                            int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);

@@ -1,0 +1,79 @@
+"""In-kernel timeline of u8_gemm_kernel (developer tool): phase durations in shader cycles.
+
+Usage: python tools/gemm_timeline.py [NQ] [N] [DIM]
+"""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import quantization_amd as qa
+from quantization_amd import _lib
+
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
+dim = int(sys.argv[3]) if len(sys.argv) > 3 else 768
+dev = torch.device("cuda", 0)
+data = torch.rand((n, dim), device=dev)
+enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, qa.DistanceType.Dot, False))
+del data
+batch = enc.encode_query_batch(torch.rand((nq, dim), device=dev))
+ids = torch.empty(nq * 30, dtype=torch.int32, device=dev)
+sc = torch.empty(nq * 30, dtype=torch.float32, device=dev)
+L = _lib.lib()
+L.qamd_dev_gemm_stamps.argtypes = [C.c_void_p]
+WAVES = int(os.environ.get("WAVES", 8))
+for _ in range(2):
+    enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc)
+torch.cuda.synchronize()
+stamps = torch.zeros(4096 * WAVES * 16, dtype=torch.int64, device=dev)
+assert L.qamd_dev_gemm_stamps(C.c_void_p(stamps.data_ptr())) == 0
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc)
+e1.record()
+torch.cuda.synchronize()
+L.qamd_dev_gemm_stamps(None)
+print(f"topk_batch with stamps: {e0.elapsed_time(e1):.2f} ms")
+st = stamps.cpu().numpy().reshape(4096, WAVES, 16)
+if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "p":
+    # ping-pong kernel: persistent workgroups; slot 0 entry, 1 prologue done, 2..9 MFMAs of tile
+    # 0..7 issued, 10 end of the last stamped epilogue, 12 exit
+    blk = st[:256]
+    ok = (blk[:, :, 12] > 0).all(axis=1)
+    blk = blk[ok]
+    print("workgroups with stamps:", blk.shape[0])
+    def dd(a, b):
+        x = (blk[:, :, b] - blk[:, :, a]).astype(np.float64)
+        return f"{x.mean():9.0f} (p10 {np.percentile(x, 10):7.0f}, p90 {np.percentile(x, 90):7.0f})"
+    n_slabs = (enc.metadata["actual_dim"] + 63) // 64
+    print(f"K-tiles per tile: {n_slabs}; ideal MFMA cycles per tile: {n_slabs * 1024}")
+    print("entry -> prologue done          ", dd(0, 1))
+    print("tile 0 main loop                ", dd(1, 2))
+    for tix in range(1, 8):
+        print(f"tile {tix} period (epilogue {tix-1} + loop)", dd(1 + tix, 2 + tix))
+    print("whole workgroup                 ", dd(0, 12))
+    sys.exit(0)
+# the LAST launch that wrote stamps is the filter pass over the full store (the sample pass ran
+# first and was overwritten for the blocks both have).  Use blocks 1024.. (steady state).
+blk = st[1024:4096]
+ok = blk[:, :, 12] > 0
+print("blocks with stamps:", int(ok.all(axis=1).sum()))
+def d(a, b):
+    x = (blk[:, :, b] - blk[:, :, a])[ok]
+    return f"{x.mean():9.0f} (p10 {np.percentile(x, 10):7.0f}, p90 {np.percentile(x, 90):7.0f})"
+print("entry -> first slab staged   ", d(0, 1))
+n_slabs = (enc.metadata["actual_dim"] + 127) // 128
+prev = 1
+for s in range(min(n_slabs, 8)):
+    print(f"slab {s}: MFMAs issued         ", d(prev, 2 + s))
+    prev = 2 + s
+print("last slab -> loop end        ", d(prev, 10))
+print("loop end -> epilogue consts  ", d(10, 11))
+print("epilogue                     ", d(11, 12))
+print("whole workgroup              ", d(0, 12))
+# workgroup-level: how long is a CU busy with one tile, and start-to-start spacing per CU unknown;
+# report the spread of wave end times inside a workgroup
+end = blk[:, :, 12]
+print("wave end skew inside a workgroup (max-min):", float((end.max(axis=1) - end.min(axis=1)).mean()))
