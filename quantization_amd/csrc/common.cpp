@@ -69,6 +69,31 @@ void DevBuf::release() {
     bytes = 0;
 }
 
+qamd_status StreamBuf::alloc(size_t n, hipStream_t s, bool zero) {
+    release();
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+    });
+    if (n == 0) n = 16;
+    stream = s;
+    QAMD_HIP(hipMallocAsync(&ptr, n, s));
+    bytes = n;
+    if (zero) QAMD_HIP(hipMemsetAsync(ptr, 0, n, s));
+    return QAMD_OK;
+}
+
+void StreamBuf::release() {
+    if (ptr) (void)hipFreeAsync(ptr, stream);
+    ptr = nullptr;
+    bytes = 0;
+}
+
 qamd_status copy_in(void *dev_dst, const void *src, qamd_mem src_mem, size_t bytes, hipStream_t s) {
     if (bytes == 0) return QAMD_OK;
     if (src_mem == QAMD_MEM_DEVICE) {

@@ -64,6 +64,23 @@ struct DevBuf {
 
 inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
+// Per-call scratch, stream-ordered (hipMallocAsync / hipFreeAsync on the call's stream).  The
+// device's default pool keeps what it has been given (release threshold raised once), so a
+// steady stream of calls neither pays hipMalloc nor hands memory back to the driver, whose
+// clearing of returned VRAM competes with the kernels that follow.
+struct StreamBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    hipStream_t stream = nullptr;
+    StreamBuf() = default;
+    StreamBuf(const StreamBuf &) = delete;
+    StreamBuf &operator=(const StreamBuf &) = delete;
+    ~StreamBuf() { release(); }
+    qamd_status alloc(size_t n, hipStream_t s, bool zero = false);
+    void release();
+    template <typename T> T *as() const { return static_cast<T *>(ptr); }
+};
+
 // Copy helpers: `mem` describes the caller side.
 qamd_status copy_in(void *dev_dst, const void *src, qamd_mem src_mem, size_t bytes, hipStream_t s);
 qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t bytes, hipStream_t s);

@@ -55,11 +55,19 @@ struct BatchFilter {
     uint32_t *counters;              // [Qpad * kCounterStride]
     unsigned long long *candidates;  // [Qpad][kBatchCap]
     int largest;
+    // ping-pong kernel: candidates are first appended to wave-private lists (no global atomic in
+    // the GEMM's epilogue), then distributed to the per-query lists by wave_scatter_kernel
+    uint4 *wave_cand;       // [n_waves][wave_cap]  {key, row, query, 0}
+    uint32_t *wave_counts;  // [n_waves] entries appended (may exceed wave_cap: overflow)
+    uint32_t wave_cap;
+    uint32_t wave_base;     // first wave list of this launch
+    uint32_t query_base;    // global index of the launch's query 0
 };
 
 // Developer timeline (tools/gemm_timeline.py): when set, lane 0 of every wave of the first 4096
 // workgroups stores s_memtime at the phase boundaries, 16 slots per wave.
 __device__ unsigned long long *g_gemm_stamps = nullptr;
+__device__ unsigned int g_gemm_dbg = 0;  // TIMING EXPERIMENTS ONLY (results are wrong when set): bit0 skip A DMA, bit1 skip B DMA
 constexpr uint32_t kStampBlocks = 4096;
 
 // S[q][row] for the tile; MODE 0: write scores out[q * out_pitch + row]; MODE 1 / 2: filter for the
@@ -266,13 +274,16 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 //   WAR  B of K-tile u+3 (ring slot of K-tile u-1) is issued in slots 4u / 4u+1; the last reads of
 //        K-tile u-1's B were issued in slot 4u-3 and waited for in slot 4u-2.  A of K-tile u+3 is
 //        issued in slots 4u+2 / 4u+3; the last reads of K-tile u-1's A were issued in slot 4u-1
-//        and waited for in slot 4u.  (Issuing the DMA inside the MFMA slot instead was measured:
-//        the main loop got 10 % slower.)
+//        and waited for in slot 4u.
+// Measured alternatives (in-kernel timeline, tools/gemm_timeline.py): DMA issued inside the MFMA
+// slot: K loop +10 %; one 16-MFMA slot per K-tile and group (half the barriers): K loop +5..15 %.
+// With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
+// 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
 constexpr int PP_KT = 64;                      // K-tile bytes per row
 constexpr int PP_UNIT = 256 * PP_KT;           // one operand of one K-tile: 16 KiB
 constexpr int PP_SLOT = 2 * PP_UNIT;           // B then A
 constexpr int PP_RING = 4;
-constexpr size_t PP_LDS = (size_t)PP_RING * PP_SLOT + 2 * 256 * sizeof(float);
+constexpr size_t PP_LDS = (size_t)PP_RING * PP_SLOT + 3 * 256 * sizeof(float) + 64;  // + q_off, pivot, B_q, 8 counters
 
 #define PP_BARRIER()                          \
     do {                                      \
@@ -295,7 +306,31 @@ __device__ __forceinline__ void pp_wait_vm(uint32_t n) {  // n is wave-uniform, 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int MODE>
+// Integer pre-filter (MODE 1/2).  The filter "score at least as good as the pivot" is, in exact
+// arithmetic, s >= P_q + R_row (or <=, template LOW: when multiplier < 0 xor smallest-first) with
+// P_q = (pivot_q - q_offset_q) / multiplier and R_row = -v_offset_row / multiplier.  Both are
+// rounded to integers on the safe side by more than the f32 epilogue can be off (pp_bound), and
+// the accumulators START at -(B_q + B_row): after the K loop "may pass" is a sign test on the
+// AND (OR) of four accumulators; only groups that may pass run the exact f32 epilogue, which
+// alone decides.  A wrong bound could only cost time, never a result... provided it is on the
+// safe side, which is what pp_bound's slack is for:
+//   |computed score - real score| <= 2^-21 (|m s| + |q_off| + |v_off|)  (four roundings), and for a
+//   candidate the filter rejects, either |m s| <= 2 (|pivot| + |q_off| + |v_off|), which the 2^-19
+//   terms cover, or the real score misses the pivot by more than |m s| / 2 >> that error.
+constexpr float kPpLim = 536870912.0f;  // 2^29: |B_q| + |B_row| + s < 2^31 for actual_dim <= 32768
+template <bool LOW>
+__device__ __forceinline__ int pp_bound(float num /* pivot - q_off, or -v_off */, float mag /* |pivot|+|q_off| or |v_off| */,
+                                        float m, int extra) {
+    const float x = num / m;
+    const float slack = 1.0f + (mag * 0x1p-19f) / fabsf(m) + fabsf(x) * 0x1p-22f;
+    float t = LOW ? ceilf(x + slack) + (float)extra : floorf(x - slack);
+    const float all = LOW ? kPpLim : -kPpLim;
+    if (!(t == t)) t = all;  // NaN: let the exact epilogue decide
+    t = fminf(fmaxf(t, -kPpLim), kPpLim);
+    return (int)t;
+}
+
+template <int MODE, bool LOW>
 __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restrict__ codes,
                                                         const float *__restrict__ v_offsets,
                                                         const uint8_t *__restrict__ qcodes, uint32_t q_pitch,
@@ -325,13 +360,27 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
         if (stamps) stamps[slot] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    const bool dbg = g_gemm_stamps != nullptr;  // wave-uniform
+    unsigned long long dbg_flagged = 0;         // (query group, row) lanes sent to the exact epilogue
 
     // The workgroup's query tile never changes: its per-query constants are staged once.
     float *q_off_s = reinterpret_cast<float *>(lds_raw + (size_t)PP_RING * PP_SLOT);  // [256]
     float *pivot_s = q_off_s + 256;                                                   // [256]
+    int *bq_s = reinterpret_cast<int *>(pivot_s + 256);                               // [256] integer query bounds
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(bq_s + 256) + wave;             // this wave's append counter
+    if (MODE != 0 && lane == 0) *wcount_s = 0;
+    constexpr bool LARGEST = MODE == 1;
     if (t < 256) {
-        q_off_s[t] = q_offsets[q0 + t];
-        if (MODE != 0) pivot_s[t] = filt.pivot_scores[q0 + t];
+        const float qo = q_offsets[q0 + t];
+        q_off_s[t] = qo;
+        if (MODE != 0) {
+            const float pv = filt.pivot_scores[q0 + t];
+            pivot_s[t] = pv;
+            int bq = pp_bound<LOW>(pv - qo, fabsf(pv) + fabsf(qo), multiplier, 1);  // LOW: s <= T  <=>  s - (T+1) < 0
+            if (__builtin_isinf(pv))  // padding query (nothing may pass) or a degenerate pivot (everything does)
+                bq = ((pv > 0.0f) == LARGEST) == LOW ? -(int)kPpLim : (int)kPpLim;
+            bq_s[t] = bq;
+        }
     }
     __syncthreads();
 
@@ -340,17 +389,21 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     const uint32_t dma_row = wave * 16 + (lane >> 2);
     const uint32_t dma_chunk = (((uint32_t)lane & 3u) ^ ((uint32_t)lane >> 4)) * 16;
     uint32_t pf_tile = first, pf_kt = 0, pf_u = 0;
+    const uint32_t dbgf = g_gemm_dbg;
     auto issue_B = [&]() {
         const uint8_t *src = codes + ((uint64_t)pf_tile * 256 + dma_row) * ad + pf_kt * PP_KT + dma_chunk;
         uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + wave * 1024;
+        if (dbgf & 2u) return;
         pp_glds16(src, dst);
         pp_glds16(src + (uint64_t)128 * ad, dst + 128 * PP_KT);
     };
     auto issue_A = [&]() {  // second half of a K-tile's DMA: advances the prefetch position
         const uint8_t *src = qcodes + ((uint64_t)q0 + dma_row) * q_pitch + pf_kt * PP_KT + dma_chunk;
         uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + PP_UNIT + wave * 1024;
-        pp_glds16(src, dst);
-        pp_glds16(src + (uint64_t)128 * q_pitch, dst + 128 * PP_KT);
+        if (!(dbgf & 1u)) {
+            pp_glds16(src, dst);
+            pp_glds16(src + (uint64_t)128 * q_pitch, dst + 128 * PP_KT);
+        }
         pf_u++;
         if (++pf_kt == nkt) {
             pf_kt = 0;
@@ -361,6 +414,23 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     const uint32_t swz = ((uint32_t)r >> 2) & 3u;
     const uint32_t off0 = (((uint32_t)h) ^ swz) * 16, off1 = ((2u + (uint32_t)h) ^ swz) * 16;
     const uint32_t fragA = PP_UNIT + (g * 128 + r) * PP_KT, fragB = (wr * 64 + r) * PP_KT;
+
+    // v_offset of this lane's two rows (jj = 0, 1) for the tile about to start.  Loaded one tile
+    // ahead by inline asm so that the compiler attaches no wait to it (next to LDS-DMA it would
+    // drain everything with vmcnt(0)); the loads are older than the DMA that follows, so the
+    // counted waits of the K loop retire them (K-tile 1's wait at the latest: the launcher sends
+    // stores with fewer than three K-tiles per row to u8_gemm_kernel).  The values are only
+    // touched (copied, used) after the K loop; check the .s when editing this (a register copy
+    // placed before the data has landed would copy garbage).
+    auto load_voff = [&](uint32_t tile_idx, float &v0, float &v1) {
+        const float *p0 = v_offsets + (uint64_t)tile_idx * 256 + wr * 64 + r;  // padded like codes[]
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:128"
+                     : "=&v"(v0), "=&v"(v1)
+                     : "v"(p0)
+                     : "memory");
+    };
+    float vo_next0 = 0.0f, vo_next1 = 0.0f;
+    if (MODE != 0) load_voff(first, vo_next0, vo_next1);
 
     // prologue: K-tiles 0..2 in flight, K-tile 0 retired
     for (int k = 0; k < 3; k++)
@@ -373,17 +443,40 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     stamp(1);
     if (g == 1) PP_BARRIER();  // group 1 runs one slot behind
 
-    constexpr bool LARGEST = MODE == 1;
     const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
     uint32_t tile = first, u = 0;
     for (uint32_t ti = 0; ti < my_tiles; ti++, tile += step) {
     v16i acc[4][2];
+    float vo_cur0 = 0.0f, vo_cur1 = 0.0f;
+    int br0 = 0, br1 = 0;
+    if (MODE == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++)
+            for (int jj = 0; jj < 2; jj++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jj][e] = 0;
+                for (int e = 0; e < 16; e++) acc[i][jj][e] = 0;
+    } else {
+        asm volatile("" : "+v"(vo_next0), "+v"(vo_next1));  // ordered after every wait above
+        vo_cur0 = vo_next0;
+        vo_cur1 = vo_next1;
+        if (ti + 1 < my_tiles) load_voff(tile + step, vo_next0, vo_next1);
+        const uint64_t row_a = (uint64_t)tile * 256 + wr * 64 + r;
+        br0 = row_a < n_rows ? pp_bound<LOW>(-vo_cur0, fabsf(vo_cur0), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+        br1 = row_a + 32 < n_rows ? pp_bound<LOW>(-vo_cur1, fabsf(vo_cur1), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + g * 128 + i * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc[i][0][4 * gq + e] = -(bq4[e] + br0);
+                    acc[i][1][4 * gq + e] = -(bq4[e] + br1);
+                }
+            }
+    }
+    if (ti < 4) stamp(2 + 3 * (int)ti);  // tile set up
     for (uint32_t kt = 0; kt < nkt; kt++, u++) {
         const uint8_t *slot = lds_raw + (u & 3u) * PP_SLOT;
         const uint8_t *pA = slot + fragA, *pB = slot + fragB;
@@ -436,54 +529,69 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
         // ---- tile finished.  Both groups run the epilogue together (group 0 waits one slot for
         // group 1's last MFMAs; group 1 falls one slot behind again afterwards).
         if (g == 0) PP_BARRIER();
-        if (ti < 8) stamp(2 + (int)ti);  // tile's MFMAs issued (first 8 tiles)
+        if (ti < 4) stamp(3 + 3 * (int)ti);  // K loop done
         const uint64_t row0 = (uint64_t)tile * 256;
-        // opaque per tile: keeps the 128 per-query output addresses from being hoisted out of the
-        // K loop as loop invariants (256 registers' worth, i.e. spilled)
-        // (same for everything else the epilogue derives from the lane / wave id: with 128
-        // accumulators live, every hoisted invariant is a spill in the K loop)
+        // opaque per tile: keeps per-query output addresses and everything else the epilogue
+        // derives from the lane / wave id from being hoisted out of the K loop as loop invariants
+        // (with 128 accumulators live, every hoisted invariant is a spill in that loop)
         uint32_t q0_e = q0, wave_e = (uint32_t)wave, lane_e = (uint32_t)lane;
         asm volatile("" : "+s"(q0_e), "+s"(wave_e), "+v"(lane_e));
+        uint4 *wave_list = MODE != 0 ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
         const uint32_t g_e = wave_e >> 2, wr_e = wave_e & 3u, r_e = lane_e & 31u, h_e = lane_e >> 5;
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
             const uint64_t row = row0 + wr_e * 64 + jj * 32 + r_e;
             const bool row_ok = row < n_rows;
-            const float v_off = (MODE == 0 || row_ok) ? v_offsets[row] : never;  // padded like codes[]
+            float v_off;
+            if (MODE == 0) v_off = v_offsets[row];  // padded like codes[]
+            else v_off = row_ok ? (jj ? vo_cur1 : vo_cur0) : never;
+            const int br = jj ? br1 : br0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time: no load clustering across tiles
+                if (MODE == 0) __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time: no load clustering
+                if (MODE != 0) {
+                    // two-level test: one sign test for the whole 32 x 32 accumulator tile first (about
+                    // three quarters of them hold no candidate at all), then per group of four
+                    int all = acc[i][jj][0];
+#pragma unroll
+                    for (int e = 1; e < 16; e++) all = LOW ? (all | acc[i][jj][e]) : (all & acc[i][jj][e]);
+                    if (!__builtin_amdgcn_readfirstlane(__ballot(LOW ? all < 0 : all >= 0) != 0)) continue;
+                }
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {  // registers 4gq .. 4gq+3 are four consecutive queries
                     const uint32_t ql = g_e * 128 + i * 32 + 8 * gq + 4 * h_e;
-                    const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
-                    const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
-                    float sc[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) sc[e] = (multiplier * (float)acc[i][jj][4 * gq + e] + qo[e]) + v_off;
                     if (MODE == 0) {
+                        const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
+                        const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
+                            const float sc = (multiplier * (float)acc[i][jj][4 * gq + e] + qo[e]) + v_off;
                             const uint32_t q = q0_e + ql + e;
-                            if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc[e];
+                            if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc;
                         }
                     } else {
-                        const float4 pv4 = *reinterpret_cast<const float4 *>(pivot_s + ql);
-                        const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
-                        float d[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) d[e] = LARGEST ? sc[e] - pv[e] : pv[e] - sc[e];
-                        const float dmax = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
-                        if (dmax >= 0.0f) {
+                        const int a0 = acc[i][jj][4 * gq], a1 = acc[i][jj][4 * gq + 1], a2 = acc[i][jj][4 * gq + 2],
+                                  a3 = acc[i][jj][4 * gq + 3];
+                        const bool may_pass = LOW ? ((a0 | a1 | a2 | a3) < 0) : ((a0 & a1 & a2 & a3) >= 0);
+                        if (dbg) dbg_flagged += __builtin_popcountll(__ballot(may_pass));
+                        if (may_pass) {  // rare: the exact f32 epilogue for these four (query, row) pairs
+                            const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + ql);
+                            const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
+                            const float4 pv4 = *reinterpret_cast<const float4 *>(pivot_s + ql);
+                            const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                            const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                            const int av[4] = {a0, a1, a2, a3};
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                if (d[e] >= 0.0f) {
-                                    const uint32_t q = q0_e + ql + e;
-                                    const uint32_t key = topk_ordered_bits(sc[e], LARGEST);
-                                    const uint32_t pos = atomicAdd(filt.counters + (uint64_t)q * kCounterStride, 1u);
-                                    if (pos < kBatchCap)
-                                        filt.candidates[(uint64_t)q * kBatchCap + pos] =
-                                            ((unsigned long long)key << 32) | (uint32_t)row;
+                                const int s_int = av[e] + bq4[e] + br;  // the plain integer dot product
+                                const float sc = (multiplier * (float)s_int + qo[e]) + v_off;
+                                const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
+                                if (d >= 0.0f) {
+                                    // wave-private list: an LDS counter, a fire-and-forget 16-byte store
+                                    const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                    if (pos < filt.wave_cap)
+                                        wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row,
+                                                                    filt.query_base + q0_e + ql + e, 0u);
                                 }
                             }
                         }
@@ -491,10 +599,13 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
                 }
             }
         }
-        if (ti < 8) stamp(10);  // overwritten per tile: last epilogue end among the first 8
+        if (ti < 4) stamp(4 + 3 * (int)ti);  // epilogue done
         if (g == 1 && ti + 1 < my_tiles) PP_BARRIER();  // fall one slot behind again
     }
-    stamp(12);
+    stamp(15);
+    if (stamps) stamps[14] = dbg_flagged;
+    if (stamps) stamps[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]
+    if (MODE != 0 && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
 // Gather `n` sampled rows (codes + offsets) into a dense sub-store for the pivot pass.
@@ -509,6 +620,27 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *__restric
         const uint64_t src = ((hsh >> 32) * n_rows) >> 32;  // same golden-ratio scatter as topk.hip
         out_codes[i] = codes[src * row_chunks + c];
         if (c == 0) out_offsets[j] = offsets[src];
+    }
+}
+
+// Wave-private candidate lists -> per-query lists (grid = wave lists).  A list that overflowed
+// sets *overflow: the caller then redoes every query exactly.
+__global__ __launch_bounds__(256) void wave_scatter_kernel(const uint4 *__restrict__ wave_cand,
+                                                          const uint32_t *__restrict__ wave_counts, uint32_t wave_cap,
+                                                          uint32_t *__restrict__ counters,
+                                                          unsigned long long *__restrict__ candidates,
+                                                          uint32_t *__restrict__ overflow) {
+    const uint32_t w = blockIdx.x;
+    uint32_t count = wave_counts[w];
+    if (count > wave_cap) {
+        if (threadIdx.x == 0) *overflow = 1;
+        count = wave_cap;
+    }
+    const uint4 *list = wave_cand + (uint64_t)w * wave_cap;
+    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+        const uint4 c = list[i];
+        const uint32_t pos = atomicAdd(counters + (uint64_t)c.z * kCounterStride, 1u);
+        if (pos < kBatchCap) candidates[(uint64_t)c.z * kBatchCap + pos] = ((unsigned long long)c.x << 32) | c.y;
     }
 }
 
@@ -648,15 +780,21 @@ qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, cons
     return QAMD_OK;
 }
 
+inline uint32_t pp_waves_per_launch() { return (uint32_t)std::max(1, device_info().cu_count / 8) * 8 * 8; }
+inline uint32_t pp_launches(uint64_t n_queries) {
+    const uint64_t per = (uint64_t)std::max(1, device_info().cu_count / 8) * 256;
+    return (uint32_t)((n_queries + per - 1) / per);
+}
+
 // Ping-pong kernel launch: one persistent workgroup per CU; at most 32 query tiles per launch
 // (8192 queries), larger batches go in slices of 8192.
-template <int MODE>
-qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+template <int MODE, bool LOW>
+qamd_status launch_gemm_pp_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
     });
     const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
@@ -668,10 +806,10 @@ qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const
         BatchFilter f = filt;
         if (MODE != 0) {
             f.pivot_scores += q_base;
-            f.counters += q_base * kCounterStride;
-            f.candidates += q_base * kBatchCap;
+            f.query_base = (uint32_t)q_base;
+            f.wave_base = (uint32_t)(qt0 / cus_per_xcd) * pp_waves_per_launch();
         }
-        hipLaunchKernelGGL((u8_gemm_pp_kernel<MODE>), dim3(8 * row_lanes * q_tiles), dim3(512), PP_LDS, s, codes,
+        hipLaunchKernelGGL((u8_gemm_pp_kernel<MODE, LOW>), dim3(8 * row_lanes * q_tiles), dim3(512), PP_LDS, s, codes,
                            v_offsets, b->codes.as<uint8_t>() + q_base * b->pitch, (uint32_t)b->pitch,
                            b->offsets.as<float>() + q_base, h->meta.multiplier, (uint32_t)n_rows,
                            (uint32_t)(b->n_queries - q_base), (uint32_t)h->meta.actual_dim, q_tiles, row_lanes,
@@ -682,14 +820,35 @@ qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const
 }
 
 template <int MODE>
+qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                           const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                           const BatchFilter &filt, hipStream_t s) {
+    if (MODE == 0) return launch_gemm_pp_cfg<0, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    // "may pass" is s <= bound when the score falls with s (multiplier < 0) xor smallest-first
+    const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
+    if (low) return launch_gemm_pp_cfg<(MODE == 0 ? 1 : MODE), true>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    return launch_gemm_pp_cfg<(MODE == 0 ? 1 : MODE), false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+}
+
+// Which kernel serves a batch: the ping-pong kernel for more than 128 queries (rows of at least
+// three 64-byte K-tiles, a usable multiplier for its integer pre-filter), else u8_gemm_kernel.
+bool pp_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
+    if (b->n_queries <= 128) return false;
+    static const char *cfg = getenv("QAMD_GEMM_CFG");  // developer A/B switch: 0/3/4/5 = u8_gemm_kernel shapes
+    if (cfg && cfg[0] != 'p') return false;
+    const float m = h->meta.multiplier;
+    return h->meta.actual_dim > 128 && h->meta.actual_dim <= 32768 && (!filter_mode || (std::isfinite(m) && m != 0.0f));
+}
+
+template <int MODE>
 qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                         const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                         const BatchFilter &filt, hipStream_t s) {
     if (n_rows == 0 || b->n_queries == 0) return QAMD_OK;
     // q_pad is a multiple of 256 and the row padding of every store covers a 256-row tile.
+    if (pp_selected(h, b, MODE != 0)) return launch_gemm_pp<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (b->n_queries > 128) {
-        static const char *cfg = getenv("QAMD_GEMM_CFG");  // developer A/B switch
-        if (!cfg || cfg[0] == 'p') return launch_gemm_pp<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        static const char *cfg = getenv("QAMD_GEMM_CFG");
         if (cfg && cfg[0] == '3')  // two 4-wave workgroups per CU (61 KiB LDS each), 128 q x 256 rows
             return launch_gemm_cfg<MODE, 128, 256, 2, 2, 64>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
         if (cfg && cfg[0] == '4')  // same, 256 q x 128 rows
@@ -704,6 +863,11 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
 }  // namespace
 
 extern "C" {
+
+QAMD_API qamd_status qamd_dev_gemm_debug(unsigned int flags) {
+    QAMD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &flags, sizeof(flags)));
+    return QAMD_OK;
+}
 
 // Developer hook: device buffer of kStampBlocks * 8 * 16 u64 (or null to switch the timeline off).
 QAMD_API qamd_status qamd_dev_gemm_stamps(void *dev_buffer) {
@@ -788,41 +952,68 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     const uint32_t r = n ? (uint32_t)std::ceil((double)S * target / (double)n) : 0;
     const bool fused = n >= (1u << 20) && r <= 64;
 
-    DevBuf ids_tmp, sc_tmp;
+    StreamBuf ids_tmp, sc_tmp;
     uint32_t *ids_dev = out_ids;
     float *sc_dev = out_scores;
     if (out_mem == QAMD_MEM_HOST) {
-        QAMD_TRY(ids_tmp.alloc(Q * k * 4));
-        QAMD_TRY(sc_tmp.alloc(Q * k * 4));
+        QAMD_TRY(ids_tmp.alloc(Q * k * 4, s));
+        QAMD_TRY(sc_tmp.alloc(Q * k * 4, s));
         ids_dev = ids_tmp.as<uint32_t>();
         sc_dev = sc_tmp.as<float>();
     }
     std::vector<uint32_t> status(Q, 1);
     if (fused) {
         const uint64_t ad = h->meta.actual_dim;
-        DevBuf s_codes, s_offs, s_scores, pivots, counters, cand, status_dev;
-        QAMD_TRY(s_codes.alloc((uint64_t)(S + TR) * ad, true));  // + one tile of zero rows
-        QAMD_TRY(s_offs.alloc((uint64_t)(S + TR) * 4, true));
-        QAMD_TRY(s_scores.alloc(Q * (uint64_t)S * 4));
-        QAMD_TRY(pivots.alloc(b->q_pad * 4, true));
-        QAMD_TRY(counters.alloc(b->q_pad * kCounterStride * 4, true));
-        QAMD_TRY(cand.alloc(Q * (uint64_t)kBatchCap * 8));
-        QAMD_TRY(status_dev.alloc(Q * 4));
+        StreamBuf s_codes, s_offs, s_scores, pivots, counters, cand, status_dev;
+        QAMD_TRY(s_codes.alloc((uint64_t)(S + TR) * ad, s, true));  // + one tile of zero rows
+        QAMD_TRY(s_offs.alloc((uint64_t)(S + TR) * 4, s, true));
+        QAMD_TRY(s_scores.alloc(Q * (uint64_t)S * 4, s));
+        QAMD_TRY(pivots.alloc(b->q_pad * 4, s, true));
+        QAMD_TRY(counters.alloc(b->q_pad * kCounterStride * 4, s, true));
+        QAMD_TRY(cand.alloc(Q * (uint64_t)kBatchCap * 8, s));
+        QAMD_TRY(status_dev.alloc(Q * 4, s));
         hipLaunchKernelGGL(gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->codes.as<uint4>(),
                            h->offsets.as<float>(), h->row_chunks, n, S, s_codes.as<uint4>(), s_offs.as<float>());
         QAMD_TRY(launch_gemm<0>(h, b, s_codes.as<uint8_t>(), s_offs.as<float>(), S, s_scores.as<float>(), S,
                                 BatchFilter{}, s));
         hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores.as<float>(), S,
                            (uint64_t)S, r, largest, (uint32_t)Q, pivots.as<float>(), counters.as<uint32_t>());
-        BatchFilter f{pivots.as<float>(), counters.as<uint32_t>(), cand.as<unsigned long long>(), largest};
+        BatchFilter f{};
+        f.pivot_scores = pivots.as<float>();
+        f.counters = counters.as<uint32_t>();
+        f.candidates = cand.as<unsigned long long>();
+        f.largest = largest;
+        const bool pp = pp_selected(h, b, true);
+        StreamBuf wave_cand, wave_counts, overflow_dev;
+        uint32_t n_lists = 0;
+        if (pp) {
+            // wave-private lists: 4x the expected appends per wave (about `target`..2*target per query)
+            n_lists = pp_launches(Q) * pp_waves_per_launch();
+            const double per_wave = 2.0 * target * (double)Q / (double)n_lists;
+            f.wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(1024.0, 4.0 * per_wave));
+            QAMD_TRY(wave_cand.alloc((uint64_t)n_lists * f.wave_cap * sizeof(uint4), s));
+            QAMD_TRY(wave_counts.alloc((uint64_t)n_lists * 4, s, true));
+            QAMD_TRY(overflow_dev.alloc(4, s, true));
+            f.wave_cand = wave_cand.as<uint4>();
+            f.wave_counts = wave_counts.as<uint32_t>();
+        }
         if (largest)
             QAMD_TRY(launch_gemm<1>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
         else
             QAMD_TRY(launch_gemm<2>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
+        if (pp)
+            hipLaunchKernelGGL(wave_scatter_kernel, dim3(n_lists), dim3(256), 0, s, wave_cand.as<uint4>(),
+                               wave_counts.as<uint32_t>(), f.wave_cap, counters.as<uint32_t>(),
+                               cand.as<unsigned long long>(), overflow_dev.as<uint32_t>());
         hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand.as<unsigned long long>(),
                            counters.as<uint32_t>(), n, k, largest, ids_dev, sc_dev, status_dev.as<uint32_t>());
         QAMD_HIP(hipGetLastError());
         QAMD_TRY(copy_out(status.data(), QAMD_MEM_HOST, status_dev.ptr, Q * 4, s));  // synchronises
+        if (pp) {
+            uint32_t overflow = 0;
+            QAMD_TRY(copy_out(&overflow, QAMD_MEM_HOST, overflow_dev.ptr, 4, s));
+            if (overflow) std::fill(status.begin(), status.end(), 1u);  // a wave list overflowed: redo all exactly
+        }
         if (getenv("QAMD_DEBUG_TOPK")) {
             std::vector<uint32_t> cnt(b->q_pad * kCounterStride);
             (void)hipMemcpy(cnt.data(), counters.ptr, cnt.size() * 4, hipMemcpyDeviceToHost);

@@ -3,6 +3,7 @@
 u8 dot/L2/L1 scans, binary scan, PQ scan, top-k, random-access ids, encoders.
 Prints one JSON object per line."""
 import json
+import time
 import os
 import sys
 
@@ -74,7 +75,7 @@ if "u8" in which or "topk" in which or "ids" in which:
                     med, mn = timeit(lambda: enc.score_all(q, out=out))
                     report("u8_scan avx2-lane-order mode dim768", n, enc.scan_bytes_per_row(), med, mn)
             del enc, out
-            torch.cuda.empty_cache()
+            pass  # no empty_cache: returning tens of GB to the driver starts a VRAM scrub that slows (up to 4x) whatever runs next
 
 if "bin" in which:
     for dim, n in ((1024, 50_000_000), (1536, 30_000_000), (128, 100_000_000)):
@@ -88,7 +89,7 @@ if "bin" in which:
         med, mn = timeit(lambda: enc.score_all(q, out=out))
         report(f"bin_scan dim{dim}", n, nb, med, mn, note="bytes_per_row excludes the 4 B score write")
         del enc, out
-        torch.cuda.empty_cache()
+        pass  # no empty_cache: returning tens of GB to the driver starts a VRAM scrub that slows (up to 4x) whatever runs next
 
 if "pq" in which:
     for dim, chunk, n in ((768, 8, 10_000_000), (768, 4, 5_000_000), (128, 8, 20_000_000)):
@@ -105,7 +106,7 @@ if "pq" in which:
         med, mn = timeit(lambda: enc.encode_query(torch.rand(dim, device=dev), reuse=q), reps=10)
         report(f"pq_encode_query (LUT build) dim{dim} m{m}", 1, m * 1024, med, mn)
         del enc, out
-        torch.cuda.empty_cache()
+        pass  # no empty_cache: returning tens of GB to the driver starts a VRAM scrub that slows (up to 4x) whatever runs next
 
 if "encode" in which:
     n, dim = 2_000_000, 768
@@ -132,7 +133,9 @@ if "batch" in which:
         data = torch.rand((n, dim), device=dev)
         enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
         del data
-        torch.cuda.empty_cache()
+        pass  # no empty_cache: returning tens of GB to the driver starts a VRAM scrub that slows (up to 4x) whatever runs next
+        torch.cuda.synchronize()
+        time.sleep(3)  # let the driver finish clearing what the encode allocated / freed
         for nq in [int(x) for x in os.environ.get("BATCH_NQ", "4,8,16,32,64,256,1024").split(",")]:
             queries = torch.rand((nq, dim), device=dev)
             batch = enc.encode_query_batch(queries)
@@ -149,4 +152,4 @@ if "batch" in which:
                               "speedup_vs_single_query_loop_at_1.12ms": round(nq * 1.12 * (n / 1e7) * (dim / 768) / med, 1)}),
                   flush=True)
         del enc
-        torch.cuda.empty_cache()
+        pass  # no empty_cache: returning tens of GB to the driver starts a VRAM scrub that slows (up to 4x) whatever runs next

@@ -27,6 +27,9 @@ WAVES = int(os.environ.get("WAVES", 8))
 for _ in range(2):
     enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc)
 torch.cuda.synchronize()
+if os.environ.get("DBG"):
+    L.qamd_dev_gemm_debug.argtypes = [C.c_uint]
+    L.qamd_dev_gemm_debug(int(os.environ["DBG"]))
 stamps = torch.zeros(4096 * WAVES * 16, dtype=torch.int64, device=dev)
 assert L.qamd_dev_gemm_stamps(C.c_void_p(stamps.data_ptr())) == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,7 +44,7 @@ if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "p":
     # ping-pong kernel: persistent workgroups; slot 0 entry, 1 prologue done, 2..9 MFMAs of tile
     # 0..7 issued, 10 end of the last stamped epilogue, 12 exit
     blk = st[:256]
-    ok = (blk[:, :, 12] > 0).all(axis=1)
+    ok = (blk[:, :, 15] > 0).all(axis=1)
     blk = blk[ok]
     print("workgroups with stamps:", blk.shape[0])
     def dd(a, b):
@@ -49,11 +52,22 @@ if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "p":
         return f"{x.mean():9.0f} (p10 {np.percentile(x, 10):7.0f}, p90 {np.percentile(x, 90):7.0f})"
     n_slabs = (enc.metadata["actual_dim"] + 63) // 64
     print(f"K-tiles per tile: {n_slabs}; ideal MFMA cycles per tile: {n_slabs * 1024}")
-    print("entry -> prologue done          ", dd(0, 1))
-    print("tile 0 main loop                ", dd(1, 2))
-    for tix in range(1, 8):
-        print(f"tile {tix} period (epilogue {tix-1} + loop)", dd(1 + tix, 2 + tix))
-    print("whole workgroup                 ", dd(0, 12))
+    print("entry -> prologue done   ", dd(0, 1))
+    prev = 1
+    for tix in range(4):
+        print(f"tile {tix}: set-up          ", dd(prev, 2 + 3 * tix))
+        print(f"tile {tix}: K loop          ", dd(2 + 3 * tix, 3 + 3 * tix))
+        print(f"tile {tix}: epilogue        ", dd(3 + 3 * tix, 4 + 3 * tix))
+        prev = 4 + 3 * tix
+    print("whole workgroup          ", dd(0, 15))
+    hw = blk[:, :, 13]
+    simd = (hw >> 4) & 3
+    print("SIMD of waves 0..7, first workgroups:", [list(map(int, simd[i])) for i in range(4)])
+    same = sum(int(simd[i, w] == simd[i, w + 4]) for i in range(blk.shape[0]) for w in range(4))
+    print(f"wave w and w+4 on the same SIMD: {same} of {blk.shape[0] * 4}")
+    flagged = float(blk[:, :, 14].sum())
+    groups = nq / 4.0 * n  # (query group, row) pairs of the filter pass
+    print(f"groups sent to the exact epilogue: {flagged:.0f} of {groups:.3g} = {flagged / groups:.2e}")
     sys.exit(0)
 # the LAST launch that wrote stamps is the filter pass over the full store (the sample pass ran
 # first and was overwritten for the blocks both have).  Use blocks 1024.. (steady state).
