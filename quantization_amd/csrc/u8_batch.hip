@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
                 }
             }
         }
-        if (ti < 4) stamp(4 + 3 * (int)ti);  // epilogue done
+        if (ti < 3) stamp(4 + 3 * (int)ti);  // epilogue done (slot 13 is HW_ID)
         if (g == 1 && ti + 1 < my_tiles) PP_BARRIER();  // fall one slot behind again
     }
     stamp(15);

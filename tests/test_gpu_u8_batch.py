@@ -72,12 +72,15 @@ def test_topk_batch_small_store_uses_exact_single_query_path(largest):
 
 @pytest.mark.parametrize("k,largest", [(30, True), (200, False)])
 @pytest.mark.parametrize("dist,invert,lo", [(D.L2, False, 0.0), (D.Dot, False, 0.0), (D.Dot, True, 5.0), (D.L2, True, -3.0)])
-def test_topk_batch_fused_large_store(k, largest, dist, invert, lo):
-    """n >= 2^20: per-query pivots from the sampled sub-store, integer pre-filter folded into the
-    accumulators (both directions: multiplier > 0 and < 0), exact f32 test, per-query sort.
+@pytest.mark.parametrize("dim,nq", [(64, 150), (192, 300)])
+def test_topk_batch_fused_large_store(k, largest, dist, invert, lo, dim, nq):
+    """n >= 2^20: per-query pivots from the sampled sub-store, filter pass, per-query sort.
+    dim 64 (rows of one K-tile) runs u8_gemm_kernel; dim 192 runs the ping-pong kernel: integer
+    pre-filter folded into the accumulators in both directions (multiplier > 0 and < 0, largest
+    and smallest), wave-private candidate lists, padding queries in the second query tile.
     `lo` shifts the data so that offset != 0 and vector_offset varies a lot inside a tile."""
     rng = np.random.default_rng(7)
-    n, dim, nq = 1_300_000, 64, 150
+    n = 1_300_000 if dim == 64 else 1_100_000
     data = rng.random((n, dim), dtype=np.float32) + np.float32(lo)
     queries = rng.random((nq, dim), dtype=np.float32) + np.float32(lo)
     enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
@@ -87,6 +90,25 @@ def test_topk_batch_fused_large_store(k, largest, dist, invert, lo):
         order = np.lexsort((np.arange(n), -scores if largest else scores))[:k]
         assert np.array_equal(ids[qi], order.astype(np.uint32)), qi
         assert np.array_equal(sc[qi].view(np.uint32), scores[order].view(np.uint32))
+
+
+@pytest.mark.parametrize("largest", [True, False])
+@pytest.mark.parametrize("dist,invert", [(D.Dot, False), (D.L2, True)])
+def test_topk_batch_prefilter_survives_huge_offsets(largest, dist, invert):
+    """Data in [1000, 1001): alpha = 1/127 against |offset| = 1000, so scores are ~1e8 with an f32
+    spacing of 8 while one code step moves a score by ~8: the f32 epilogue's rounding is as large
+    as the quantity the integer pre-filter thresholds.  The pre-filter may only ever be too
+    permissive: the batch result must still equal the exact single-query top-k bit for bit."""
+    rng = np.random.default_rng(11)
+    n, dim, nq, k = 1_100_000, 192, 140, 40
+    data = rng.random((n, dim), dtype=np.float32) + np.float32(1000.0)
+    queries = rng.random((nq, dim), dtype=np.float32) + np.float32(1000.0)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
+    ids, sc = enc.topk_batch(enc.encode_query_batch(queries), k, largest=largest)
+    for qi in (0, 3, nq - 1):
+        want_ids, want_sc = enc.topk(enc.encode_query(queries[qi]), k, largest=largest)
+        assert np.array_equal(ids[qi], want_ids), qi
+        assert np.array_equal(sc[qi].view(np.uint32), want_sc.view(np.uint32)), qi
 
 
 @pytest.mark.parametrize("nq,dim", [(6, 64), (6, 768), (13, 256)])

@@ -57,7 +57,8 @@ if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "p":
     for tix in range(4):
         print(f"tile {tix}: set-up          ", dd(prev, 2 + 3 * tix))
         print(f"tile {tix}: K loop          ", dd(2 + 3 * tix, 3 + 3 * tix))
-        print(f"tile {tix}: epilogue        ", dd(3 + 3 * tix, 4 + 3 * tix))
+        if tix < 3:  # slot 13 holds HW_ID
+            print(f"tile {tix}: epilogue        ", dd(3 + 3 * tix, 4 + 3 * tix))
         prev = 4 + 3 * tix
     print("whole workgroup          ", dd(0, 15))
     hw = blk[:, :, 13]
