@@ -112,12 +112,21 @@ def cpu_baseline(qa, enc, data_sample, queries, gpu_scores_sample, dist_id):
 
     all_cores()
     tn = float(np.median([all_cores() for _ in range(10)]))
+    cpu_model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": S / t1, "unit": "vectors/s", "cores": 1, "kind": kind,
         "sample": f"first {S} rows of the same store, 1 query, median of {len(samples)} passes of the "
                   f"reference loop (encode_query + score_point per row, "
                   f"{'compiled reference impl_score_dot_avx' if use_ref else 'oracle restatement'}); "
-                  f"host has {cores} logical cores",
+                  f"host: {cpu_model}, {cores} logical cores",
         "all_cores": {"value": S / tn, "cores": nthreads},
         "gpu_matches_cpu_bits": parity,
     }
