@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queries", type=int, default=16)
+    ap.add_argument("--batch-queries", type=int, default=0,
+                    help="opt-in second workload (BASELINE config 4 shape): per step, top-k of this many queries "
+                         "at once over the shard on the matrix cores (u8 only), then one all-gather of "
+                         "world*Q*k pairs and a merge; the default 0 runs the headline single-query scan")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank code path, e.g. several ranks on one GPU)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
@@ -209,6 +213,61 @@ def main():
         bytes_per_row = m
         kernel_name = "pq_scan_fast_kernel"
     args.no_cpu_baseline = args.no_cpu_baseline or args.quantizer != "u8"
+
+    if args.batch_queries > 0:
+        if args.quantizer != "u8":
+            raise SystemExit("--batch-queries is the scalar-u8 multi-query path")
+        from quantization_amd.sharded import ShardedTopKBatch
+        Q, k = args.batch_queries, args.k
+        bq = torch.rand((Q, dim), generator=qgen, device=dev, dtype=torch.float32)
+        batch = enc.encode_query_batch(bq)
+        xchg = ShardedTopKBatch(dist, torch, Q, k, dev, rank, world, total_rows)
+        ids, sc = xchg.buffers()
+
+        def bstep():
+            enc.topk_batch(batch, k, largest=True, out_ids=ids, out_scores=sc)
+            return xchg.exchange(largest=True)
+
+        for _ in range(max(1, args.warmup)):
+            bstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            bstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                         device=dev if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if rank == 0:
+            ad = enc.metadata["actual_dim"]
+            ops = 2.0 * Q * n * ad  # per GPU and step
+            per_gpu_tops = ops * args.steps / elapsed / 1e12
+            print(json.dumps({
+                "metric": f"(query, vector) pairs scored/sec, {Q} queries x {n}x{dim} u8 dot per GPU, top-{k} each",
+                "value": float(Q) * total_rows * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
+                "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x u8 -> i32 (MFMA int8)",
+                "data": "synthetic",
+                "config": {"workload": f"{Q} queries x {n} x {dim} scalar-u8 rows per GPU, per step: topk_batch over the "
+                                       f"shard + all-gather of world*Q*k pairs + per-query merge (host)",
+                           "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows},
+                "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": 5000.0, "unit": "TFLOP/s",
+                             "frac": per_gpu_tops / 5000.0, "traffic": None,
+                             "note": "int8 op/s per GPU over the whole step (sample pass, filter GEMM, scatter, "
+                                     "sort, exchange); algorithmic ops = 2 * actual_dim per (query, row) pair"},
+            }), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     qobj = enc.encode_query(queries[0])
     gather = topk = None

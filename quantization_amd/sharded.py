@@ -154,3 +154,50 @@ class ShardedTopK:
         ids = host[:, : self.k].view(np.uint32)
         sc = host[:, self.k:].view(np.float32)
         return merge_topk(ids, sc, self.bases, self.k, largest)
+
+
+class ShardedTopKBatch:
+    """Batched form of ShardedTopK (BASELINE config 4: many queries, top-k each, rows sharded):
+    every rank runs `topk_batch` over its shard into `buffers()`, one all-gather moves
+    world * n_queries * k (id, score) pairs, and each query's lists are merged with the
+    single-GPU tie rule."""
+
+    def __init__(self, dist, torch, n_queries: int, k: int, device, rank: int, world: int, count: int, group=None):
+        self.dist, self.torch, self.k, self.nq = dist, torch, k, n_queries
+        self.rank, self.world, self.group = rank, world, group
+        self.bases = [shard_range(count, r, world)[0] for r in range(world)]
+        # [2][n_queries][k] int32 bit patterns: plane 0 ids, plane 1 scores
+        self.pack = torch.empty((2, n_queries, k), dtype=torch.int32, device=device)
+        self.all = torch.empty((world, 2, n_queries, k), dtype=torch.int32, device=device)
+
+    def buffers(self):
+        """(ids [n_queries*k], scores [n_queries*k]) device views for the local topk_batch."""
+        return self.pack[0].view(-1), self.pack[1].view(-1).view(self.torch.float32)
+
+    def exchange(self, largest: bool = True):
+        if self.world == 1:
+            self.all[0].copy_(self.pack)
+        elif _needs_host_staging(self.dist, self.pack):
+            hp = self.pack.cpu()
+            ha = self.torch.empty(self.all.shape, dtype=self.torch.int32)
+            self.dist.all_gather_into_tensor(ha.view(-1), hp.view(-1), group=self.group)
+            self.all.copy_(ha)
+        else:
+            self.dist.all_gather_into_tensor(self.all.view(-1), self.pack.view(-1), group=self.group)
+        host = self.all.cpu().numpy()
+        ids = host[:, 0].view(np.uint32)   # [world, nq, k]
+        sc = host[:, 1].view(np.float32)
+        # all queries at once: [nq, world*k] candidates per query, one lexsort along the rows
+        valid = (ids != 0xFFFFFFFF).transpose(1, 0, 2).reshape(self.nq, -1)
+        gids = (ids.astype(np.int64) + np.asarray(self.bases, dtype=np.int64)[:, None, None])
+        gids = gids.transpose(1, 0, 2).reshape(self.nq, -1)
+        s2 = sc.transpose(1, 0, 2).reshape(self.nq, -1)
+        key = np.where(valid, -s2 if largest else s2, np.inf).astype(np.float64)  # padding sorts last
+        gkey = np.where(valid, gids, np.iinfo(np.int64).max)
+        order = np.lexsort((gkey, key), axis=1)[:, : self.k]
+        out_ids = np.take_along_axis(gids, order, axis=1).astype(np.uint32)
+        out_sc = np.take_along_axis(s2, order, axis=1).astype(np.float32)
+        ok = np.take_along_axis(valid, order, axis=1)
+        out_ids[~ok] = 0xFFFFFFFF
+        out_sc[~ok] = -np.inf if largest else np.inf
+        return out_ids, out_sc

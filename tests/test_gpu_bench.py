@@ -49,3 +49,22 @@ def test_bench_two_ranks_one_gpu_gloo_rehearsal(exchange):
     j = _last_json(res.stdout)
     assert j["n_gpus"] == 2 and j["config"]["total_rows"] == 400000 and j["scaling"] == "weak"
     assert "cpu_baseline" not in j
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_batched_topk_mode(ranks):
+    """The opt-in config-4 shape: many queries per step on the matrix cores, sharded rows, one
+    all-gather of world*Q*k pairs (two ranks rehearsed on one GPU over gloo)."""
+    base = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--rows-per-gpu",
+            "1200000", "--dim", "192", "--batch-queries", "200", "--k", "10"]
+    if ranks == 1:
+        cmd = [sys.executable] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29534"] + base + ["--backend", "gloo", "--all-ranks-on-device", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["n_gpus"] == ranks and j["unit"] == "pairs/s" and j["value"] > 0
+    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    assert j["config"]["total_rows"] == 1200000 * ranks

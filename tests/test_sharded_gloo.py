@@ -25,8 +25,8 @@ def _worker(rank, world, port, n, dim, tmp):
     import torch.distributed as dist
 
     from oracle import qoracle as qo
-    from quantization_amd.sharded import (ScoreGather, ShardedTopK, assemble_global_scores, max_shard_rows,
-                                          shard_range)
+    from quantization_amd.sharded import (ScoreGather, ShardedTopK, ShardedTopKBatch, assemble_global_scores,
+                                          max_shard_rows, shard_range)
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -63,6 +63,27 @@ def _worker(rank, world, port, n, dim, tmp):
         assert np.array_equal(merged_ids, worder.astype(np.uint32)), "merged top-k ids differ"
         assert np.array_equal(merged_sc, want[worder])
         results.append(True)
+    # batched exchange: all three queries at once, k = 7 (some shards hold fewer than k rows when n is tiny)
+    kb = 7
+    batch = ShardedTopKBatch(dist, torch, len(queries), kb, "cpu", rank, world, n)
+    bids, bsc = batch.buffers()
+    wants = []
+    for qi, q in enumerate(queries):
+        codes, qoff = qo.u8_encode_query(meta, q)
+        local = qo.u8_score_all(meta, rows, codes, qoff)
+        order = np.lexsort((np.arange(local.size), -local))[:kb]
+        ids_q = np.full(kb, -1, dtype=np.int32)  # 0xFFFFFFFF padding
+        sc_q = np.full(kb, -np.inf, dtype=np.float32)
+        ids_q[: order.size] = order
+        sc_q[: order.size] = local[order]
+        bids[qi * kb:(qi + 1) * kb] = torch.from_numpy(ids_q)
+        bsc[qi * kb:(qi + 1) * kb] = torch.from_numpy(sc_q)
+        wants.append(qo.u8_score_all(g_meta, g_rows, codes, qoff))
+    mids, msc = batch.exchange(largest=True)
+    for qi, want in enumerate(wants):
+        worder = np.lexsort((np.arange(n), -want))[:kb]
+        assert np.array_equal(mids[qi][: worder.size], worder.astype(np.uint32)), "batched merged ids differ"
+        assert np.array_equal(msc[qi][: worder.size], want[worder])
     gather.drain()
     dist.barrier()
     dist.destroy_process_group()
