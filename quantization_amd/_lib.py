@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libquantization_amd.so")
+LIB_PATH = os.environ.get("QAMD_LIB_PATH") or os.path.join(HERE, "libquantization_amd.so")  # env: developer A/B of two builds
 CSRC = os.path.join(HERE, "csrc")
 
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 //        issued in slots 4u+2 / 4u+3; the last reads of K-tile u-1's A were issued in slot 4u-1
 //        and waited for in slot 4u.
 // Measured alternatives (in-kernel timeline, tools/gemm_timeline.py): DMA issued inside the MFMA
-// slot: K loop +10 %; one 16-MFMA slot per K-tile and group (half the barriers): K loop +5..15 %.
+// slot: K loop +10 %; one 16-MFMA slot per K-tile and group (half the barriers): K loop +5..15 %
+// (and the 128-query tile, 8 MFMAs per K-tile in one slot: 2.14-2.59 ms vs 1.87-2.08 for 4..128 queries).
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
 constexpr int PP_KT = 64;                      // K-tile bytes per row
@@ -298,10 +299,12 @@ __device__ __forceinline__ void pp_glds16(const uint8_t *src, uint8_t *lds_dst) 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
-__device__ __forceinline__ void pp_wait_vm(uint32_t n) {  // n is wave-uniform, one of 0 2 4 6 8
+__device__ __forceinline__ void pp_wait_vm(uint32_t n) {  // n is wave-uniform; rounded DOWN to a supported count
     if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -330,7 +333,10 @@ __device__ __forceinline__ int pp_bound(float num /* pivot - q_off, or -v_off */
     return (int)t;
 }
 
-template <int MODE, bool LOW>
+// MI = 32-query fragments per wave: 4 -> workgroup tile of 256 queries (the shape described above),
+// 2 -> 128 queries for batches of up to 128 (each wave 64 x 64, 4 MFMAs per phase: that shape is
+// bound by the HBM read of the store, which it streams exactly once).
+template <int MODE, bool LOW, int MI>
 __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restrict__ codes,
                                                         const float *__restrict__ v_offsets,
                                                         const uint8_t *__restrict__ qcodes, uint32_t q_pitch,
@@ -346,7 +352,11 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
     if (j >= row_lanes * q_tiles) return;
     const uint32_t q_tile = j % q_tiles, row_lane = j / q_tiles;
-    const uint32_t q0 = q_tile * 256;
+    constexpr int TQH = MI * 32;   // queries per wave group
+    constexpr int TQW = 2 * TQH;   // queries per workgroup
+    constexpr int HALF = MI / 2;   // query fragments per phase
+    constexpr uint32_t GA = MI == 4 ? 2 : 1;  // DMA instructions per wave for a K-tile's query operand
+    const uint32_t q0 = q_tile * TQW;
     const uint32_t n_rtiles = (n_rows + 255) / 256;
     const uint32_t first = xcd + 8 * row_lane, step = 8 * row_lanes;
     if (first >= n_rtiles) return;
@@ -368,9 +378,10 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     float *pivot_s = q_off_s + 256;                                                   // [256]
     int *bq_s = reinterpret_cast<int *>(pivot_s + 256);                               // [256] integer query bounds
     uint32_t *wcount_s = reinterpret_cast<uint32_t *>(bq_s + 256) + wave;             // this wave's append counter
+    // (arrays sized for the 256-query tile; the 128-query tile uses their first halves)
     if (MODE != 0 && lane == 0) *wcount_s = 0;
     constexpr bool LARGEST = MODE == 1;
-    if (t < 256) {
+    if (t < TQW) {
         const float qo = q_offsets[q0 + t];
         q_off_s[t] = qo;
         if (MODE != 0) {
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
         uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + PP_UNIT + wave * 1024;
         if (!(dbgf & 1u)) {
             pp_glds16(src, dst);
-            pp_glds16(src + (uint64_t)128 * q_pitch, dst + 128 * PP_KT);
+            if (MI == 4) pp_glds16(src + (uint64_t)128 * q_pitch, dst + 128 * PP_KT);
         }
         pf_u++;
         if (++pf_kt == nkt) {
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     // fragment read offsets: chunk 2*ks + h of row r (+ multiples of 16 rows), swizzled
     const uint32_t swz = ((uint32_t)r >> 2) & 3u;
     const uint32_t off0 = (((uint32_t)h) ^ swz) * 16, off1 = ((2u + (uint32_t)h) ^ swz) * 16;
-    const uint32_t fragA = PP_UNIT + (g * 128 + r) * PP_KT, fragB = (wr * 64 + r) * PP_KT;
+    const uint32_t fragA = PP_UNIT + (g * TQH + r) * PP_KT, fragB = (wr * 64 + r) * PP_KT;
 
     // v_offset of this lane's two rows (jj = 0, 1) for the tile about to start.  Loaded one tile
     // ahead by inline asm so that the compiler attaches no wait to it (next to LDS-DMA it would
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
             issue_B();
             issue_A();
         }
-    pp_wait_vm((total > 1 ? 4u : 0u) + (total > 2 ? 4u : 0u));
+    pp_wait_vm((total > 1 ? 2u + GA : 0u) + (total > 2 ? 2u + GA : 0u));
     PP_BARRIER();
     stamp(1);
     if (g == 1) PP_BARRIER();  // group 1 runs one slot behind
@@ -446,12 +457,12 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
     uint32_t tile = first, u = 0;
     for (uint32_t ti = 0; ti < my_tiles; ti++, tile += step) {
-    v16i acc[4][2];
+    v16i acc[MI][2];
     float vo_cur0 = 0.0f, vo_cur1 = 0.0f;
     int br0 = 0, br1 = 0;
     if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int jj = 0; jj < 2; jj++)
 #pragma unroll
@@ -465,10 +476,10 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
         br0 = row_a < n_rows ? pp_bound<LOW>(-vo_cur0, fabsf(vo_cur0), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
         br1 = row_a + 32 < n_rows ? pp_bound<LOW>(-vo_cur1, fabsf(vo_cur1), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
-                const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + g * 128 + i * 32 + 8 * gq + 4 * h);
+                const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + g * TQH + i * 32 + 8 * gq + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     acc[i][0][4 * gq + e] = -(bq4[e] + br0);
@@ -480,15 +491,15 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     for (uint32_t kt = 0; kt < nkt; kt++, u++) {
         const uint8_t *slot = lds_raw + (u & 3u) * PP_SLOT;
         const uint8_t *pA = slot + fragA, *pB = slot + fragB;
-        // ---- phase 0: query fragments 0,1 and both row fragments
-        v4i a[2][2], bf[2][2];
+        // ---- phase 0: the first half of the query fragments and both row fragments
+        v4i a[HALF][2], bf[2][2];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             bf[i][0] = *reinterpret_cast<const v4i *>(pB + i * 32 * PP_KT + off0);
             bf[i][1] = *reinterpret_cast<const v4i *>(pB + i * 32 * PP_KT + off1);
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < HALF; i++) {
             a[i][0] = *reinterpret_cast<const v4i *>(pA + i * 32 * PP_KT + off0);
             a[i][1] = *reinterpret_cast<const v4i *>(pA + i * 32 * PP_KT + off1);
         }
@@ -499,18 +510,18 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < HALF; i++)
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++)
                     acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ks], bf[jj][ks], acc[i][jj], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        pp_wait_vm((u + 2 < total ? 4u : 0u) + (more ? 2u : 0u));  // retires K-tile u+1
+        pp_wait_vm((u + 2 < total ? 2u + GA : 0u) + (more ? 2u : 0u));  // retires K-tile u+1
         PP_BARRIER();
-        // ---- phase 1: query fragments 2,3 against the row fragments already in registers
+        // ---- phase 1: the other query fragments against the row fragments already in registers
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            a[i][0] = *reinterpret_cast<const v4i *>(pA + (2 + i) * 32 * PP_KT + off0);
-            a[i][1] = *reinterpret_cast<const v4i *>(pA + (2 + i) * 32 * PP_KT + off1);
+        for (int i = 0; i < HALF; i++) {
+            a[i][0] = *reinterpret_cast<const v4i *>(pA + (HALF + i) * 32 * PP_KT + off0);
+            a[i][1] = *reinterpret_cast<const v4i *>(pA + (HALF + i) * 32 * PP_KT + off1);
         }
         if (more) issue_A();
         PP_BARRIER();
@@ -518,10 +529,10 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < HALF; i++)
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++)
-                    acc[2 + i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ks], bf[jj][ks], acc[2 + i][jj], 0, 0, 0);
+                    acc[HALF + i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ks], bf[jj][ks], acc[HALF + i][jj], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_BARRIER();
     }
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
             else v_off = row_ok ? (jj ? vo_cur1 : vo_cur0) : never;
             const int br = jj ? br1 : br0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < MI; i++) {
                 if (MODE == 0) __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time: no load clustering
                 if (MODE != 0) {
                     // two-level test: one sign test for the whole 32 x 32 accumulator tile first (about
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
                 }
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {  // registers 4gq .. 4gq+3 are four consecutive queries
-                    const uint32_t ql = g_e * 128 + i * 32 + 8 * gq + 4 * h_e;
+                    const uint32_t ql = g_e * TQH + i * 32 + 8 * gq + 4 * h_e;
                     if (MODE == 0) {
                         const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
                         const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
@@ -782,35 +793,36 @@ qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, cons
 
 inline uint32_t pp_waves_per_launch() { return (uint32_t)std::max(1, device_info().cu_count / 8) * 8 * 8; }
 inline uint32_t pp_launches(uint64_t n_queries) {
-    const uint64_t per = (uint64_t)std::max(1, device_info().cu_count / 8) * 256;
+    const uint64_t per = (uint64_t)std::max(1, device_info().cu_count / 8) * (n_queries <= 128 ? 128 : 256);
     return (uint32_t)((n_queries + per - 1) / per);
 }
 
 // Ping-pong kernel launch: one persistent workgroup per CU; at most 32 query tiles per launch
 // (8192 queries), larger batches go in slices of 8192.
-template <int MODE, bool LOW>
+template <int MODE, bool LOW, int MI>
 qamd_status launch_gemm_pp_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW, MI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
     });
+    constexpr uint64_t TQW = 64 * MI;  // queries per workgroup tile
     const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
-    const uint64_t all_q_tiles = (b->n_queries + 255) / 256;
+    const uint64_t all_q_tiles = (b->n_queries + TQW - 1) / TQW;
     for (uint64_t qt0 = 0; qt0 < all_q_tiles; qt0 += cus_per_xcd) {
         const uint32_t q_tiles = (uint32_t)std::min<uint64_t>(cus_per_xcd, all_q_tiles - qt0);
         const uint32_t row_lanes = cus_per_xcd / q_tiles;
-        const uint64_t q_base = qt0 * 256;
+        const uint64_t q_base = qt0 * TQW;
         BatchFilter f = filt;
         if (MODE != 0) {
             f.pivot_scores += q_base;
             f.query_base = (uint32_t)q_base;
             f.wave_base = (uint32_t)(qt0 / cus_per_xcd) * pp_waves_per_launch();
         }
-        hipLaunchKernelGGL((u8_gemm_pp_kernel<MODE, LOW>), dim3(8 * row_lanes * q_tiles), dim3(512), PP_LDS, s, codes,
-                           v_offsets, b->codes.as<uint8_t>() + q_base * b->pitch, (uint32_t)b->pitch,
+        hipLaunchKernelGGL((u8_gemm_pp_kernel<MODE, LOW, MI>), dim3(8 * row_lanes * q_tiles), dim3(512), PP_LDS, s,
+                           codes, v_offsets, b->codes.as<uint8_t>() + q_base * b->pitch, (uint32_t)b->pitch,
                            b->offsets.as<float>() + q_base, h->meta.multiplier, (uint32_t)n_rows,
                            (uint32_t)(b->n_queries - q_base), (uint32_t)h->meta.actual_dim, q_tiles, row_lanes,
                            MODE == 0 ? out + q_base * out_pitch : out, out_pitch, f);
@@ -823,17 +835,23 @@ template <int MODE>
 qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
-    if (MODE == 0) return launch_gemm_pp_cfg<0, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    const bool small = b->n_queries <= 128;  // 128-query tile: the store is streamed once, HBM-bound
+    if (MODE == 0)
+        return small ? launch_gemm_pp_cfg<0, false, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
+                     : launch_gemm_pp_cfg<0, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     // "may pass" is s <= bound when the score falls with s (multiplier < 0) xor smallest-first
+    constexpr int M = MODE == 0 ? 1 : MODE;
     const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
-    if (low) return launch_gemm_pp_cfg<(MODE == 0 ? 1 : MODE), true>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
-    return launch_gemm_pp_cfg<(MODE == 0 ? 1 : MODE), false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    if (small)
+        return low ? launch_gemm_pp_cfg<M, true, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
+                   : launch_gemm_pp_cfg<M, false, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    return low ? launch_gemm_pp_cfg<M, true, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
+               : launch_gemm_pp_cfg<M, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
 }
 
-// Which kernel serves a batch: the ping-pong kernel for more than 128 queries (rows of at least
-// three 64-byte K-tiles, a usable multiplier for its integer pre-filter), else u8_gemm_kernel.
+// Which kernel serves a batch: the ping-pong kernel (rows of at least three 64-byte K-tiles, a
+// usable multiplier for its integer pre-filter), else u8_gemm_kernel.
 bool pp_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
-    if (b->n_queries <= 128) return false;
     static const char *cfg = getenv("QAMD_GEMM_CFG");  // developer A/B switch: 0/3/4/5 = u8_gemm_kernel shapes
     if (cfg && cfg[0] != 'p') return false;
     const float m = h->meta.multiplier;
@@ -947,8 +965,13 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     QAMD_TRY(ensure_device(h->device));
     hipStream_t s = as_stream(stream);
     const uint64_t Q = b->n_queries, n = h->count;
-    const uint32_t S = kTopkSample;
+    // Pivot rank r of S sampled rows: the number of rows at least as good as the pivot is about
+    // n*Beta(r, S-r+1): mean n*r/S = target, relative spread 1/sqrt(r).  With many queries per call the
+    // tails matter (a list that overflows kBatchCap or holds fewer than k sends its query to the
+    // exact single-query path, milliseconds each): S grows with n so that r stays near 16
+    // (r = 4 at 10M rows overflowed 8192 slots about once per 1600 queries: 0.6 per 1024-query call).
     const double target = std::max<double>(2048.0, 3.0 * k);
+    const uint32_t S = (uint32_t)std::min<double>(262144.0, std::max<double>(kTopkSample, round_up((uint64_t)(16.0 * (double)n / target), 256)));
     const uint32_t r = n ? (uint32_t)std::ceil((double)S * target / (double)n) : 0;
     const bool fused = n >= (1u << 20) && r <= 64;
 
