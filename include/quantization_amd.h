@@ -156,7 +156,8 @@ QAMD_API void qamd_u8_free(qamd_u8 *h);
  * queries, demos/src/ann_benchmark.rs:245-260, with its per-query 30-entry heap,
  * demos/src/ann_benchmark_data.rs:151-167).  On the GPU this is a dense u8 x u8 -> i32
  * contraction on the matrix cores; every score is bit-identical to qamd_u8_score_all for the
- * same query.  Dot and L2 only (the reference's dot kernel, encoded_vectors_u8.rs:339-341). */
+ * same query.  Dot and L2 run the reference's dot kernel (encoded_vectors_u8.rs:339-341) as that
+ * contraction; L1 (sum |q - v|, no matrix form) is served by the single-query kernel per query. */
 typedef struct qamd_u8_query_batch qamd_u8_query_batch; /* n x EncodedQueryU8 */
 /* queries: n_queries x qdim f32, row-major.  *batch_io is created when NULL, else re-used. */
 QAMD_API qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries,

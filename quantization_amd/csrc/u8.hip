@@ -1372,6 +1372,20 @@ qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const flo
     return st;
 }
 
+// score_all for one member of a query batch (the L1 route of the batch API: L1 has no MFMA form).
+qamd_status u8_score_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, float *out_dev,
+                            hipStream_t stream) {
+    qamd_u8_query q;
+    q.device = h->device;
+    q.actual_dim = h->meta.actual_dim;
+    QAMD_TRY(q.buf.alloc(16 + q.actual_dim + 16, true));
+    QAMD_HIP(hipMemcpyAsync(q.buf.ptr, offset_dev, 4, hipMemcpyDeviceToDevice, stream));
+    QAMD_HIP(hipMemcpyAsync(q.buf.as<uint8_t>() + 16, codes_dev, q.actual_dim, hipMemcpyDeviceToDevice, stream));
+    qamd_status st = qamd_u8_score_all(h, &q, out_dev, QAMD_MEM_DEVICE, stream);
+    QAMD_HIP(hipStreamSynchronize(stream));  // q.buf is freed on return
+    return st;
+}
+
 }  // namespace qamd
 
 // Developer-only accessors for the tuning harness (tune.hip); not part of include/.

@@ -763,8 +763,6 @@ qamd_status check_batch(const qamd_u8 *h, const qamd_u8_query_batch *b) {
     if (b->actual_dim != h->meta.actual_dim)
         return fail(QAMD_ERR_ARGUMENTS, "queries have %llu codes, store rows have %llu",
                     (unsigned long long)b->actual_dim, (unsigned long long)h->meta.actual_dim);
-    if (h->meta.vector_parameters.distance_type == QAMD_L1)
-        return fail(QAMD_ERR_ARGUMENTS, "the multi-query path covers Dot and L2 (the dot kernel); L1 has no MFMA form");
     return QAMD_OK;
 }
 
@@ -950,8 +948,15 @@ qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, 
         QAMD_TRY(tmp.alloc(total * 4));
         out_dev = tmp.as<float>();
     }
-    QAMD_TRY(launch_gemm<0>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), h->count, out_dev, h->count,
-                            BatchFilter{}, s));
+    if (h->meta.vector_parameters.distance_type == QAMD_L1) {
+        // sum |q - v| is not a contraction: no MFMA form; the batch API loops the single-query scan
+        for (uint64_t q = 0; q < b->n_queries; q++)
+            QAMD_TRY(u8_score_single(h, b->codes.as<uint8_t>() + q * b->pitch, b->offsets.as<float>() + q,
+                                     out_dev + q * h->count, s));
+    } else {
+        QAMD_TRY(launch_gemm<0>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), h->count, out_dev, h->count,
+                                BatchFilter{}, s));
+    }
     if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, total * 4, s));
     return QAMD_OK;
 }
@@ -973,7 +978,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     const double target = std::max<double>(2048.0, 3.0 * k);
     const uint32_t S = (uint32_t)std::min<double>(262144.0, std::max<double>(kTopkSample, round_up((uint64_t)(16.0 * (double)n / target), 256)));
     const uint32_t r = n ? (uint32_t)std::ceil((double)S * target / (double)n) : 0;
-    const bool fused = n >= (1u << 20) && r <= 64;
+    const bool fused = n >= (1u << 20) && r <= 64 && h->meta.vector_parameters.distance_type != QAMD_L1;
 
     StreamBuf ids_tmp, sc_tmp;
     uint32_t *ids_dev = out_ids;

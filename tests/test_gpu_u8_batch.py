@@ -34,12 +34,22 @@ def test_score_batch_equals_single_query_and_oracle(qo, n, dim, nq, dist, invert
     assert_bits_equal(got[: single.shape[0]], single, "batch vs single-query path")
 
 
-def test_batch_l1_is_rejected():
-    data = np.zeros((10, 16), dtype=np.float32)
-    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(16, 10, D.L1, False))
-    b = enc.encode_query_batch(data[:2])
-    with pytest.raises(qa.EncodingError):
-        enc.score_batch(b)
+def test_batch_l1_runs_the_single_query_kernel():
+    """sum |q - v| is not a contraction (no MFMA form): the batch API serves L1 by looping the
+    single-query scan / top-k, so the results are those, bit for bit."""
+    rng = np.random.default_rng(3)
+    n, dim, nq, k = 3000, 80, 5, 12
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L1, False))
+    b = enc.encode_query_batch(queries)
+    got = enc.score_batch(b)
+    ids, sc = enc.topk_batch(b, k, largest=False)
+    for qi in range(nq):
+        qobj = enc.encode_query(queries[qi])
+        assert_bits_equal(got[qi], enc.score_all(qobj), f"L1 scores of query {qi}")
+        want_ids, want_sc = enc.topk(qobj, k, largest=False)
+        assert np.array_equal(ids[qi], want_ids) and np.array_equal(sc[qi].view(np.uint32), want_sc.view(np.uint32))
 
 
 def test_device_queries_and_outputs(qo):
