@@ -399,26 +399,33 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     // lane writes LDS (row, position lane%4) and fetches chunk (lane%4) ^ ((row>>2)&3).
     const uint32_t dma_row = wave * 16 + (lane >> 2);
     const uint32_t dma_chunk = (((uint32_t)lane & 3u) ^ ((uint32_t)lane >> 4)) * 16;
-    uint32_t pf_tile = first, pf_kt = 0, pf_u = 0;
+    // per-lane source pointers kept across the loop and advanced by wave-uniform amounts (one
+    // 64-bit add per DMA instruction in the read slot instead of a 64-bit multiply-add chain)
+    const uint8_t *src_a0 = qcodes + ((uint64_t)q0 + dma_row) * q_pitch + dma_chunk;
+    const uint8_t *src_b = codes + ((uint64_t)first * 256 + dma_row) * ad + dma_chunk;
+    const uint64_t tile_stride_b = (uint64_t)step * 256 * ad, half_b = (uint64_t)128 * ad, half_a = (uint64_t)128 * q_pitch;
+    uint32_t pf_kt = 0, pf_koff = 0, pf_u = 0;
     const uint32_t dbgf = g_gemm_dbg;
     auto issue_B = [&]() {
-        const uint8_t *src = codes + ((uint64_t)pf_tile * 256 + dma_row) * ad + pf_kt * PP_KT + dma_chunk;
+        const uint8_t *src = src_b + pf_koff;
         uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + wave * 1024;
         if (dbgf & 2u) return;
         pp_glds16(src, dst);
-        pp_glds16(src + (uint64_t)128 * ad, dst + 128 * PP_KT);
+        pp_glds16(src + half_b, dst + 128 * PP_KT);
     };
     auto issue_A = [&]() {  // second half of a K-tile's DMA: advances the prefetch position
-        const uint8_t *src = qcodes + ((uint64_t)q0 + dma_row) * q_pitch + pf_kt * PP_KT + dma_chunk;
+        const uint8_t *src = src_a0 + pf_koff;
         uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + PP_UNIT + wave * 1024;
         if (!(dbgf & 1u)) {
             pp_glds16(src, dst);
-            if (MI == 4) pp_glds16(src + (uint64_t)128 * q_pitch, dst + 128 * PP_KT);
+            if (MI == 4) pp_glds16(src + half_a, dst + 128 * PP_KT);
         }
         pf_u++;
+        pf_koff += PP_KT;
         if (++pf_kt == nkt) {
             pf_kt = 0;
-            pf_tile += step;
+            pf_koff = 0;
+            src_b += tile_stride_b;
         }
     };
     // fragment read offsets: chunk 2*ks + h of row r (+ multiples of 16 rows), swizzled
