@@ -13,6 +13,8 @@ D = qa.DistanceType
 
 @pytest.mark.parametrize("n,dim,nq", [(1000, 768, 5), (300, 65, 130), (5000, 1536, 64), (129, 16, 3),
                                       (700, 100, 257), (64, 2048, 2), (2500, 128, 1),
+                                      # ping-pong kernel, 256-query tile: partial row tiles, two query tiles
+                                      (600, 200, 300), (100, 256, 130), (1025, 144, 513),
                                       # small batches (padded to one 128-query MFMA tile)
                                       (3000, 256, 9), (500, 1024, 16), (800, 1536, 7), (400, 512, 12),
                                       (2000, 768, 16), (777, 768, 1), (900, 2048, 5)])
