@@ -917,6 +917,27 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
     }
     const uint64_t dim = vp->dim, count = vp->count;
 
+    // Host rows: both passes (min/max, quantize) need every value, so when the f32 data fits in
+    // a quarter of the free HBM it is uploaded ONCE into a scratch copy and encoded from there
+    // (the PCIe transfer is the whole cost of a host-side encode); larger inputs are staged
+    // twice, 256 MiB at a time.  With alpha_offset given there is only one pass anyway.
+    StreamBuf whole;  // from the stream-ordered pool: a fresh hipMalloc of 6 GB costs as much as its upload
+    if (data_mem == QAMD_MEM_HOST && !alpha_offset) {
+        size_t free_b = 0, total_b = 0;
+        const uint64_t bytes = count * dim * sizeof(float);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= free_b / 4) {
+            QAMD_TRY(whole.alloc(bytes, s));
+            const uint64_t piece = 256ull << 20;
+            for (uint64_t off = 0; off < bytes; off += piece) {
+                if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
+                QAMD_TRY(copy_in(static_cast<char *>(whole.ptr) + off, reinterpret_cast<const char *>(data) + off,
+                                 QAMD_MEM_HOST, std::min<uint64_t>(piece, bytes - off), s));
+            }
+            data = whole.as<float>();
+            data_mem = QAMD_MEM_DEVICE;
+        }
+    }
+
     // Source rows: device-resident rows are processed in place (large batches: the stop
     // callback is polled between them), host rows are staged in bounded 256 MiB batches.
     const uint64_t batch_bytes = data_mem == QAMD_MEM_HOST ? (256ull << 20) : (8ull << 30);
