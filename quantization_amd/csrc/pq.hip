@@ -411,37 +411,32 @@ __global__ __launch_bounds__(kBlock) void pq_restride_kernel(const uint8_t *__re
 // ------------------------------------------------------------------------------ k-means (kmeans.rs)
 // All chunks iterate in lockstep; a converged chunk (done[c] != 0) is frozen.
 // sample: [S][dim]; cen: [256][dim] (centroid-major, like Metadata.centroids).
-__global__ __launch_bounds__(kBlock) void km_assign_accumulate_kernel(
+__global__ __launch_bounds__(kBlock) void km_accumulate_kernel(
     const float *__restrict__ sample, uint32_t S, uint32_t dim, uint32_t chunk_size, uint32_t m,
-    const float *__restrict__ cen, const int *__restrict__ done, double *__restrict__ acc /*[256][dim]*/,
+    const uint8_t *__restrict__ assign /*[S][m]*/, const int *__restrict__ done, double *__restrict__ acc /*[256][dim]*/,
     uint32_t *__restrict__ cnt /*[m][256]*/) {
-    extern __shared__ __attribute__((aligned(16))) float cen_s[];
+    // update_centroids, kmeans.rs:49-100 (f64 sums); the assignment (update_indexes, :139-166) is
+    // the PQ encoder's nearest-centroid kernel, run on the sample with the current centroids
     const uint32_t c = blockIdx.y;
     if (done[c]) return;
-    const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
-    for (uint32_t i = threadIdx.x; i < kCentroids * len; i += kBlock) {
-        const uint32_t kc = i / len, j = i - kc * len;
-        cen_s[kc * chunk_size + j] = cen[(size_t)kc * dim + lo + j];
-    }
-    __syncthreads();
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= S) return;
+    const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
+    const uint32_t min_i = assign[(size_t)s * m + c];
     const float *src = sample + (size_t)s * dim + lo;
-    float min_d = 3.40282347e+38f;
-    uint32_t min_i = 0;
-    for (uint32_t kc = 0; kc < (uint32_t)kCentroids; kc++) {  // update_indexes, kmeans.rs:139-166
-        float d = 0.0f;
-        for (uint32_t j = 0; j < len; j++) {
-            const float t = src[j] - cen_s[kc * chunk_size + j];
-            d += t * t;
-        }
-        if (d < min_d) {
-            min_d = d;
-            min_i = kc;
-        }
-    }
-    atomicAdd(&cnt[c * kCentroids + min_i], 1u);  // update_centroids, kmeans.rs:49-100 (f64 sums)
+    atomicAdd(&cnt[c * kCentroids + min_i], 1u);
     for (uint32_t j = 0; j < len; j++) atomicAdd(&acc[(size_t)min_i * dim + lo + j], (double)src[j]);
+}
+
+// The k-means sample: n_out evenly strided rows of a device-resident [count][dim] array.
+__global__ __launch_bounds__(kBlock) void km_gather_rows_kernel(const float *__restrict__ data, uint64_t count,
+                                                               uint32_t dim, uint64_t n_out, float *__restrict__ out) {
+    const uint64_t total = n_out * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t k = i / dim, j = i - k * dim;
+        const uint64_t r = (uint64_t)((unsigned __int128)k * count / n_out);
+        out[i] = data[r * dim + j];
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void km_finalize_kernel(const float *__restrict__ sample, uint32_t S,
@@ -613,6 +608,60 @@ qamd_status check_query(const qamd_pq *h, const qamd_pq_query *q) {
     return QAMD_OK;
 }
 
+// Nearest-centroid codes of `nr` device-resident rows: rows_out[(r0 + r) * row_stride + c].
+// `pair_table` (built by build_pair_table from the same centroids) selects the scalar-path kernel.
+bool cs_fast_shape(uint64_t dim, uint64_t chunk_size) {
+    return dim % chunk_size == 0 && (chunk_size == 1 || chunk_size == 2 || chunk_size == 4 || chunk_size == 8 ||
+                                     chunk_size == 16 || chunk_size == 32);
+}
+
+qamd_status build_pair_table(const float *centroids_dev, uint64_t dim, uint64_t chunk_size, uint64_t m, DevBuf &table,
+                             hipStream_t s) {
+    const uint32_t n = (uint32_t)(m * kCentroids * chunk_size);
+    if (!table.ptr) QAMD_TRY(table.alloc((size_t)n * 4));
+    hipLaunchKernelGGL(pq_pair_table_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, centroids_dev,
+                       (uint32_t)dim, (uint32_t)chunk_size, (uint32_t)m, table.as<float>());
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+qamd_status launch_assign(const float *src, uint64_t nr, uint64_t dim, uint64_t chunk_size, uint64_t m,
+                          const float *centroids_dev, const DevBuf *pair_table, uint8_t *rows_out, uint64_t row_stride,
+                          uint64_t r0, hipStream_t s) {
+    const size_t lds = (size_t)kCentroids * chunk_size * sizeof(float);
+    if (lds > kLdsBudget) return fail(QAMD_ERR_ARGUMENTS, "chunk_size %llu too large", (unsigned long long)chunk_size);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_encode_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    });
+    const uint32_t gx = (uint32_t)((nr + kBlock - 1) / kBlock);
+    // few row blocks -> split the chunk loop over blockIdx.y to fill the chip
+    uint32_t slices = 1;
+    const uint32_t want = (uint32_t)device_info().cu_count * 4;
+    if (gx < want) slices = std::min<uint32_t>((uint32_t)m, (want + gx - 1) / gx);
+    const uint32_t per = (uint32_t)((m + slices - 1) / slices);
+    slices = (uint32_t)((m + per - 1) / per);
+#define QAMD_PQ_ENC(CSV)                                                                                     \
+    case CSV:                                                                                               \
+        hipLaunchKernelGGL((pq_encode_cs_kernel<CSV>), dim3(gx, slices), dim3(kBlock), 0, s, src, nr, (uint32_t)dim, \
+                           (uint32_t)m, pair_table->as<f32x2>(), rows_out, (uint32_t)row_stride, r0, per);   \
+        break;
+    bool fast = pair_table && pair_table->ptr && cs_fast_shape(dim, chunk_size);
+    if (fast) {
+        switch (chunk_size) {
+            QAMD_PQ_ENC(1) QAMD_PQ_ENC(2) QAMD_PQ_ENC(4) QAMD_PQ_ENC(8) QAMD_PQ_ENC(16) QAMD_PQ_ENC(32)
+            default: fast = false;
+        }
+    }
+#undef QAMD_PQ_ENC
+    if (!fast)
+        hipLaunchKernelGGL(pq_encode_kernel, dim3(gx, slices), dim3(kBlock), lds, s, src, nr, (uint32_t)dim,
+                           (uint32_t)chunk_size, (uint32_t)m, centroids_dev, rows_out, (uint32_t)row_stride, r0, per);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
 qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_stop_fn stop, void *stop_user,
                         hipStream_t s) {
     const uint64_t dim = h->vp.dim, count = h->count;
@@ -622,24 +671,9 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
     const uint64_t batch_rows = std::max<uint64_t>(1, std::min<uint64_t>(count, batch_bytes / (dim * 4)));
     DevBuf stage;
     if (data_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(batch_rows * dim * 4));
-    const size_t lds = (size_t)kCentroids * h->chunk_size * sizeof(float);
-    if (lds > kLdsBudget) return fail(QAMD_ERR_ARGUMENTS, "chunk_size %llu too large", (unsigned long long)h->chunk_size);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_encode_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    });
-    const bool cs_fast = dim % h->chunk_size == 0 && (h->chunk_size == 1 || h->chunk_size == 2 || h->chunk_size == 4 ||
-                                                      h->chunk_size == 8 || h->chunk_size == 16 || h->chunk_size == 32);
     DevBuf pair_table;  // [chunk][centroid pair][j][2], read through the scalar cache
-    if (cs_fast) {
-        const uint32_t n = (uint32_t)(h->m * kCentroids * h->chunk_size);
-        QAMD_TRY(pair_table.alloc((size_t)n * 4));
-        hipLaunchKernelGGL(pq_pair_table_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                           h->centroids.as<float>(), (uint32_t)dim, (uint32_t)h->chunk_size, (uint32_t)h->m,
-                           pair_table.as<float>());
-        QAMD_HIP(hipGetLastError());
-    }
+    if (cs_fast_shape(dim, h->chunk_size))
+        QAMD_TRY(build_pair_table(h->centroids.as<float>(), dim, h->chunk_size, h->m, pair_table, s));
     for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
         if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :198-200
         const uint64_t nr = std::min(batch_rows, count - r0);
@@ -648,31 +682,8 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
             QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
             src = stage.as<float>();
         }
-        const uint32_t gx = (uint32_t)((nr + kBlock - 1) / kBlock);
-        // few row blocks -> split the chunk loop over blockIdx.y to fill the chip
-        uint32_t slices = 1;
-        const uint32_t want = (uint32_t)device_info().cu_count * 4;
-        if (gx < want) slices = std::min<uint32_t>((uint32_t)h->m, (want + gx - 1) / gx);
-        const uint32_t per = (uint32_t)((h->m + slices - 1) / slices);
-        slices = (uint32_t)((h->m + per - 1) / per);
-#define QAMD_PQ_ENC(CSV)                                                                                     \
-    case CSV:                                                                                               \
-        hipLaunchKernelGGL((pq_encode_cs_kernel<CSV>), dim3(gx, slices), dim3(kBlock), 0, s, src, nr, (uint32_t)dim, \
-                           (uint32_t)h->m, pair_table.as<f32x2>(), h->rows.as<uint8_t>(), (uint32_t)h->ds, r0, per); \
-        break;
-        bool fast = cs_fast;
-        if (fast) {
-            switch (h->chunk_size) {
-                QAMD_PQ_ENC(1) QAMD_PQ_ENC(2) QAMD_PQ_ENC(4) QAMD_PQ_ENC(8) QAMD_PQ_ENC(16) QAMD_PQ_ENC(32)
-                default: fast = false;
-            }
-        }
-#undef QAMD_PQ_ENC
-        if (!fast)
-            hipLaunchKernelGGL(pq_encode_kernel, dim3(gx, slices), dim3(kBlock), lds, s, src, nr, (uint32_t)dim,
-                               (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
-                               h->rows.as<uint8_t>(), (uint32_t)h->ds, r0, per);
-        QAMD_HIP(hipGetLastError());
+        QAMD_TRY(launch_assign(src, nr, dim, h->chunk_size, h->m, h->centroids.as<float>(), &pair_table,
+                               h->rows.as<uint8_t>(), h->ds, r0, s));
         if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
     }
     QAMD_HIP(hipStreamSynchronize(s));
@@ -689,10 +700,17 @@ qamd_status train_centroids(qamd_pq *h, const float *data, qamd_mem data_mem, qa
     // evenly strided subset in index order (deterministic; centroid values are parity-unpinned).
     DevBuf sample;
     QAMD_TRY(sample.alloc((size_t)S * dim * 4));
-    for (uint32_t k = 0; k < S; k++) {
-        const uint64_t r = (uint64_t)((unsigned __int128)k * count / S);
-        QAMD_HIP(hipMemcpyAsync(sample.as<float>() + (size_t)k * dim, data + r * dim, dim * 4,
-                                data_mem == QAMD_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    if (data_mem == QAMD_MEM_HOST) {  // gather on the host, one upload (not S small copies)
+        std::vector<float> picks((size_t)S * dim);
+        for (uint32_t k = 0; k < S; k++) {
+            const uint64_t r = (uint64_t)((unsigned __int128)k * count / S);
+            memcpy(picks.data() + (size_t)k * dim, data + r * dim, dim * 4);
+        }
+        QAMD_TRY(copy_in(sample.ptr, picks.data(), QAMD_MEM_HOST, picks.size() * 4, s));
+    } else {
+        hipLaunchKernelGGL(km_gather_rows_kernel, dim3(grid_for((uint64_t)S * dim, kBlock * 4, 8)), dim3(kBlock), 0, s,
+                           data, count, (uint32_t)dim, (uint64_t)S, sample.as<float>());
+        QAMD_HIP(hipGetLastError());
     }
     if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :303-305
     const size_t ncen = (size_t)kCentroids * dim;
@@ -704,21 +722,20 @@ qamd_status train_centroids(qamd_pq *h, const float *data, qamd_mem data_mem, qa
     QAMD_TRY(diff.alloc((size_t)m * 4));
     // initial centroids = the first 256 sample rows (kmeans.rs:25)
     QAMD_HIP(hipMemcpyAsync(cen.ptr, sample.ptr, ncen * 4, hipMemcpyDeviceToDevice, s));
-    const size_t lds = (size_t)kCentroids * h->chunk_size * sizeof(float);
-    if (lds > kLdsBudget) return fail(QAMD_ERR_ARGUMENTS, "chunk_size %llu too large", (unsigned long long)h->chunk_size);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&km_assign_accumulate_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    });
+    DevBuf assign, pair_table;
+    QAMD_TRY(assign.alloc((size_t)S * m));
+    const bool cs = cs_fast_shape(dim, h->chunk_size);
     std::vector<int> done_h(m, 0);
     std::vector<float> diff_h(m);
     for (int iter = 0; iter < kKmeansMaxIter; iter++) {
         if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // kmeans.rs:29-31
         QAMD_HIP(hipMemsetAsync(cnt.ptr, 0, (size_t)m * kCentroids * 4, s));
         QAMD_HIP(hipMemsetAsync(diff.ptr, 0, (size_t)m * 4, s));
-        hipLaunchKernelGGL(km_assign_accumulate_kernel, dim3((S + kBlock - 1) / kBlock, m), dim3(kBlock), lds, s,
-                           sample.as<float>(), S, (uint32_t)dim, (uint32_t)h->chunk_size, m, cen.as<float>(),
+        if (cs) QAMD_TRY(build_pair_table(cen.as<float>(), dim, h->chunk_size, m, pair_table, s));
+        QAMD_TRY(launch_assign(sample.as<float>(), S, dim, h->chunk_size, m, cen.as<float>(), &pair_table,
+                               assign.as<uint8_t>(), m, 0, s));
+        hipLaunchKernelGGL(km_accumulate_kernel, dim3((S + kBlock - 1) / kBlock, m), dim3(kBlock), 0, s,
+                           sample.as<float>(), S, (uint32_t)dim, (uint32_t)h->chunk_size, m, assign.as<uint8_t>(),
                            done.as<int>(), acc.as<double>(), cnt.as<uint32_t>());
         hipLaunchKernelGGL(km_finalize_kernel, dim3((uint32_t)((ncen + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                            sample.as<float>(), S, (uint32_t)dim, (uint32_t)h->chunk_size, m, cen.as<float>(),
