@@ -71,15 +71,17 @@ void DevBuf::release() {
 
 qamd_status StreamBuf::alloc(size_t n, hipStream_t s, bool zero) {
     release();
-    static std::once_flag once;
-    std::call_once(once, [] {
-        int dev = 0;
-        hipMemPool_t pool = nullptr;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-            uint64_t keep = ~0ull;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        }
-    });
+    static std::once_flag once[64];  // per device: its default pool keeps what it is given
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::call_once(once[dev], [dev] {
+            hipMemPool_t pool = nullptr;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+                uint64_t keep = ~0ull;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+        });
+    }
     if (n == 0) n = 16;
     stream = s;
     QAMD_HIP(hipMallocAsync(&ptr, n, s));
