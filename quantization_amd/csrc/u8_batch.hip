@@ -43,7 +43,7 @@ using namespace qamd;
 
 namespace {
 
-constexpr int TQ = 256, TR = 256;  // largest workgroup tile (queries x rows): padding granularity
+constexpr int TQ = 256;  // largest query tile: padding granularity of a query batch
 constexpr uint32_t kBatchCap = kTopkCandCap;  // candidate slots per query
 constexpr uint32_t kCounterStride = 16;       // u32: one counter per 64-byte line
 
@@ -259,8 +259,9 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 //     (XCD, row_lane) walk the same row tiles, so a row tile comes from HBM once per XCD.
 //   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers and
 //     no ds_write pass; K is a continuous stream of 64-byte K-tiles (across output tiles too, so
-//     the next tile's first K-tiles are in flight during the epilogue) through a ring of four
-//     32 KiB slots, three K-tiles ahead, retired with COUNTED vmcnt waits.
+//     the next tile's first K-tiles are in flight during the epilogue) through a ring of RING
+//     LDS slots, RING-1 K-tiles ahead, retired with COUNTED vmcnt waits (4 x 32 KiB for the
+//     256 x 256 tile, 3 x 40 KiB for the 128 x 512 tile of small batches).
 //   * LDS image is lane-linear per DMA instruction (16 rows x 64 B); the 16-byte chunk index is
 //     XOR-swizzled with (row>>2)&3 on the SOURCE address and on the fragment read, which makes
 //     every ds_read_b128 lane group hit 16 distinct 16-byte slots.
@@ -271,20 +272,30 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 // 4u+2p+g (reads + DMA issue) and 4u+2p+g+1 (MFMAs).  Hazards, by slot number:
 //   RAW  K-tile u+1 is first read in slot 4u+4; every wave retires its DMA of K-tile u+1 with a
 //        counted vmcnt at the end of its phase-0 MFMA slot of K-tile u (slots 4u+1 / 4u+2).
-//   WAR  B of K-tile u+3 (ring slot of K-tile u-1) is issued in slots 4u / 4u+1; the last reads of
-//        K-tile u-1's B were issued in slot 4u-3 and waited for in slot 4u-2.  A of K-tile u+3 is
-//        issued in slots 4u+2 / 4u+3; the last reads of K-tile u-1's A were issued in slot 4u-1
-//        and waited for in slot 4u.
+//   WAR  B of K-tile u+RING-1 (ring slot of K-tile u-1) is issued in slots 4u / 4u+1; the last reads
+//        of K-tile u-1's B were issued in slot 4u-3 and waited for in slot 4u-2.  A of K-tile
+//        u+RING-1 is issued in slots 4u+2 / 4u+3; the last reads of K-tile u-1's A were issued in
+//        slot 4u-1 and waited for in slot 4u.  (Nothing in the argument depends on RING beyond
+//        "the slot being refilled is the one K-tile u-1 used".)
 // Measured alternatives (in-kernel timeline, tools/gemm_timeline.py): DMA issued inside the MFMA
 // slot: K loop +10 %; one 16-MFMA slot per K-tile and group (half the barriers): K loop +5..15 %
 // (and the 128-query tile, 8 MFMAs per K-tile in one slot: 2.14-2.59 ms vs 1.87-2.08 for 4..128 queries).
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
-constexpr int PP_KT = 64;                      // K-tile bytes per row
-constexpr int PP_UNIT = 256 * PP_KT;           // one operand of one K-tile: 16 KiB
-constexpr int PP_SLOT = 2 * PP_UNIT;           // B then A
-constexpr int PP_RING = 4;
-constexpr size_t PP_LDS = (size_t)PP_RING * PP_SLOT + 3 * 256 * sizeof(float) + 64;  // + q_off, pivot, B_q, 8 counters
+constexpr int PP_KT = 64;  // K-tile bytes per row
+// Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
+//   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
+//   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
+//          once, so the shape that moves the most row bytes per slot wins (HBM-bound)
+template <int MI, int MJ> struct PpShape {
+    static constexpr int TQH = MI * 32, TQW = 2 * TQH;  // queries per wave group / workgroup
+    static constexpr int RW = MJ * 32, TR = 4 * RW;     // rows per wave / workgroup
+    static constexpr uint32_t GA = TQW / 128, GB = TR / 128;
+    static constexpr int BYTES_B = TR * PP_KT, BYTES_A = TQW * PP_KT, SLOT = BYTES_B + BYTES_A;
+    static constexpr size_t CONSTS = 3 * 256 * sizeof(float) + 64;  // q_off, pivot, B_q, 8 counters
+    static constexpr int RING = (size_t)4 * SLOT + CONSTS <= 160 * 1024 ? 4 : 3;
+    static constexpr size_t LDS = (size_t)RING * SLOT + CONSTS;
+};
 
 #define PP_BARRIER()                          \
     do {                                      \
@@ -301,11 +312,13 @@ __device__ __forceinline__ void pp_glds16(const uint8_t *src, uint8_t *lds_dst) 
 }
 __device__ __forceinline__ void pp_wait_vm(uint32_t n) {  // n is wave-uniform; rounded DOWN to a supported count
     if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -333,10 +346,13 @@ __device__ __forceinline__ int pp_bound(float num /* pivot - q_off, or -v_off */
     return (int)t;
 }
 
-// MI = 32-query fragments per wave: 4 -> workgroup tile of 256 queries (the shape described above),
-// 2 -> 128 queries for batches of up to 128 (each wave 64 x 64, 4 MFMAs per phase: that shape is
-// bound by the HBM read of the store, which it streams exactly once).
-template <int MODE, bool LOW, int MI>
+// A wave owns MI x MJ 32x32 accumulator tiles (PpShape): <4,2> is the 256 x 256 workgroup tile
+// described above; <2,4> = 128 queries x 512 rows serves batches of up to 128 queries, where the
+// store is streamed exactly once and the shape that moves the most row bytes per slot wins
+// (measured: K loop at 5.5 TB/s of row bytes; 1.76-1.85 ms per 10M x 768 for 4..64 queries against
+// 1.86-2.0 with a 128 x 256 tile; splitting its phases by row fragments instead of query fragments
+// to balance the read slots changed nothing).
+template <int MODE, bool LOW, int MI, int MJ>
 __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restrict__ codes,
                                                         const float *__restrict__ v_offsets,
                                                         const uint8_t *__restrict__ qcodes, uint32_t q_pitch,
@@ -352,12 +368,16 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
     if (j >= row_lanes * q_tiles) return;
     const uint32_t q_tile = j % q_tiles, row_lane = j / q_tiles;
-    constexpr int TQH = MI * 32;   // queries per wave group
-    constexpr int TQW = 2 * TQH;   // queries per workgroup
-    constexpr int HALF = MI / 2;   // query fragments per phase
-    constexpr uint32_t GA = MI == 4 ? 2 : 1;  // DMA instructions per wave for a K-tile's query operand
+    using Shape = PpShape<MI, MJ>;
+    constexpr int TQH = Shape::TQH;  // queries per wave group
+    constexpr int TQW = Shape::TQW;  // queries per workgroup
+    constexpr int HALF = MI / 2;     // query fragments per phase
+    constexpr int RW = Shape::RW;    // rows per wave
+    constexpr int TR = Shape::TR;    // rows per workgroup tile
+    constexpr uint32_t GA = Shape::GA, GB = Shape::GB;  // DMA instructions per wave and K-tile (queries / rows)
+    constexpr int BYTES_B = Shape::BYTES_B, SLOT = Shape::SLOT, RING = Shape::RING, AHEAD = RING - 1;
     const uint32_t q0 = q_tile * TQW;
-    const uint32_t n_rtiles = (n_rows + 255) / 256;
+    const uint32_t n_rtiles = (n_rows + TR - 1) / TR;
     const uint32_t first = xcd + 8 * row_lane, step = 8 * row_lanes;
     if (first >= n_rtiles) return;
     const uint32_t my_tiles = __builtin_amdgcn_readfirstlane((n_rtiles - first + step - 1) / step);
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     unsigned long long dbg_flagged = 0;         // (query group, row) lanes sent to the exact epilogue
 
     // The workgroup's query tile never changes: its per-query constants are staged once.
-    float *q_off_s = reinterpret_cast<float *>(lds_raw + (size_t)PP_RING * PP_SLOT);  // [256]
+    float *q_off_s = reinterpret_cast<float *>(lds_raw + (size_t)RING * SLOT);  // [256]
     float *pivot_s = q_off_s + 256;                                                   // [256]
     int *bq_s = reinterpret_cast<int *>(pivot_s + 256);                               // [256] integer query bounds
     uint32_t *wcount_s = reinterpret_cast<uint32_t *>(bq_s + 256) + wave;             // this wave's append counter
@@ -402,25 +422,26 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     // per-lane source pointers kept across the loop and advanced by wave-uniform amounts (one
     // 64-bit add per DMA instruction in the read slot instead of a 64-bit multiply-add chain)
     const uint8_t *src_a0 = qcodes + ((uint64_t)q0 + dma_row) * q_pitch + dma_chunk;
-    const uint8_t *src_b = codes + ((uint64_t)first * 256 + dma_row) * ad + dma_chunk;
-    const uint64_t tile_stride_b = (uint64_t)step * 256 * ad, half_b = (uint64_t)128 * ad, half_a = (uint64_t)128 * q_pitch;
-    uint32_t pf_kt = 0, pf_koff = 0, pf_u = 0;
+    const uint8_t *src_b = codes + ((uint64_t)first * TR + dma_row) * ad + dma_chunk;
+    const uint64_t tile_stride_b = (uint64_t)step * TR * ad, half_b = (uint64_t)128 * ad, half_a = (uint64_t)128 * q_pitch;
+    uint32_t pf_kt = 0, pf_koff = 0, pf_u = 0, pf_slot = 0;  // pf_slot = pf_u % RING
     const uint32_t dbgf = g_gemm_dbg;
-    auto issue_B = [&]() {
+    auto issue_B = [&](uint32_t idx_lo, uint32_t idx_hi) {
         const uint8_t *src = src_b + pf_koff;
-        uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + wave * 1024;
+        uint8_t *dst = lds_raw + pf_slot * SLOT + wave * 1024;
         if (dbgf & 2u) return;
-        pp_glds16(src, dst);
-        pp_glds16(src + half_b, dst + 128 * PP_KT);
+#pragma unroll
+        for (uint32_t idx = idx_lo; idx < idx_hi; idx++) pp_glds16(src + idx * half_b, dst + idx * 128 * PP_KT);
     };
     auto issue_A = [&]() {  // second half of a K-tile's DMA: advances the prefetch position
         const uint8_t *src = src_a0 + pf_koff;
-        uint8_t *dst = lds_raw + (pf_u & 3u) * PP_SLOT + PP_UNIT + wave * 1024;
+        uint8_t *dst = lds_raw + pf_slot * SLOT + BYTES_B + wave * 1024;
         if (!(dbgf & 1u)) {
-            pp_glds16(src, dst);
-            if (MI == 4) pp_glds16(src + half_a, dst + 128 * PP_KT);
+#pragma unroll
+            for (uint32_t idx = 0; idx < GA; idx++) pp_glds16(src + idx * half_a, dst + idx * 128 * PP_KT);
         }
         pf_u++;
+        pf_slot = pf_slot + 1 == (uint32_t)RING ? 0u : pf_slot + 1;
         pf_koff += PP_KT;
         if (++pf_kt == nkt) {
             pf_kt = 0;
@@ -431,77 +452,99 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     // fragment read offsets: chunk 2*ks + h of row r (+ multiples of 16 rows), swizzled
     const uint32_t swz = ((uint32_t)r >> 2) & 3u;
     const uint32_t off0 = (((uint32_t)h) ^ swz) * 16, off1 = ((2u + (uint32_t)h) ^ swz) * 16;
-    const uint32_t fragA = PP_UNIT + (g * TQH + r) * PP_KT, fragB = (wr * 64 + r) * PP_KT;
+    const uint32_t fragA = BYTES_B + (g * TQH + r) * PP_KT, fragB = (wr * RW + r) * PP_KT;
 
-    // v_offset of this lane's two rows (jj = 0, 1) for the tile about to start.  Loaded one tile
+    // v_offset of this lane's MJ rows (jj = 0 .. MJ-1) for the tile about to start.  Loaded one tile
     // ahead by inline asm so that the compiler attaches no wait to it (next to LDS-DMA it would
     // drain everything with vmcnt(0)); the loads are older than the DMA that follows, so the
     // counted waits of the K loop retire them (K-tile 1's wait at the latest: the launcher sends
     // stores with fewer than three K-tiles per row to u8_gemm_kernel).  The values are only
     // touched (copied, used) after the K loop; check the .s when editing this (a register copy
     // placed before the data has landed would copy garbage).
-    auto load_voff = [&](uint32_t tile_idx, float &v0, float &v1) {
-        const float *p0 = v_offsets + (uint64_t)tile_idx * 256 + wr * 64 + r;  // padded like codes[]
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:128"
-                     : "=&v"(v0), "=&v"(v1)
-                     : "v"(p0)
-                     : "memory");
+    float vo_next[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // [MJ] used
+    auto load_voff = [&](uint32_t tile_idx) {
+        const float *p0 = v_offsets + (uint64_t)tile_idx * TR + wr * RW + r;  // padded like codes[]
+        if (MJ == 2)
+            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:128"
+                         : "=&v"(vo_next[0]), "=&v"(vo_next[1])
+                         : "v"(p0)
+                         : "memory");
+        else
+            asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:128\n\t"
+                         "global_load_dword %2, %4, off offset:256\n\tglobal_load_dword %3, %4, off offset:384"
+                         : "=&v"(vo_next[0]), "=&v"(vo_next[1]), "=&v"(vo_next[2]), "=&v"(vo_next[3])
+                         : "v"(p0)
+                         : "memory");
     };
-    float vo_next0 = 0.0f, vo_next1 = 0.0f;
-    if (MODE != 0) load_voff(first, vo_next0, vo_next1);
+    if (MODE != 0) load_voff(first);
 
-    // prologue: K-tiles 0..2 in flight, K-tile 0 retired
-    for (int k = 0; k < 3; k++)
+    // prologue: K-tiles 0 .. AHEAD-1 in flight, K-tile 0 retired
+    for (int k = 0; k < AHEAD; k++)
         if (pf_u < total) {
-            issue_B();
+            issue_B(0, GB);
             issue_A();
         }
-    pp_wait_vm((total > 1 ? 2u + GA : 0u) + (total > 2 ? 2u + GA : 0u));
+    {
+        uint32_t n0 = 0;
+        for (int v = 1; v < AHEAD; v++) n0 += (uint32_t)v < total ? GB + GA : 0u;
+        pp_wait_vm(n0);
+    }
     PP_BARRIER();
     stamp(1);
     if (g == 1) PP_BARRIER();  // group 1 runs one slot behind
 
     const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
-    uint32_t tile = first, u = 0;
+    uint32_t tile = first, u = 0, rd_slot = 0;  // rd_slot = u % RING
     for (uint32_t ti = 0; ti < my_tiles; ti++, tile += step) {
-    v16i acc[MI][2];
-    float vo_cur0 = 0.0f, vo_cur1 = 0.0f;
-    int br0 = 0, br1 = 0;
+    v16i acc[MI][MJ];
+    float vo_cur[MJ];
+    int br[MJ];
+#pragma unroll
+    for (int jj = 0; jj < MJ; jj++) {
+        vo_cur[jj] = 0.0f;
+        br[jj] = 0;
+    }
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < MI; i++)
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++)
+            for (int jj = 0; jj < MJ; jj++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][jj][e] = 0;
     } else {
-        asm volatile("" : "+v"(vo_next0), "+v"(vo_next1));  // ordered after every wait above
-        vo_cur0 = vo_next0;
-        vo_cur1 = vo_next1;
-        if (ti + 1 < my_tiles) load_voff(tile + step, vo_next0, vo_next1);
-        const uint64_t row_a = (uint64_t)tile * 256 + wr * 64 + r;
-        br0 = row_a < n_rows ? pp_bound<LOW>(-vo_cur0, fabsf(vo_cur0), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
-        br1 = row_a + 32 < n_rows ? pp_bound<LOW>(-vo_cur1, fabsf(vo_cur1), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+        if (MJ == 2) asm volatile("" : "+v"(vo_next[0]), "+v"(vo_next[1]));  // ordered after every wait above
+        else asm volatile("" : "+v"(vo_next[0]), "+v"(vo_next[1]), "+v"(vo_next[2]), "+v"(vo_next[3]));
+#pragma unroll
+        for (int jj = 0; jj < MJ; jj++) vo_cur[jj] = vo_next[jj];
+        if (ti + 1 < my_tiles) load_voff(tile + step);
+        const uint64_t row_a = (uint64_t)tile * TR + wr * RW + r;
+#pragma unroll
+        for (int jj = 0; jj < MJ; jj++)
+            br[jj] = row_a + 32 * jj < n_rows ? pp_bound<LOW>(-vo_cur[jj], fabsf(vo_cur[jj]), multiplier, 0)
+                                              : (LOW ? -(int)kPpLim : (int)kPpLim);
 #pragma unroll
         for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + g * TQH + i * 32 + 8 * gq + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    acc[i][0][4 * gq + e] = -(bq4[e] + br0);
-                    acc[i][1][4 * gq + e] = -(bq4[e] + br1);
-                }
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int jj = 0; jj < MJ; jj++) acc[i][jj][4 * gq + e] = -(bq4[e] + br[jj]);
             }
     }
     if (ti < 4) stamp(2 + 3 * (int)ti);  // tile set up
     for (uint32_t kt = 0; kt < nkt; kt++, u++) {
-        const uint8_t *slot = lds_raw + (u & 3u) * PP_SLOT;
+        const uint8_t *slot = lds_raw + rd_slot * SLOT;
+        rd_slot = rd_slot + 1 == (uint32_t)RING ? 0u : rd_slot + 1;
         const uint8_t *pA = slot + fragA, *pB = slot + fragB;
-        // ---- phase 0: the first half of the query fragments and both row fragments
-        v4i a[HALF][2], bf[2][2];
+        const bool more = u + AHEAD < total;
+        uint32_t nw = more ? GB : 0u;  // DMA instructions younger than K-tile u+1's at the phase-0 wait
+        for (int v = 2; v < AHEAD; v++) nw += u + v < total ? GB + GA : 0u;
+        // ---- phase 0: the first half of the query fragments and all row fragments
+        v4i a[HALF][2], bf[MJ][2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < MJ; i++) {
             bf[i][0] = *reinterpret_cast<const v4i *>(pB + i * 32 * PP_KT + off0);
             bf[i][1] = *reinterpret_cast<const v4i *>(pB + i * 32 * PP_KT + off1);
         }
@@ -510,8 +553,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
             a[i][0] = *reinterpret_cast<const v4i *>(pA + i * 32 * PP_KT + off0);
             a[i][1] = *reinterpret_cast<const v4i *>(pA + i * 32 * PP_KT + off1);
         }
-        const bool more = u + 3 < total;
-        if (more) issue_B();
+        if (more) issue_B(0, GB);
         PP_BARRIER();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -519,10 +561,10 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
 #pragma unroll
             for (int i = 0; i < HALF; i++)
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++)
+                for (int jj = 0; jj < MJ; jj++)
                     acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ks], bf[jj][ks], acc[i][jj], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        pp_wait_vm((u + 2 < total ? 2u + GA : 0u) + (more ? 2u : 0u));  // retires K-tile u+1
+        pp_wait_vm(nw);  // retires this wave's DMA of K-tile u+1
         PP_BARRIER();
         // ---- phase 1: the other query fragments against the row fragments already in registers
 #pragma unroll
@@ -538,7 +580,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
 #pragma unroll
             for (int i = 0; i < HALF; i++)
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++)
+                for (int jj = 0; jj < MJ; jj++)
                     acc[HALF + i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ks], bf[jj][ks], acc[HALF + i][jj], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_BARRIER();
@@ -548,7 +590,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
         // group 1's last MFMAs; group 1 falls one slot behind again afterwards).
         if (g == 0) PP_BARRIER();
         if (ti < 4) stamp(3 + 3 * (int)ti);  // K loop done
-        const uint64_t row0 = (uint64_t)tile * 256;
+        const uint64_t row0 = (uint64_t)tile * TR;
         // opaque per tile: keeps per-query output addresses and everything else the epilogue
         // derives from the lane / wave id from being hoisted out of the K loop as loop invariants
         // (with 128 accumulators live, every hoisted invariant is a spill in that loop)
@@ -557,13 +599,13 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
         uint4 *wave_list = MODE != 0 ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
         const uint32_t g_e = wave_e >> 2, wr_e = wave_e & 3u, r_e = lane_e & 31u, h_e = lane_e >> 5;
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const uint64_t row = row0 + wr_e * 64 + jj * 32 + r_e;
+        for (int jj = 0; jj < MJ; jj++) {
+            const uint64_t row = row0 + wr_e * RW + jj * 32 + r_e;
             const bool row_ok = row < n_rows;
             float v_off;
             if (MODE == 0) v_off = v_offsets[row];  // padded like codes[]
-            else v_off = row_ok ? (jj ? vo_cur1 : vo_cur0) : never;
-            const int br = jj ? br1 : br0;
+            else v_off = row_ok ? vo_cur[jj] : never;
+            const int brj = br[jj];
 #pragma unroll
             for (int i = 0; i < MI; i++) {
                 if (MODE == 0) __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time: no load clustering
@@ -601,7 +643,7 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
                             const int av[4] = {a0, a1, a2, a3};
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                const int s_int = av[e] + bq4[e] + br;  // the plain integer dot product
+                                const int s_int = av[e] + bq4[e] + brj;  // the plain integer dot product
                                 const float sc = (multiplier * (float)s_int + qo[e]) + v_off;
                                 const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
                                 if (d >= 0.0f) {
@@ -804,16 +846,17 @@ inline uint32_t pp_launches(uint64_t n_queries) {
 
 // Ping-pong kernel launch: one persistent workgroup per CU; at most 32 query tiles per launch
 // (8192 queries), larger batches go in slices of 8192.
-template <int MODE, bool LOW, int MI>
+template <int MODE, bool LOW, int MI, int MJ>
 qamd_status launch_gemm_pp_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW, MI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW, MI, MJ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PpShape<MI, MJ>::LDS));
     });
     constexpr uint64_t TQW = 64 * MI;  // queries per workgroup tile
+    constexpr size_t lds_bytes = PpShape<MI, MJ>::LDS;
     const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
     const uint64_t all_q_tiles = (b->n_queries + TQW - 1) / TQW;
     for (uint64_t qt0 = 0; qt0 < all_q_tiles; qt0 += cus_per_xcd) {
@@ -826,7 +869,7 @@ qamd_status launch_gemm_pp_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
             f.query_base = (uint32_t)q_base;
             f.wave_base = (uint32_t)(qt0 / cus_per_xcd) * pp_waves_per_launch();
         }
-        hipLaunchKernelGGL((u8_gemm_pp_kernel<MODE, LOW, MI>), dim3(8 * row_lanes * q_tiles), dim3(512), PP_LDS, s,
+        hipLaunchKernelGGL((u8_gemm_pp_kernel<MODE, LOW, MI, MJ>), dim3(8 * row_lanes * q_tiles), dim3(512), lds_bytes, s,
                            codes, v_offsets, b->codes.as<uint8_t>() + q_base * b->pitch, (uint32_t)b->pitch,
                            b->offsets.as<float>() + q_base, h->meta.multiplier, (uint32_t)n_rows,
                            (uint32_t)(b->n_queries - q_base), (uint32_t)h->meta.actual_dim, q_tiles, row_lanes,
@@ -842,16 +885,16 @@ qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const
                            const BatchFilter &filt, hipStream_t s) {
     const bool small = b->n_queries <= 128;  // 128-query tile: the store is streamed once, HBM-bound
     if (MODE == 0)
-        return small ? launch_gemm_pp_cfg<0, false, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
-                     : launch_gemm_pp_cfg<0, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        return small ? launch_gemm_pp_cfg<0, false, 2, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
+                     : launch_gemm_pp_cfg<0, false, 4, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     // "may pass" is s <= bound when the score falls with s (multiplier < 0) xor smallest-first
     constexpr int M = MODE == 0 ? 1 : MODE;
     const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
     if (small)
-        return low ? launch_gemm_pp_cfg<M, true, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
-                   : launch_gemm_pp_cfg<M, false, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
-    return low ? launch_gemm_pp_cfg<M, true, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
-               : launch_gemm_pp_cfg<M, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+        return low ? launch_gemm_pp_cfg<M, true, 2, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
+                   : launch_gemm_pp_cfg<M, false, 2, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+    return low ? launch_gemm_pp_cfg<M, true, 4, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)
+               : launch_gemm_pp_cfg<M, false, 4, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
 }
 
 // Which kernel serves a batch: the ping-pong kernel (rows of at least three 64-byte K-tiles, a
@@ -1000,8 +1043,8 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     if (fused) {
         const uint64_t ad = h->meta.actual_dim;
         StreamBuf s_codes, s_offs, s_scores, pivots, counters, cand, status_dev;
-        QAMD_TRY(s_codes.alloc((uint64_t)(S + TR) * ad, s, true));  // + one tile of zero rows
-        QAMD_TRY(s_offs.alloc((uint64_t)(S + TR) * 4, s, true));
+        QAMD_TRY(s_codes.alloc((uint64_t)(S + 512) * ad, s, true));  // + one (largest) tile of zero rows
+        QAMD_TRY(s_offs.alloc((uint64_t)(S + 512) * 4, s, true));
         QAMD_TRY(s_scores.alloc(Q * (uint64_t)S * 4, s));
         QAMD_TRY(pivots.alloc(b->q_pad * 4, s, true));
         QAMD_TRY(counters.alloc(b->q_pad * kCounterStride * 4, s, true));
