@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--exchange", choices=["scores", "topk", "none"], default="scores",
                     help="per-query result exchange across ranks (N>1): gather of per-shard scores "
                          "to rank 0 (overlapped with the next scan), per-shard top-k + all-gather, or none")
+    ap.add_argument("--gather-root", default="rotate",
+                    help="--exchange scores: 'rotate' (step i gathers to rank i %% N: consecutive gathers use "
+                         "disjoint inbound xGMI links) or a rank number (every step to that rank)")
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -272,7 +275,8 @@ def main():
     qobj = enc.encode_query(queries[0])
     gather = topk = None
     if args.exchange == "scores":
-        gather = ScoreGather(dist, torch, n, dev, rank, world, dst=0)
+        gather = ScoreGather(dist, torch, n, dev, rank, world,
+                             dst=None if args.gather_root == "rotate" else int(args.gather_root))
     elif args.exchange == "topk":
         topk = ShardedTopK(dist, torch, args.k, dev, rank, world, total_rows)
     scores_plain = torch.empty(n, dtype=torch.float32, device=dev) if gather is None else None
@@ -380,6 +384,7 @@ def main():
                                    + (f" + {args.exchange} exchange" if world > 1 and args.exchange != "none" else ""),
                        "quantizer": args.quantizer, "rows_per_gpu": n, "dim": dim, "distance": args.distance,
                        "exchange": args.exchange,
+                       "gather_root": args.gather_root if (world > 1 and args.exchange == "scores") else None,
                        "total_rows": total_rows, "queries": args.queries},
             "roofline": roofline,
         }

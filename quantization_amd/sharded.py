@@ -37,25 +37,32 @@ def _needs_host_staging(dist, tensor) -> bool:
 
 
 class ScoreGather:
-    """Double-buffered asynchronous gather of per-shard score vectors to rank `dst`.
+    """Double-buffered asynchronous gather of per-shard score vectors to one rank per step.
 
-    submit(step, local_scores) starts the gather of `local_scores` (a tensor of `rows_padded`
-    f32 in slot step%2) and returns; the caller may immediately launch the next scan into the
-    other slot.  collect(step) waits (stream-ordered) and, on `dst`, returns the [world,
-    rows_padded] tensor holding every shard's scores of that step.
+    submit(step) starts the gather of slot step%2 (a tensor of `rows_padded` f32 the scan of that
+    step wrote) and returns; the caller may immediately launch the next scan into the other slot.
+    collect(step) waits (stream-ordered) and, on that step's root, returns the [world, rows_padded]
+    tensor holding every shard's scores of that step (None elsewhere).
+
+    dst = an int: every step gathers to that rank (its 7 inbound xGMI links carry everything).
+    dst = None ("rotate"): step i gathers to rank i % world, so consecutive gathers use disjoint
+    inbound links and overlap each other as well as the scans; each query's scores land on one GPU,
+    round-robin, which is also how their post-processing would be balanced.
     """
 
-    def __init__(self, dist, torch, rows_padded: int, device, rank: int, world: int, dst: int = 0,
-                 group=None):
+    def __init__(self, dist, torch, rows_padded: int, device, rank: int, world: int, dst=0, group=None):
         self.dist, self.torch = dist, torch
         self.rank, self.world, self.dst, self.group = rank, world, dst, group
         self.rows_padded = rows_padded
         self.local = [torch.empty(rows_padded, dtype=torch.float32, device=device) for _ in range(2)]
         self.gathered = None
-        if rank == dst and world > 1:
+        if world > 1 and (dst is None or rank == dst):
             self.gathered = [torch.empty((world, rows_padded), dtype=torch.float32, device=device)
                              for _ in range(2)]
         self.work = [None, None]
+
+    def root(self, step: int) -> int:
+        return step % self.world if self.dst is None else self.dst
 
     def slot(self, step: int):
         """Buffer the scan of `step` must write into (after the previous use has drained)."""
@@ -69,16 +76,16 @@ class ScoreGather:
         s = step % 2
         if self.world == 1:  # single shard: the local scores ARE the global scores
             return
+        dst = self.root(step)
         if _needs_host_staging(self.dist, self.local[s]):
             host = self.local[s].cpu()
-            hlist = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
-            self.dist.gather(host, gather_list=hlist, dst=self.dst, group=self.group)
-            if self.rank == self.dst:
+            hlist = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == dst else None
+            self.dist.gather(host, gather_list=hlist, dst=dst, group=self.group)
+            if self.rank == dst:
                 self.gathered[s].copy_(self.torch.stack(hlist))
             return
-        glist = list(self.gathered[s].unbind(0)) if self.rank == self.dst else None
-        self.work[s] = self.dist.gather(self.local[s], gather_list=glist, dst=self.dst, group=self.group,
-                                        async_op=True)
+        glist = list(self.gathered[s].unbind(0)) if self.rank == dst else None
+        self.work[s] = self.dist.gather(self.local[s], gather_list=glist, dst=dst, group=self.group, async_op=True)
 
     def collect(self, step: int):
         s = step % 2
@@ -87,7 +94,7 @@ class ScoreGather:
             self.work[s] = None
         if self.world == 1:
             return self.local[s].unsqueeze(0)
-        return self.gathered[s] if self.rank == self.dst else None
+        return self.gathered[s] if self.rank == self.root(step) else None
 
     def drain(self) -> None:
         for s in range(2):

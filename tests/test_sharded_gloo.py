@@ -39,6 +39,7 @@ def _worker(rank, world, port, n, dim, tmp):
     rows, meta = qo.u8_encode_with(data[b:e], qo.DOT, False, alpha, offset)  # this rank's shard only
     pad = max_shard_rows(n, world)
     gather = ScoreGather(dist, torch, pad, "cpu", rank, world, dst=0)
+    rotating = ScoreGather(dist, torch, pad, "cpu", rank, world, dst=None)  # root = step % world
     topk = ShardedTopK(dist, torch, 10, "cpu", rank, world, n)
     g_rows, g_meta = qo.u8_encode_with(data, qo.DOT, False, alpha, offset)
     results = []
@@ -54,11 +55,19 @@ def _worker(rank, world, port, n, dim, tmp):
         ids[:] = torch.from_numpy(order.astype(np.int32))
         sc[:] = torch.from_numpy(local[order])
         merged_ids, merged_sc = topk.exchange(largest=True)
+        rslot = rotating.slot(step)
+        rslot[: e - b] = torch.from_numpy(local)
+        rotating.submit(step)
         got = gather.collect(step)
         want = qo.u8_score_all(g_meta, g_rows, codes, qoff)
         if rank == 0:
             flat = assemble_global_scores(got, n, world).numpy()
             assert np.array_equal(flat.view(np.uint32), want.view(np.uint32)), "gathered scores differ"
+        got_r = rotating.collect(step)
+        assert (got_r is not None) == (rank == step % world), "rotating root"
+        if got_r is not None:
+            flat = assemble_global_scores(got_r, n, world).numpy()
+            assert np.array_equal(flat.view(np.uint32), want.view(np.uint32)), "rotating-root gathered scores differ"
         worder = np.lexsort((np.arange(n), -want))[:10]
         assert np.array_equal(merged_ids, worder.astype(np.uint32)), "merged top-k ids differ"
         assert np.array_equal(merged_sc, want[worder])
@@ -85,6 +94,7 @@ def _worker(rank, world, port, n, dim, tmp):
         assert np.array_equal(mids[qi][: worder.size], worder.astype(np.uint32)), "batched merged ids differ"
         assert np.array_equal(msc[qi][: worder.size], want[worder])
     gather.drain()
+    rotating.drain()
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
