@@ -351,7 +351,8 @@ __device__ __forceinline__ int pp_bound(float num /* pivot - q_off, or -v_off */
 // store is streamed exactly once and the shape that moves the most row bytes per slot wins
 // (measured: K loop at 5.5 TB/s of row bytes; 1.76-1.85 ms per 10M x 768 for 4..64 queries against
 // 1.86-2.0 with a 128 x 256 tile; splitting its phases by row fragments instead of query fragments
-// to balance the read slots changed nothing).
+// to balance the read slots changed nothing; the nt cache policy on its row DMA cost 30 %: a
+// 64-byte K-tile is half a cache line, and the other half must still be in L2 one K-tile later).
 template <int MODE, bool LOW, int MI, int MJ>
 __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restrict__ codes,
                                                         const float *__restrict__ v_offsets,
