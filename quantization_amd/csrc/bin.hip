@@ -535,6 +535,22 @@ qamd_status qamd_bin_score_ids(const qamd_bin *h, const qamd_bin_query *q, const
     hipStream_t s = as_stream(stream);
     DevBuf ids_tmp, out_tmp;
     const uint32_t *ids_dev = ids;
+    // per-pair granularity (score_point and friends): ids and results through the calling
+    // thread's mapped host scratch -- no allocation, no copy calls
+    const HostScratch hs = (ids_mem == QAMD_MEM_HOST && out_mem == QAMD_MEM_HOST && n_ids <= 1024) ? host_scratch()
+                                                                                                  : HostScratch{};
+    if (hs.host) {
+        for (uint64_t k = 0; k < n_ids; k++) {
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+            hs.host[k] = ids[k];
+        }
+        QAMD_TRY(words_launch(h, q->buf.as<uint32_t>(), hs.dev, n_ids, reinterpret_cast<float *>(hs.dev + 1024), s));
+        QAMD_HIP(hipStreamSynchronize(s));
+        memcpy(out, hs.host + 1024, n_ids * 4);
+        return QAMD_OK;
+    }
     if (ids_mem == QAMD_MEM_HOST) {
         for (uint64_t k = 0; k < n_ids; k++)
             if (ids[k] >= h->count)
@@ -564,10 +580,18 @@ qamd_status qamd_bin_score_internal(const qamd_bin *h, uint32_t i, uint32_t j, f
     if (i >= h->count || j >= h->count)
         return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
     QAMD_TRY(ensure_device(h->device));
+    const uint32_t *qrow = h->rows.as<uint32_t>() + (uint64_t)i * (h->ds / 4);
+    const HostScratch hs = host_scratch();
+    if (hs.host) {
+        hs.host[0] = j;
+        QAMD_TRY(words_launch(h, qrow, hs.dev, 1, reinterpret_cast<float *>(hs.dev + 1024), nullptr));
+        QAMD_HIP(hipStreamSynchronize(nullptr));
+        memcpy(out, hs.host + 1024, 4);
+        return QAMD_OK;
+    }
     DevBuf tmp;
     QAMD_TRY(tmp.alloc(16));
     QAMD_TRY(copy_in(tmp.ptr, &j, QAMD_MEM_HOST, 4, nullptr));
-    const uint32_t *qrow = h->rows.as<uint32_t>() + (uint64_t)i * (h->ds / 4);
     QAMD_TRY(words_launch(h, qrow, tmp.as<uint32_t>(), 1, tmp.as<float>() + 1, nullptr));
     return copy_out(out, QAMD_MEM_HOST, tmp.as<float>() + 1, 4, nullptr);
 }

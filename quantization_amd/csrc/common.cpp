@@ -118,6 +118,20 @@ qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t by
     return QAMD_OK;
 }
 
+HostScratch host_scratch() {
+    static thread_local HostScratch hs = [] {
+        HostScratch r;
+        void *p = nullptr, *d = nullptr;
+        if (hipHostMalloc(&p, kHostScratchWords * 4, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+            hipHostGetDevicePointer(&d, p, 0) == hipSuccess) {
+            r.host = static_cast<uint32_t *>(p);
+            r.dev = static_cast<uint32_t *>(d);
+        }
+        return r;
+    }();
+    return hs;
+}
+
 const DeviceInfo &device_info() {
     static DeviceInfo info;
     static std::once_flag once;

@@ -1032,6 +1032,22 @@ qamd_status qamd_pq_score_ids(const qamd_pq *h, const qamd_pq_query *q, const ui
     hipStream_t s = as_stream(stream);
     DevBuf ids_tmp, out_tmp;
     const uint32_t *ids_dev = ids;
+    // per-pair granularity (score_point and friends): ids and results through the calling
+    // thread's mapped host scratch -- no allocation, no copy calls
+    const HostScratch hs = (ids_mem == QAMD_MEM_HOST && out_mem == QAMD_MEM_HOST && n_ids <= 1024) ? host_scratch()
+                                                                                                  : HostScratch{};
+    if (hs.host) {
+        for (uint64_t k = 0; k < n_ids; k++) {
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+            hs.host[k] = ids[k];
+        }
+        QAMD_TRY(scan_launch(h, q->lut.as<float>(), hs.dev, n_ids, reinterpret_cast<float *>(hs.dev + 1024), s));
+        QAMD_HIP(hipStreamSynchronize(s));
+        memcpy(out, hs.host + 1024, n_ids * 4);
+        return QAMD_OK;
+    }
     if (ids_mem == QAMD_MEM_HOST) {
         for (uint64_t k = 0; k < n_ids; k++)
             if (ids[k] >= h->count)
@@ -1061,12 +1077,22 @@ qamd_status qamd_pq_score_internal(const qamd_pq *h, uint32_t i, uint32_t j, flo
     if (i >= h->count || j >= h->count)
         return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
     QAMD_TRY(ensure_device(h->device));
+    const HostScratch hs = host_scratch();
     DevBuf tmp;
-    QAMD_TRY(tmp.alloc(16));
+    float *res = hs.host ? reinterpret_cast<float *>(hs.dev + 1024) : nullptr;
+    if (!res) {
+        QAMD_TRY(tmp.alloc(16));
+        res = tmp.as<float>();
+    }
     hipLaunchKernelGGL(pq_internal_kernel, dim3(1), dim3(64), 0, nullptr, h->rows.as<uint8_t>(), (uint32_t)h->ds,
                        (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
-                       h->vp.distance_type, h->vp.invert, i, j, tmp.as<float>());
+                       h->vp.distance_type, h->vp.invert, i, j, res);
     QAMD_HIP(hipGetLastError());
+    if (hs.host) {
+        QAMD_HIP(hipStreamSynchronize(nullptr));
+        memcpy(out, hs.host + 1024, 4);
+        return QAMD_OK;
+    }
     return copy_out(out, QAMD_MEM_HOST, tmp.ptr, 4, nullptr);
 }
 

@@ -1285,6 +1285,23 @@ qamd_status qamd_u8_score_ids(const qamd_u8 *h, const qamd_u8_query *q, const ui
     hipStream_t s = as_stream(stream);
     DevBuf ids_tmp, out_tmp;
     const uint32_t *ids_dev = ids;
+    // per-pair granularity (score_point and friends): ids and results through the calling
+    // thread's mapped host scratch -- no allocation, no copy calls
+    const HostScratch hs = (ids_mem == QAMD_MEM_HOST && out_mem == QAMD_MEM_HOST && n_ids <= 1024) ? host_scratch()
+                                                                                                  : HostScratch{};
+    if (hs.host) {
+        for (uint64_t k = 0; k < n_ids; k++) {
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+            hs.host[k] = ids[k];
+        }
+        QAMD_TRY(score_ids_dev(h, reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16), q->buf.as<float>(), 0.0f,
+                               EPI_POINT, hs.dev, n_ids, reinterpret_cast<float *>(hs.dev + 1024), s));
+        QAMD_HIP(hipStreamSynchronize(s));
+        memcpy(out, hs.host + 1024, n_ids * 4);
+        return QAMD_OK;
+    }
     if (ids_mem == QAMD_MEM_HOST) {
         for (uint64_t k = 0; k < n_ids; k++)
             if (ids[k] >= h->count)  // the reference panics here (encoded_storage.rs:29)
@@ -1318,11 +1335,19 @@ qamd_status qamd_u8_score_internal(const qamd_u8 *h, uint32_t i, uint32_t j, flo
     // :389-395  diff = actual_dim*offset*offset (negated if invert)
     float diff = (float)h->meta.actual_dim * h->meta.offset * h->meta.offset;
     if (h->meta.vector_parameters.invert) diff = -diff;
+    const uint4 *qc = h->codes.as<uint4>() + (uint64_t)i * h->row_chunks;
+    const float *qo = h->offsets.as<float>() + i;
+    const HostScratch hs = host_scratch();
+    if (hs.host) {
+        hs.host[0] = j;
+        QAMD_TRY(score_ids_dev(h, qc, qo, diff, EPI_INTERNAL, hs.dev, 1, reinterpret_cast<float *>(hs.dev + 1024), nullptr));
+        QAMD_HIP(hipStreamSynchronize(nullptr));
+        memcpy(out, hs.host + 1024, 4);
+        return QAMD_OK;
+    }
     DevBuf tmp;
     QAMD_TRY(tmp.alloc(16));
     QAMD_TRY(copy_in(tmp.ptr, &j, QAMD_MEM_HOST, 4, nullptr));
-    const uint4 *qc = h->codes.as<uint4>() + (uint64_t)i * h->row_chunks;
-    const float *qo = h->offsets.as<float>() + i;
     QAMD_TRY(score_ids_dev(h, qc, qo, diff, EPI_INTERNAL, tmp.as<uint32_t>(), 1, tmp.as<float>() + 1, nullptr));
     return copy_out(out, QAMD_MEM_HOST, tmp.as<float>() + 1, 4, nullptr);
 }
