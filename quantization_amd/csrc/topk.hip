@@ -352,8 +352,15 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
         unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + off_cand);
         float *sample = reinterpret_cast<float *>(ws + off_sample);
         uint32_t *ids = reinterpret_cast<uint32_t *>(ws + off_ids);
-        uint32_t *ids_dev = out_mem == QAMD_MEM_DEVICE ? out_ids : reinterpret_cast<uint32_t *>(ws + off_out);
-        float *sc_dev = out_mem == QAMD_MEM_DEVICE ? out_scores : reinterpret_cast<float *>(ws + off_out) + k;
+        // host outputs: the emit kernel writes them into the calling thread's mapped host scratch
+        // (k <= 1024 ids + 1024 scores fit), so the status read below is the call's only copy
+        const HostScratch hs = out_mem == QAMD_MEM_HOST ? host_scratch() : HostScratch{};
+        uint32_t *ids_dev = out_mem == QAMD_MEM_DEVICE ? out_ids
+                            : hs.host               ? hs.dev
+                                                    : reinterpret_cast<uint32_t *>(ws + off_out);
+        float *sc_dev = out_mem == QAMD_MEM_DEVICE ? out_scores
+                        : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
+                                                : reinterpret_cast<float *>(ws + off_out) + k;
         hipLaunchKernelGGL(sample_ids_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, ids, S, n);
         qamd_status stt = scan.score_ids(ids, S, sample, stream);
         if (stt == QAMD_OK) {
@@ -375,8 +382,13 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
                     (unsigned long long)n, k, r, dbg.pivot_key, dbg.total, dbg.status);
         }
         if (stt == QAMD_OK && status == 0 && out_mem == QAMD_MEM_HOST) {
-            stt = copy_out(out_ids, QAMD_MEM_HOST, ids_dev, (size_t)k * 4, stream);
-            if (stt == QAMD_OK) stt = copy_out(out_scores, QAMD_MEM_HOST, sc_dev, (size_t)k * 4, stream);
+            if (hs.host) {  // the stream was synchronised by the status read
+                memcpy(out_ids, hs.host, (size_t)k * 4);
+                memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
+            } else {
+                stt = copy_out(out_ids, QAMD_MEM_HOST, ids_dev, (size_t)k * 4, stream);
+                if (stt == QAMD_OK) stt = copy_out(out_scores, QAMD_MEM_HOST, sc_dev, (size_t)k * 4, stream);
+            }
         }
         (void)hipFreeAsync(ws, stream);
         if (stt != QAMD_OK) return stt;
@@ -402,14 +414,21 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
     QAMD_HIP(hipMallocAsync(&ws, ws_bytes + extra, stream));
     uint32_t *ids_dev = out_ids;
     float *sc_dev = out_scores;
+    const HostScratch hs = out_mem == QAMD_MEM_HOST ? host_scratch() : HostScratch{};
     if (out_mem == QAMD_MEM_HOST) {
-        ids_dev = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes);
-        sc_dev = reinterpret_cast<float *>(ids_dev + k);
+        ids_dev = hs.host ? hs.dev : reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes);
+        sc_dev = hs.host ? reinterpret_cast<float *>(hs.dev + 1024) : reinterpret_cast<float *>(ids_dev + k);
     }
     qamd_status st = topk_f32(scores_dev, n, k, largest != 0, ids_dev, sc_dev, ws, stream);
     if (st == QAMD_OK && out_mem == QAMD_MEM_HOST) {
-        st = copy_out(out_ids, QAMD_MEM_HOST, ids_dev, (size_t)k * 4, stream);
-        if (st == QAMD_OK) st = copy_out(out_scores, QAMD_MEM_HOST, sc_dev, (size_t)k * 4, stream);
+        if (hs.host) {
+            if (hipStreamSynchronize(stream) != hipSuccess) st = fail(QAMD_ERR_DEVICE, "top-k: stream synchronisation failed");
+            memcpy(out_ids, hs.host, (size_t)k * 4);
+            memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
+        } else {
+            st = copy_out(out_ids, QAMD_MEM_HOST, ids_dev, (size_t)k * 4, stream);
+            if (st == QAMD_OK) st = copy_out(out_scores, QAMD_MEM_HOST, sc_dev, (size_t)k * 4, stream);
+        }
     }
     (void)hipFreeAsync(ws, stream);
     return st;
