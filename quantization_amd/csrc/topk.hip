@@ -213,23 +213,21 @@ struct FusedState {
     uint32_t counters[kTopkShards * kTopkCounterStride];  // one per shard, 256 bytes apart
 };
 
-// One workgroup picks the pivot from the S = 16384 sample scores.  ANY pivot is correct (the
+// One workgroup picks the pivot from the S sample scores (16384 .. 131072).  ANY pivot is correct (the
 // final selection is exact); it only has to let roughly `target` rows through.  Each thread
-// takes the best of its 16 strided samples and the r-th best of those 1024 per-thread bests is
+// takes the best of its S/1024 strided samples and the r-th best of those 1024 per-thread bests is
 // the pivot (for r << 1024 the r best samples sit in different threads with high probability,
 // so this is the sample's r-th best up to a rank or two).  The 1024 bests are bitonic-sorted
 // in LDS (55 stages).  A 32-round bisection and a rank-counting loop both measured ~60 us on
 // the single CU this runs on; this form is a few us.
 __global__ __launch_bounds__(1024) void pivot_kernel(const float *__restrict__ sample, uint32_t S, uint32_t r,
                                                     int largest, FusedState *st) {
-    constexpr int PER = kTopkSample / 1024;
     __shared__ uint32_t best[1024];
     const int t = threadIdx.x;
     uint32_t mine = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        const uint32_t i = t + 1024u * j;
-        const uint32_t key = i < S ? topk_ordered_bits(sample[i], largest != 0) : 0xFFFFFFFFu;
+#pragma unroll 4
+    for (uint32_t i = t; i < S; i += 1024u) {
+        const uint32_t key = topk_ordered_bits(sample[i], largest != 0);
         mine = key < mine ? key : mine;
     }
     best[t] = mine;
@@ -335,9 +333,13 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
                        qamd_mem out_mem, hipStream_t stream, const FusedScan &scan) {
     if (k == 0) return QAMD_OK;
     if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
-    const uint32_t S = kTopkSample;
-    // expected candidates ~ max(2048, 3k): the pivot is (about) the r-th best of the sample.
+    // expected candidates ~ max(2048, 3k): the pivot is (about) the r-th best of the sample, so the
+    // count of rows at least as good is ~ n*Beta(r, S-r+1): mean n*r/S, relative spread 1/sqrt(r).
+    // The sample grows with n to keep r near 8 (a fixed 16384-row sample has r = 4 at 10M rows --
+    // one overflow of the 8192 candidate slots per ~1600 queries -- and r = 1 at 100M, where the
+    // filter pass was wasted almost every time).
     const double target = std::max<double>(2048.0, 3.0 * k);
+    const uint32_t S = (uint32_t)std::min<double>(131072.0, std::max<double>(kTopkSample, round_up((uint64_t)(8.0 * (double)n / target), 1024)));
     const uint32_t r = (uint32_t)std::ceil((double)S * target / (double)n);
     // Small stores: sampling buys nothing (and r must stay << 1024 for the pivot rule) —
     // classic path (scores + exact radix select).

@@ -24,7 +24,7 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);
 
 // Fused scan + selection: the scan never materialises the score array.
-//   1. score kTopkSample (16384) pseudo-randomly chosen rows (random-access kernel),
+//   1. score S pseudo-randomly chosen rows (random-access kernel; S = 16384 .. 131072, growing with n),
 //   2. take the r-th best sample as pivot so that ~max(2048, 3k) rows are expected to pass,
 //   3. run the scan in FILTER mode: rows at least as good as the pivot are appended to a
 //      candidate buffer (8192 slots),
