@@ -1,0 +1,27 @@
+"""One-off stress check: binary store of 400M x 256 bits (u32 row ids near their limit are not
+reached, but offsets pass 2^32 bytes and the tie-heavy top-k paths are exercised)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import quantization_amd as qa
+dev = torch.device("cuda", 0)
+n, dim = 400_000_000, 256
+g = torch.Generator(device=dev); g.manual_seed(3)
+rows = torch.randint(0, 256, (n, dim // 8), generator=g, device=dev, dtype=torch.uint8)
+vp = qa.VectorParameters(dim, n, qa.DistanceType.Dot, False)
+enc = qa.EncodedVectorsBin.from_storage(rows, vp)
+del rows
+q = enc.encode_query(torch.randn(dim, generator=g, device=dev))
+out = torch.empty(n, dtype=torch.float32, device=dev)
+t0 = time.perf_counter(); enc.score_all(q, out=out); torch.cuda.synchronize(); t1 = time.perf_counter()
+ids, sc = enc.topk(q, 50)
+best = torch.topk(out, 50).values.cpu().numpy()
+ok_scores = np.array_equal(np.sort(sc)[::-1], best)
+ok_ids = np.array_equal(out[torch.from_numpy(ids.astype(np.int64)).to(dev)].cpu().numpy(), sc)
+# tie rule: among equal scores ids ascend
+ok_ties = all(ids[i] < ids[i + 1] for i in range(49) if sc[i] == sc[i + 1])
+# exact set check at the boundary score: ids with score == sc[-1] must be the lowest such ids
+b = float(sc[-1]); cnt_b = int((sc == b).sum())
+lowest = torch.nonzero(out == b)[:cnt_b, 0].cpu().numpy()
+ok_boundary = np.array_equal(np.sort(ids[sc == b]), lowest.astype(np.uint32))
+print(f"binary {n} x {dim}: scan {1e3*(t1-t0):.2f} ms; topk scores {ok_scores}, ids consistent {ok_ids}, tie order {ok_ties}, boundary ids {ok_boundary}")
