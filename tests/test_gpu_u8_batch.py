@@ -137,3 +137,20 @@ def test_topk_batch_small_batch_scan(nq, dim):
             wi, ws = enc.topk(enc.encode_query(queries[qi]), 40, largest=largest)
             assert np.array_equal(ids[qi], wi), (dist, qi)
             assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32))
+
+
+def test_batch_degenerate_store_constant_data():
+    """All values equal: alpha = 0, multiplier = 0 (and 0/0 codes): the integer pre-filter has no
+    usable bound, the batch runs on the first kernel; results still equal the single-query path."""
+    n, dim, nq, k = 3000, 192, 130, 7
+    data = np.full((n, dim), 0.25, dtype=np.float32)
+    queries = np.random.default_rng(2).random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    b = enc.encode_query_batch(queries)
+    got = enc.score_batch(b)
+    ids, sc = enc.topk_batch(b, k)
+    for qi in (0, 64, nq - 1):
+        qobj = enc.encode_query(queries[qi])
+        assert_bits_equal(got[qi], enc.score_all(qobj), f"query {qi}")
+        want_ids, want_sc = enc.topk(qobj, k)
+        assert np.array_equal(ids[qi], want_ids) and np.array_equal(sc[qi].view(np.uint32), want_sc.view(np.uint32))
