@@ -1022,12 +1022,16 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     hipStream_t s = as_stream(stream);
     const uint64_t Q = b->n_queries, n = h->count;
     // Pivot rank r of S sampled rows: the number of rows at least as good as the pivot is about
-    // n*Beta(r, S-r+1): mean n*r/S = target, relative spread 1/sqrt(r).  With many queries per call the
-    // tails matter (a list that overflows kBatchCap or holds fewer than k sends its query to the
-    // exact single-query path, milliseconds each): S grows with n so that r stays near 16
-    // (r = 4 at 10M rows overflowed 8192 slots about once per 1600 queries: 0.6 per 1024-query call).
-    const double target = std::max<double>(2048.0, 3.0 * k);
-    const uint32_t S = (uint32_t)std::min<double>(262144.0, std::max<double>(kTopkSample, round_up((uint64_t)(16.0 * (double)n / target), 256)));
+    // n*Beta(r, S-r+1): mean n*r/S, relative spread 1/sqrt(r).  With many queries per call both tails
+    // matter (a list that overflows kBatchCap or holds fewer than k rows sends its query to the exact
+    // single-query path, milliseconds each), and so does the mean: every passing (query, row) pair
+    // costs an exact epilogue + a list append inside the GEMM (2048 expected per query instead of 512
+    // measured +7..10 % on the whole call).  So: about max(512, 3k) rows expected to pass at pivot
+    // rank >= 8 (P(fewer than k) < 1e-7, P(more than 8192) ~ 0); S = 8 n / that, capped at 524288
+    // sampled rows (beyond 33M rows the expected count grows instead of r shrinking).
+    const double want = std::max<double>(512.0, 3.0 * k);
+    const uint32_t S = (uint32_t)std::min<double>(524288.0, std::max<double>(kTopkSample, round_up((uint64_t)(8.0 * (double)n / want), 256)));
+    const double target = std::max<double>(want, 8.0 * (double)n / (double)S);
     const uint32_t r = n ? (uint32_t)std::ceil((double)S * target / (double)n) : 0;
     const bool fused = n >= (1u << 20) && r <= 64 && h->meta.vector_parameters.distance_type != QAMD_L1;
 
