@@ -141,7 +141,7 @@ if "batch" in which:
             batch = enc.encode_query_batch(queries)
             ids = torch.empty(nq * 30, dtype=torch.int32, device=dev)
             sc = torch.empty(nq * 30, dtype=torch.float32, device=dev)
-            med, mn = timeit(lambda: enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc), reps=5, warm=1)
+            med, mn = timeit(lambda: enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc), reps=9, warm=12)
             ops = 2.0 * nq * n * enc.metadata["actual_dim"]
             print(json.dumps({"kernel": f"u8_topk_batch k30 dim{dim}", "rows": n, "queries": nq,
                               "median_ms": round(med, 3), "min_ms": round(mn, 3),
