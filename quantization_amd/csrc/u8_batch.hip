@@ -1047,59 +1047,84 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     std::vector<uint32_t> status(Q, 1);
     if (fused) {
         const uint64_t ad = h->meta.actual_dim;
-        StreamBuf s_codes, s_offs, s_scores, pivots, counters, cand, status_dev;
-        QAMD_TRY(s_codes.alloc((uint64_t)(S + 512) * ad, s, true));  // + one (largest) tile of zero rows
-        QAMD_TRY(s_offs.alloc((uint64_t)(S + 512) * 4, s, true));
-        QAMD_TRY(s_scores.alloc(Q * (uint64_t)S * 4, s));
-        QAMD_TRY(pivots.alloc(b->q_pad * 4, s, true));
-        QAMD_TRY(counters.alloc(b->q_pad * kCounterStride * 4, s, true));
-        QAMD_TRY(cand.alloc(Q * (uint64_t)kBatchCap * 8, s));
-        QAMD_TRY(status_dev.alloc(Q * 4, s));
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->codes.as<uint4>(),
-                           h->offsets.as<float>(), h->row_chunks, n, S, s_codes.as<uint4>(), s_offs.as<float>());
-        QAMD_TRY(launch_gemm<0>(h, b, s_codes.as<uint8_t>(), s_offs.as<float>(), S, s_scores.as<float>(), S,
-                                BatchFilter{}, s));
-        hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores.as<float>(), S,
-                           (uint64_t)S, r, largest, (uint32_t)Q, pivots.as<float>(), counters.as<uint32_t>());
-        BatchFilter f{};
-        f.pivot_scores = pivots.as<float>();
-        f.counters = counters.as<uint32_t>();
-        f.candidates = cand.as<unsigned long long>();
-        f.largest = largest;
+        // ONE stream-ordered allocation for all scratch of the call, carved up below: hipFreeAsync
+        // costs ~65 us per buffer on this runtime, and ten buffers were a third of a small batch's time.
         const bool pp = pp_selected(h, b, true);
-        StreamBuf wave_cand, wave_counts, overflow_dev;
-        uint32_t n_lists = 0;
+        uint32_t n_lists = 0, wave_cap = 0;
         if (pp) {
             // wave-private lists: 4x the expected appends per wave (about `target`..2*target per query)
             n_lists = pp_launches(Q) * pp_waves_per_launch();
             const double per_wave = 2.0 * target * (double)Q / (double)n_lists;
-            f.wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(1024.0, 4.0 * per_wave));
-            QAMD_TRY(wave_cand.alloc((uint64_t)n_lists * f.wave_cap * sizeof(uint4), s));
-            QAMD_TRY(wave_counts.alloc((uint64_t)n_lists * 4, s, true));
-            QAMD_TRY(overflow_dev.alloc(4, s, true));
-            f.wave_cand = wave_cand.as<uint4>();
-            f.wave_counts = wave_counts.as<uint32_t>();
+            wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(1024.0, 4.0 * per_wave));
+        }
+        size_t arena_bytes = 0;
+        auto reserve = [&](size_t bytes) {
+            const size_t off = arena_bytes;
+            arena_bytes += round_up(std::max<size_t>(bytes, 16), 256);
+            return off;
+        };
+        // zero-initialised part first (one memset): pivots, counters, wave counts, overflow flag
+        const size_t o_pivots = reserve(b->q_pad * 4);
+        const size_t o_counters = reserve(b->q_pad * kCounterStride * 4);
+        const size_t o_wcounts = reserve((uint64_t)n_lists * 4);
+        const size_t o_overflow = reserve(4);
+        const size_t zero_bytes = arena_bytes;
+        const size_t o_codes = reserve((uint64_t)(S + 512) * ad);  // + one (largest) tile of zero rows
+        const size_t o_offs = reserve((uint64_t)(S + 512) * 4);
+        const size_t o_scores = reserve(Q * (uint64_t)S * 4);
+        const size_t o_cand = reserve(Q * (uint64_t)kBatchCap * 8);
+        const size_t o_status = reserve(Q * 4);
+        const size_t o_wcand = reserve((uint64_t)n_lists * wave_cap * sizeof(uint4));
+        StreamBuf arena;
+        QAMD_TRY(arena.alloc(arena_bytes, s));
+        char *base = arena.as<char>();
+        QAMD_HIP(hipMemsetAsync(base, 0, zero_bytes, s));
+        QAMD_HIP(hipMemsetAsync(base + o_codes + (uint64_t)S * ad, 0, (uint64_t)512 * ad, s));  // the padding tile
+        QAMD_HIP(hipMemsetAsync(base + o_offs + (uint64_t)S * 4, 0, 512 * 4, s));
+        uint8_t *s_codes = reinterpret_cast<uint8_t *>(base + o_codes);
+        float *s_offs = reinterpret_cast<float *>(base + o_offs);
+        float *pivots = reinterpret_cast<float *>(base + o_pivots);
+        uint32_t *counters = reinterpret_cast<uint32_t *>(base + o_counters);
+        uint32_t *wave_counts = reinterpret_cast<uint32_t *>(base + o_wcounts);
+        uint32_t *overflow_dev = reinterpret_cast<uint32_t *>(base + o_overflow);
+        float *s_scores = reinterpret_cast<float *>(base + o_scores);
+        unsigned long long *cand = reinterpret_cast<unsigned long long *>(base + o_cand);
+        uint32_t *status_dev = reinterpret_cast<uint32_t *>(base + o_status);
+        uint4 *wave_cand = reinterpret_cast<uint4 *>(base + o_wcand);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->codes.as<uint4>(),
+                           h->offsets.as<float>(), h->row_chunks, n, S, reinterpret_cast<uint4 *>(s_codes), s_offs);
+        QAMD_TRY(launch_gemm<0>(h, b, s_codes, s_offs, S, s_scores, S, BatchFilter{}, s));
+        hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores, S, (uint64_t)S, r,
+                           largest, (uint32_t)Q, pivots, counters);
+        BatchFilter f{};
+        f.pivot_scores = pivots;
+        f.counters = counters;
+        f.candidates = cand;
+        f.largest = largest;
+        if (pp) {
+            f.wave_cap = wave_cap;
+            f.wave_cand = wave_cand;
+            f.wave_counts = wave_counts;
         }
         if (largest)
             QAMD_TRY(launch_gemm<1>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
         else
             QAMD_TRY(launch_gemm<2>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
         if (pp)
-            hipLaunchKernelGGL(wave_scatter_kernel, dim3(n_lists), dim3(256), 0, s, wave_cand.as<uint4>(),
-                               wave_counts.as<uint32_t>(), f.wave_cap, counters.as<uint32_t>(),
-                               cand.as<unsigned long long>(), overflow_dev.as<uint32_t>());
-        hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand.as<unsigned long long>(),
-                           counters.as<uint32_t>(), n, k, largest, ids_dev, sc_dev, status_dev.as<uint32_t>());
+            hipLaunchKernelGGL(wave_scatter_kernel, dim3(n_lists), dim3(256), 0, s, wave_cand, wave_counts, f.wave_cap,
+                               counters, cand, overflow_dev);
+        hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand, counters, n, k, largest, ids_dev,
+                           sc_dev, status_dev);
         QAMD_HIP(hipGetLastError());
-        QAMD_TRY(copy_out(status.data(), QAMD_MEM_HOST, status_dev.ptr, Q * 4, s));  // synchronises
+        QAMD_TRY(copy_out(status.data(), QAMD_MEM_HOST, status_dev, Q * 4, s));  // synchronises
         if (pp) {
             uint32_t overflow = 0;
-            QAMD_TRY(copy_out(&overflow, QAMD_MEM_HOST, overflow_dev.ptr, 4, s));
+            QAMD_TRY(copy_out(&overflow, QAMD_MEM_HOST, overflow_dev, 4, s));
             if (overflow) std::fill(status.begin(), status.end(), 1u);  // a wave list overflowed: redo all exactly
         }
         if (getenv("QAMD_DEBUG_TOPK")) {
             std::vector<uint32_t> cnt(b->q_pad * kCounterStride);
-            (void)hipMemcpy(cnt.data(), counters.ptr, cnt.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(cnt.data(), counters, cnt.size() * 4, hipMemcpyDeviceToHost);
             uint32_t mx = 0, mn = ~0u, redo = 0;
             uint64_t sum = 0;
             for (uint64_t q = 0; q < Q; q++) {
