@@ -10,21 +10,25 @@
 // ((multiplier*s)+q.offset)+vector_offset (encoded_vectors_u8.rs:347), so every score is
 // bit-identical to qamd_u8_score_all for that query (integer sum rounded once).
 //
-// Kernel (u8_gemm_kernel): workgroup tile 128 queries x 128 rows, 4 waves (2 x 2), each wave
-// 64 x 64 = 2 x 2 tiles of v_mfma_i32_32x32x32_i8.  Both operands are K-contiguous in memory
-// (queries [Q][D], store rows [N][D]) and the MFMA K index is only a summation index, so lane
-// (r, h) simply takes bytes [32s + 16h, +16) of query/row r in k-step s: fragments are plain
-// 16-byte pieces, no transposition anywhere.  K is walked in 128-byte slabs staged through LDS
-// with whole-line coalesced global loads (8 lanes x 16 B per row), register-staged double
-// buffering (next slab's global loads fly during the MFMAs, one barrier per slab), rows padded
-// by 16 B in LDS (144-B pitch: ds_read_b128 of 16 rows hits 16 distinct 4-bank slots).
-// Workgroups that share a row tile run on one XCD back to back (blockIdx -> tile map), so the
-// row tile comes from HBM once and from that XCD's L2 for the other query tiles.
+// Both operands are K-contiguous in memory (queries [Q][pitch], store rows [N][D]) and the MFMA
+// K index is only a summation index, so lane (r, h) simply takes bytes [32s + 16h, +16) of
+// query/row r in k-step s: fragments are plain 16-byte pieces, no transposition anywhere.
 //
-// Top-k per query is fused exactly as in topk.hip: pivot per query from 16384 sampled rows
-// (scored by this same kernel on a gathered sub-store), FILTER epilogue appending to per-query
-// candidate lists, one workgroup per query sorting its list; queries whose list over/underflows
-// are redone through the exact single-query path.
+// Two kernels (launch_gemm picks):
+//   * u8_gemm_pp_kernel<MODE, LOW, MI, MJ> -- the main one: persistent workgroups, LDS-DMA ring,
+//     two wave groups half a phase apart, integer pre-filter folded into the accumulators,
+//     wave-private candidate lists.  Described above its definition.
+//   * u8_gemm_kernel<MODE, TQ, TR, WQ, WR, BK> -- the first version (128-byte K slabs through
+//     registers -> ds_write -> LDS at a 144-byte pitch, one barrier per slab, float-compare filter,
+//     per-query global atomics); now only for rows of fewer than three 64-byte K-tiles, a
+//     zero / non-finite multiplier, and the developer switch QAMD_GEMM_CFG.
+// In both, the workgroups that share a row tile run on one XCD, so a row tile comes from HBM
+// once and from that XCD's L2 for the other query tiles (measured: 1.03x the store bytes).
+//
+// Top-k per query is fused as in topk.hip: a pivot per query from S sampled rows (scored by the
+// same kernel on a gathered sub-store; S grows with the store, see qamd_u8_topk_batch), a filter
+// pass appending candidates, one workgroup per query sorting its list; queries whose list
+// over/underflows are redone through the exact single-query path.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
