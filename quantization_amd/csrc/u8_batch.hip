@@ -71,7 +71,9 @@ struct BatchFilter {
 // Developer timeline (tools/gemm_timeline.py): when set, lane 0 of every wave of the first 4096
 // workgroups stores s_memtime at the phase boundaries, 16 slots per wave.
 __device__ unsigned long long *g_gemm_stamps = nullptr;
+#ifdef QAMD_GEMM_ABLATION  // developer builds only (make EXTRA=-DQAMD_GEMM_ABLATION): the shipped library has no such switch
 __device__ unsigned int g_gemm_dbg = 0;  // TIMING EXPERIMENTS ONLY (results are wrong when set): bit0 skip A DMA, bit1 skip B DMA
+#endif
 constexpr uint32_t kStampBlocks = 4096;
 
 // S[q][row] for the tile; MODE 0: write scores out[q * out_pitch + row]; MODE 1 / 2: filter for the
@@ -430,7 +432,11 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     const uint8_t *src_b = codes + ((uint64_t)first * TR + dma_row) * ad + dma_chunk;
     const uint64_t tile_stride_b = (uint64_t)step * TR * ad, half_b = (uint64_t)128 * ad, half_a = (uint64_t)128 * q_pitch;
     uint32_t pf_kt = 0, pf_koff = 0, pf_u = 0, pf_slot = 0;  // pf_slot = pf_u % RING
+#ifdef QAMD_GEMM_ABLATION
     const uint32_t dbgf = g_gemm_dbg;
+#else
+    constexpr uint32_t dbgf = 0;
+#endif
     auto issue_B = [&](uint32_t idx_lo, uint32_t idx_hi) {
         const uint8_t *src = src_b + pf_koff;
         uint8_t *dst = lds_raw + pf_slot * SLOT + wave * 1024;
@@ -935,10 +941,12 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
 
 extern "C" {
 
+#ifdef QAMD_GEMM_ABLATION
 QAMD_API qamd_status qamd_dev_gemm_debug(unsigned int flags) {
     QAMD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &flags, sizeof(flags)));
     return QAMD_OK;
 }
+#endif
 
 // Developer hook: device buffer of kStampBlocks * 8 * 16 u64 (or null to switch the timeline off).
 QAMD_API qamd_status qamd_dev_gemm_stamps(void *dev_buffer) {

@@ -27,7 +27,7 @@ WAVES = int(os.environ.get("WAVES", 8))
 for _ in range(2):
     enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc)
 torch.cuda.synchronize()
-if os.environ.get("DBG"):
+if os.environ.get("DBG"):  # ablations need a library built with `make EXTRA=-DQAMD_GEMM_ABLATION`
     L.qamd_dev_gemm_debug.argtypes = [C.c_uint]
     L.qamd_dev_gemm_debug(int(os.environ["DBG"]))
 stamps = torch.zeros(4096 * WAVES * 16, dtype=torch.int64, device=dev)
