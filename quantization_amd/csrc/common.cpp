@@ -132,6 +132,50 @@ HostScratch host_scratch() {
     return hs;
 }
 
+namespace {
+struct ThreadWs {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int dev = -1;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+ThreadWs &thread_ws(ThreadWsSlot slot) {
+    static thread_local ThreadWs ws[WS_SLOTS];
+    return ws[slot];
+}
+}  // namespace
+
+qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out) {
+    ThreadWs &w = thread_ws(slot);
+    int dev = 0;
+    QAMD_HIP(hipGetDevice(&dev));
+    if (bytes == 0) bytes = 16;
+    if (w.dev != dev || w.bytes < bytes) {
+        if (w.ptr && w.dev == dev) {
+            if (w.pending) (void)hipEventSynchronize(w.done);
+            (void)hipFree(w.ptr);
+        }
+        w.ptr = nullptr;
+        w.bytes = 0;
+        w.pending = false;
+        if (w.dev != dev) w.done = nullptr;  // an event belongs to the device it was created on
+        const size_t want = bytes + bytes / 4;  // head room: stores grow, k varies
+        QAMD_HIP(hipMalloc(&w.ptr, want));
+        w.bytes = want;
+        w.dev = dev;
+        if (!w.done) QAMD_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    }
+    if (w.pending) QAMD_HIP(hipStreamWaitEvent(s, w.done, 0));
+    *out = w.ptr;
+    return QAMD_OK;
+}
+
+void thread_ws_release(ThreadWsSlot slot, hipStream_t s) {
+    ThreadWs &w = thread_ws(slot);
+    if (w.ptr && w.done && hipEventRecord(w.done, s) == hipSuccess) w.pending = true;
+}
+
 const DeviceInfo &device_info() {
     static DeviceInfo info;
     static std::once_flag once;

@@ -96,6 +96,15 @@ struct HostScratch {
 };
 HostScratch host_scratch();
 
+// Grow-only device workspaces per calling thread (and device), handed from call to call in
+// stream order: release() records an event on the call's stream, the next acquire() makes its own
+// stream wait on it.  For the whole-store calls' scratch (score vector of a top-k, radix-select
+// state, PQ partial sums): hipMallocAsync + hipFreeAsync cost ~70 us per buffer and call on this
+// runtime, which is most of a top-k on a small store.  Never freed (see host_scratch).
+enum ThreadWsSlot { WS_SCORES = 0, WS_SELECT = 1, WS_PARTIAL = 2, WS_SLOTS = 3 };
+qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out);
+void thread_ws_release(ThreadWsSlot slot, hipStream_t s);
+
 struct DeviceInfo {
     int cu_count = 256;
 };

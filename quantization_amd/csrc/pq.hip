@@ -530,7 +530,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     float *partial = nullptr;
     if (n_slices > 1) {
         const uint64_t padded = round_up(n, kRowPad) + kRowPad;
-        QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&partial), padded * 16, s));
+        QAMD_TRY(thread_ws_acquire(WS_PARTIAL, padded * 16, s, reinterpret_cast<void **>(&partial)));
     }
     for (uint32_t sl = 0; sl < n_slices; sl++) {
         const uint32_t piece0 = sl * per, nvs = std::min(per, pieces - piece0);
@@ -562,7 +562,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         }
 #undef QAMD_PQ_FAST
     }
-    if (partial) (void)hipFreeAsync(partial, s);
+    if (partial) thread_ws_release(WS_PARTIAL, s);
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;
 }
@@ -1106,10 +1106,10 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
     const float *lut = q->lut.as<float>();
     if (!fast_capable(h, h->count)) {
         float *scores = nullptr;
-        QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+        QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));
         qamd_status st = scan_launch(h, lut, nullptr, h->count, scores, s);
         if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
-        (void)hipFreeAsync(scores, s);
+        thread_ws_release(WS_SCORES, s);
         return st;
     }
     FusedScan scan;

@@ -181,7 +181,7 @@ qamd_status select_kth_f32(const float *vals_dev, uint64_t n, uint64_t k, bool l
                            hipStream_t stream) {
     if (n == 0 || k == 0 || k > n || n > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "select_kth: bad k or n");
     SelState *st = nullptr;
-    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&st), sizeof(SelState), stream));
+    QAMD_TRY(thread_ws_acquire(WS_SELECT, sizeof(SelState), stream, reinterpret_cast<void **>(&st)));
     hipLaunchKernelGGL(init_kernel, dim3(1), dim3(256), 0, stream, st, (uint32_t)k);
     uint64_t want = (n + kBlock * 8 - 1) / (kBlock * 8);
     uint64_t cap = (uint64_t)device_info().cu_count * 8;
@@ -193,7 +193,7 @@ qamd_status select_kth_f32(const float *vals_dev, uint64_t n, uint64_t k, bool l
     unsigned long long prefix = 0;
     qamd_status r = hipGetLastError() == hipSuccess ? QAMD_OK : fail(QAMD_ERR_DEVICE, "select_kth launch failed");
     if (r == QAMD_OK) r = copy_out(&prefix, QAMD_MEM_HOST, &st->prefix, 8, stream);
-    (void)hipFreeAsync(st, stream);
+    thread_ws_release(WS_SELECT, stream);
     if (r != QAMD_OK) return r;
     uint32_t u = (uint32_t)(prefix >> 32);  // invert ordered_bits()
     if (largest) u = ~u;
@@ -410,10 +410,10 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
         // fall through: pivot missed (heavy ties / adversarial order) -> exact classic path
     }
     float *scores = nullptr;
-    QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(n, 1) * 4, stream));
+    QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(n, 1) * 4, stream, reinterpret_cast<void **>(&scores)));
     qamd_status st2 = scan.scan_scores(scores, stream);
     if (st2 == QAMD_OK) st2 = topk_finish(scores, n, k, largest, out_ids, out_scores, out_mem, stream);
-    (void)hipFreeAsync(scores, stream);
+    thread_ws_release(WS_SCORES, stream);
     return st2;
 }
 
@@ -425,7 +425,7 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
     void *ws = nullptr;
     size_t ws_bytes = round_up(topk_workspace_bytes(k), 256);
     size_t extra = out_mem == QAMD_MEM_HOST ? (size_t)k * 8 : 0;
-    QAMD_HIP(hipMallocAsync(&ws, ws_bytes + extra, stream));
+    QAMD_TRY(thread_ws_acquire(WS_SELECT, ws_bytes + extra, stream, &ws));
     uint32_t *ids_dev = out_ids;
     float *sc_dev = out_scores;
     const HostScratch hs = out_mem == QAMD_MEM_HOST ? host_scratch() : HostScratch{};
@@ -444,7 +444,7 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
             if (st == QAMD_OK) st = copy_out(out_scores, QAMD_MEM_HOST, sc_dev, (size_t)k * 4, stream);
         }
     }
-    (void)hipFreeAsync(ws, stream);
+    thread_ws_release(WS_SELECT, stream);
     return st;
 }
 

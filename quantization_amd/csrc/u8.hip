@@ -1368,10 +1368,10 @@ qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, i
     };
     if (!fused_capable(h)) {  // rare layouts: classic path only
         float *scores = nullptr;
-        QAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&scores), std::max<uint64_t>(h->count, 1) * 4, s));
+        QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));
         qamd_status st = scan_into(h, q, scores, s);
         if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
-        (void)hipFreeAsync(scores, s);
+        thread_ws_release(WS_SCORES, s);
         return st;
     }
     return fused_topk(h->count, k, largest, out_ids, out_scores, out_mem, s, scan);

@@ -1,0 +1,23 @@
+"""Latency of whole-store calls on SMALL stores (where per-call host overhead, not HBM, decides)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import quantization_amd as qa
+dev = torch.device("cuda", 0)
+for n in (10_000, 100_000, 1_000_000):
+    dim = 768
+    data = torch.rand((n, dim), device=dev)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, qa.DistanceType.Dot, False))
+    q = enc.encode_query(torch.rand(dim, device=dev))
+    out = torch.empty(n, device=dev)
+    ids = torch.empty(30, dtype=torch.int32, device=dev); sc = torch.empty(30, device=dev)
+    qh = np.random.default_rng(0).random(dim, dtype=np.float32)
+    def t(f, reps=300):
+        for _ in range(30): f()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): f()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e6
+    a = t(lambda: enc.score_all(q, out=out))
+    b = t(lambda: enc.topk(q, 30, out_ids=ids, out_scores=sc))
+    c = t(lambda: enc.topk(enc.encode_query(qh), 30))
+    print(f"n={n}: score_all(dev) {a:.1f} us   topk(dev out) {b:.1f} us   encode_query(host)+topk(host out) {c:.1f} us", flush=True)
