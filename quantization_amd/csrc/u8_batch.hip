@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 //        slot 4u-1 and waited for in slot 4u.  (Nothing in the argument depends on RING beyond
 //        "the slot being refilled is the one K-tile u-1 used".)
 // Measured alternatives (in-kernel timeline, tools/gemm_timeline.py): DMA issued inside the MFMA
-// slot: K loop +10 %; one 16-MFMA slot per K-tile and group (half the barriers): K loop +5..15 %
+// slot: K loop +10 % (behind the 4th MFMA) / whole call +1..3 % (behind the 8th); one 16-MFMA slot per K-tile and group (half the barriers): K loop +5..15 %
 // (and the 128-query tile, 8 MFMAs per K-tile in one slot: 2.14-2.59 ms vs 1.87-2.08 for 4..128 queries).
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
