@@ -154,3 +154,48 @@ def test_batch_degenerate_store_constant_data():
         assert_bits_equal(got[qi], enc.score_all(qobj), f"query {qi}")
         want_ids, want_sc = enc.topk(qobj, k)
         assert np.array_equal(ids[qi], want_ids) and np.array_equal(sc[qi].view(np.uint32), want_sc.view(np.uint32))
+
+
+def test_ping_pong_kernel_repeated_runs_are_bit_stable():
+    """The ping-pong kernel orders its LDS-DMA ring with counted waits and raw barriers; an
+    ordering bug would show as rare, timing-dependent wrong scores.  One store, many launches with
+    fresh queries, every score of several queries compared on the device with the single-query scan
+    (both tile shapes: 300 queries -> 256 x 256 tiles, 70 queries -> 128 x 512 tiles)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    n, dim = 700_000, 448  # 7 K-tiles per row, 2735 row tiles: every workgroup walks several tiles
+    data = torch.rand((n, dim), generator=g, device=dev)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L2, False))
+    del data
+    single = torch.empty(n, device=dev)
+    for nq in (300, 70):
+        out = torch.empty((nq, n), device=dev)
+        for it in range(12):
+            queries = torch.rand((nq, dim), generator=g, device=dev)
+            enc.score_batch(enc.encode_query_batch(queries), out=out.view(-1))
+            for qi in (0, nq // 2, nq - 1):
+                enc.score_all(enc.encode_query(queries[qi]), out=single)
+                assert torch.equal(out[qi].view(torch.int32), single.view(torch.int32)), (nq, it, qi)
+
+
+def test_ping_pong_filter_repeated_runs_match_exact_topk():
+    """Same idea for the filter pass (pre-filter in the accumulators, wave-private lists, scatter,
+    per-query sort): repeated launches with fresh queries against the exact single-query top-k."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    n, dim, k = 1_100_000, 320, 20
+    data = torch.rand((n, dim), generator=g, device=dev) - 0.3
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    del data
+    for nq in (300, 70):
+        for it in range(6):
+            queries = torch.rand((nq, dim), generator=g, device=dev) - 0.3
+            ids, sc = enc.topk_batch(enc.encode_query_batch(queries), k, largest=(it % 2 == 0))
+            for qi in (0, nq // 3, nq - 1):
+                want_ids, want_sc = enc.topk(enc.encode_query(queries[qi]), k, largest=(it % 2 == 0))
+                assert np.array_equal(ids[qi], want_ids), (nq, it, qi)
+                assert np.array_equal(sc[qi].view(np.uint32), want_sc.view(np.uint32)), (nq, it, qi)
