@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import quantization_amd as qa
-from tests.util import assert_bits_equal
+from util import assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 D = qa.DistanceType
