@@ -98,3 +98,30 @@ def test_fuzz_pq(qo):
         wi, ws = _topk_want(want, k, False)
         assert np.array_equal(gi[: wi.size], wi), tag + " topk ids"
         assert_bits_equal(gs[: wi.size], ws, tag + " topk scores")
+
+
+def test_fuzz_u8_batch():
+    """score_batch / topk_batch (both MFMA kernels and both tile shapes, chosen by nq and dim)
+    against the single-query path on random shapes."""
+    rng = np.random.default_rng(31337)
+    for case in range(30):
+        n = int(rng.integers(1, 3000))
+        dim = int(rng.integers(1, 600))
+        nq = int(rng.choice([1, 2, 7, 64, 128, 129, 200, 257, 400]))
+        dist = [D.Dot, D.L2][int(rng.integers(0, 2))]
+        invert = bool(rng.integers(0, 2))
+        data = rng.random((n, dim), dtype=np.float32) - np.float32(rng.choice([0.0, 0.4]))
+        queries = rng.random((nq, dim), dtype=np.float32)
+        tag = f"case {case}: n={n} dim={dim} nq={nq} {dist.name} invert={invert}"
+        enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
+        b = enc.encode_query_batch(queries)
+        got = enc.score_batch(b)
+        k = int(rng.integers(1, 20))
+        largest = bool(rng.integers(0, 2))
+        ids, sc = enc.topk_batch(b, k, largest=largest)
+        for qi in sorted({0, nq // 2, nq - 1}):
+            want = enc.score_all(enc.encode_query(queries[qi]))
+            assert_bits_equal(got[qi], want, tag + f" scores of query {qi}")
+            wi, ws = _topk_want(want, k, largest)
+            assert np.array_equal(ids[qi][: wi.size], wi), tag + f" topk ids of query {qi}"
+            assert_bits_equal(sc[qi][: wi.size], ws, tag + f" topk scores of query {qi}")
