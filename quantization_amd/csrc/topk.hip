@@ -338,12 +338,17 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
     // The sample grows with n to keep r near 8 (a fixed 16384-row sample has r = 4 at 10M rows --
     // one overflow of the 8192 candidate slots per ~1600 queries -- and r = 1 at 100M, where the
     // filter pass was wasted almost every time).
-    const double target = std::max<double>(2048.0, 3.0 * k);
-    const uint32_t S = (uint32_t)std::min<double>(131072.0, std::max<double>(kTopkSample, round_up((uint64_t)(8.0 * (double)n / target), 1024)));
+    // Small stores (32k .. 1M rows) take the same route with a smaller sample and fewer expected
+    // candidates: there the classic path's chain of ~10 tiny kernels (score array + four radix
+    // passes + gather + sort) is what a top-k costs, not HBM.
+    const bool small = n < (1u << 20);
+    const double target = std::max<double>(small ? 512.0 : 2048.0, 3.0 * k);
+    const uint32_t S = (uint32_t)std::min<double>(131072.0, std::max<double>(small ? 2048.0 : (double)kTopkSample,
+                                                                             round_up((uint64_t)(8.0 * (double)n / target), 1024)));
     const uint32_t r = (uint32_t)std::ceil((double)S * target / (double)n);
-    // Small stores: sampling buys nothing (and r must stay << 1024 for the pivot rule) —
+    // Tiny stores: sampling buys nothing (and r must stay << 1024 for the pivot rule) --
     // classic path (scores + exact radix select).
-    const bool use_fused = n >= (1u << 20) && r <= 64;
+    const bool use_fused = n >= 32768 && r <= 64;
     char *ws = nullptr;
     const size_t off_state = 0, off_cand = round_up(sizeof(FusedState), 256), off_sample = off_cand + (size_t)kTopkShards * kTopkShardCap * 8,
                  off_ids = off_sample + (size_t)S * 4, off_out = off_ids + (size_t)S * 4,
