@@ -89,7 +89,7 @@ qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t by
 // freed: thread exit may come after the HIP runtime is gone).  The per-pair API calls
 // (score_point, score_internal, small score_ids) put their row ids there and let the kernel
 // write the scores straight back: no allocation, no explicit copy, one launch + one sync.
-constexpr size_t kHostScratchWords = 2048;  // [0, 1024) ids, [1024, 2048) results
+constexpr size_t kHostScratchWords = 2048 + 16;  // [0, 1024) ids, [1024, 2048) results, [2048] a status word
 struct HostScratch {
     uint32_t *host = nullptr;  // what the CPU reads / writes
     uint32_t *dev = nullptr;   // the same memory as the GPU addresses it

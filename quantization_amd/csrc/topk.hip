@@ -259,7 +259,8 @@ __global__ __launch_bounds__(1024) void pivot_kernel(const float *__restrict__ s
 __global__ __launch_bounds__(1024) void fused_emit_kernel(const unsigned long long *__restrict__ cand,
                                                          FusedState *st, uint64_t n, uint32_t k, int largest,
                                                          uint32_t *__restrict__ out_ids,
-                                                         float *__restrict__ out_scores) {
+                                                         float *__restrict__ out_scores,
+                                                         uint32_t *__restrict__ status_host /* mapped host word or null */) {
     __shared__ unsigned long long s[kTopkCandCap];
     __shared__ uint32_t offs[kTopkShards + 1];
     __shared__ uint32_t overflow;
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(1024) void fused_emit_kernel(const unsigned long lo
     const uint32_t pushed = offs[kTopkShards];
     const uint32_t k_eff = n < k ? (uint32_t)n : k;
     if (overflow || pushed > kTopkCandCap || pushed < k_eff) {  // overflow, or the pivot cut below k rows
-        if (t == 0) st->status = 1;
+        if (t == 0) {
+            st->status = 1;
+            if (status_host) *status_host = 1;
+        }
         return;
     }
     uint32_t N = 64;  // sort only the next power of two above the candidate count
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(1024) void fused_emit_kernel(const unsigned long lo
             out_scores[i] = largest ? -__builtin_huge_valf() : __builtin_huge_valf();
         }
     }
+    if (t == 0 && status_host) *status_host = 0;  // (pivot_kernel set st->status = 0)
 }
 
 __global__ void sample_ids_kernel(uint32_t *ids, uint32_t S, uint64_t n) {
@@ -357,15 +362,15 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
         // Workspace (~1 MB) cached per calling thread and device: this path always synchronises
         // before it returns, so the next call may reuse it; hipMallocAsync + hipFreeAsync per call
         // cost ~70 us of a 1.2 ms top-k on this runtime.  (Never freed: see host_scratch.)
-        static thread_local struct { char *p; size_t bytes; int dev; } cache = {nullptr, 0, -1};
+        static thread_local struct { char *p; size_t bytes; int dev; uint64_t ids_n; uint32_t ids_S; size_t ids_off; } cache = {nullptr, 0, -1, 0, 0, 0};
         int dev = 0;
         QAMD_HIP(hipGetDevice(&dev));
         if (cache.dev != dev || cache.bytes < ws_bytes) {
             if (cache.p && cache.dev == dev) (void)hipFree(cache.p);
-            cache = {nullptr, 0, -1};
+            cache = {nullptr, 0, -1, 0, 0, 0};
             void *fresh = nullptr;
             QAMD_HIP(hipMalloc(&fresh, ws_bytes));
-            cache = {static_cast<char *>(fresh), ws_bytes, dev};
+            cache = {static_cast<char *>(fresh), ws_bytes, dev, 0, 0, 0};
         }
         ws = cache.p;
         FusedState *st = reinterpret_cast<FusedState *>(ws + off_state);
@@ -381,7 +386,13 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
         float *sc_dev = out_mem == QAMD_MEM_DEVICE ? out_scores
                         : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
                                                 : reinterpret_cast<float *>(ws + off_out) + k;
-        hipLaunchKernelGGL(sample_ids_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, ids, S, n);
+        // the sample ids depend on (n, S) only: the cached workspace keeps them from call to call
+        if (cache.ids_n != n || cache.ids_S != S || cache.ids_off != off_ids) {
+            hipLaunchKernelGGL(sample_ids_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, ids, S, n);
+            cache.ids_n = n;
+            cache.ids_S = S;
+            cache.ids_off = off_ids;
+        }
         qamd_status stt = scan.score_ids(ids, S, sample, stream);
         if (stt == QAMD_OK) {
             hipLaunchKernelGGL(pivot_kernel, dim3(1), dim3(1024), 0, stream, sample, S, r, largest, st);
@@ -390,10 +401,21 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
         }
         uint32_t status = 1;
         if (stt == QAMD_OK) {
+            // the status word comes back through the thread's mapped host scratch: one stream
+            // synchronisation, no copy call
+            const HostScratch hst = host_scratch();
+            if (hst.host) hst.host[2048] = 1;
             hipLaunchKernelGGL(fused_emit_kernel, dim3(1), dim3(1024), 0, stream, cand, st, n, k, largest, ids_dev,
-                               sc_dev);
+                               sc_dev, hst.host ? hst.dev + 2048 : nullptr);
             stt = hipGetLastError() == hipSuccess ? QAMD_OK : fail(QAMD_ERR_DEVICE, "fused top-k launch failed");
-            if (stt == QAMD_OK) stt = copy_out(&status, QAMD_MEM_HOST, &st->status, 4, stream);  // syncs the stream
+            if (stt == QAMD_OK) {
+                if (hst.host) {
+                    if (hipStreamSynchronize(stream) != hipSuccess) stt = fail(QAMD_ERR_DEVICE, "fused top-k: synchronisation failed");
+                    status = hst.host[2048];
+                } else {
+                    stt = copy_out(&status, QAMD_MEM_HOST, &st->status, 4, stream);  // syncs the stream
+                }
+            }
         }
         if (getenv("QAMD_DEBUG_TOPK")) {
             struct { uint32_t pivot_key, status, total; } dbg{};
