@@ -520,10 +520,12 @@ qamd_status qamd_bin_score_all(const qamd_bin *h, const qamd_bin_query *q, float
     QAMD_TRY(ensure_device(h->device));
     hipStream_t s = as_stream(stream);
     if (out_mem == QAMD_MEM_DEVICE) return scan_into(h, q, out, s);
-    DevBuf tmp;
-    QAMD_TRY(tmp.alloc(h->count * 4));
-    QAMD_TRY(scan_into(h, q, tmp.as<float>(), s));
-    return copy_out(out, QAMD_MEM_HOST, tmp.ptr, h->count * 4, s);
+    float *tmp = nullptr;  // per-thread workspace: no hipMalloc / hipFree per query
+    QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * 4, s, reinterpret_cast<void **>(&tmp)));
+    qamd_status st = scan_into(h, q, tmp, s);
+    if (st == QAMD_OK) st = copy_out(out, QAMD_MEM_HOST, tmp, h->count * 4, s);
+    thread_ws_release(WS_SCORES, s);
+    return st;
 }
 
 qamd_status qamd_bin_score_ids(const qamd_bin *h, const qamd_bin_query *q, const uint32_t *ids, uint64_t n_ids,

@@ -1270,10 +1270,12 @@ qamd_status qamd_u8_score_all(const qamd_u8 *h, const qamd_u8_query *q, float *o
     QAMD_TRY(ensure_device(h->device));
     hipStream_t s = as_stream(stream);
     if (out_mem == QAMD_MEM_DEVICE) return scan_into(h, q, out, s);
-    DevBuf tmp;
-    QAMD_TRY(tmp.alloc(h->count * sizeof(float)));
-    QAMD_TRY(scan_into(h, q, tmp.as<float>(), s));
-    return copy_out(out, QAMD_MEM_HOST, tmp.ptr, h->count * sizeof(float), s);
+    float *tmp = nullptr;  // per-thread workspace: no hipMalloc / hipFree per query
+    QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * sizeof(float), s, reinterpret_cast<void **>(&tmp)));
+    qamd_status st = scan_into(h, q, tmp, s);
+    if (st == QAMD_OK) st = copy_out(out, QAMD_MEM_HOST, tmp, h->count * sizeof(float), s);
+    thread_ws_release(WS_SCORES, s);
+    return st;
 }
 
 qamd_status qamd_u8_score_ids(const qamd_u8 *h, const qamd_u8_query *q, const uint32_t *ids, uint64_t n_ids,
