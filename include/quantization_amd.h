@@ -20,6 +20,11 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls that take
  *     a stream only ENQUEUE when every buffer is device memory; host buffers make the call
  *     synchronous.
+ *   - *_topk (all three quantizers) and *_topk_batch always synchronise `stream` before they
+ *     return, device outputs included: the fused selection reads one status word back to decide
+ *     whether the exact fallback has to run.  They cannot be captured into a hipGraph; score_all can.
+ *   - every call runs on the handle's device and leaves the calling thread's current HIP device
+ *     as it found it.
  *   - handles own device memory; row bytes handed in stay caller-owned.
  *   - all score_* / topk calls are thread-safe on a shared handle (no interior mutation),
  *     matching `&self` in the reference.
@@ -74,6 +79,11 @@ QAMD_API const char *qamd_version(void);
 QAMD_API int qamd_device_count(void);
 /* Device used by handles created afterwards on this thread (default 0). */
 QAMD_API qamd_status qamd_set_device(int device);
+QAMD_API int qamd_get_device(void);
+/* Frees what the CALLING thread has cached on the GPUs (per-device workspaces of score_all /
+ * topk with host outputs, the pinned result scratch).  They are also freed when the thread exits;
+ * call this from a long-lived thread that is done querying. */
+QAMD_API void qamd_thread_release(void);
 
 /* ===================================================================================
  * Scalar u8 quantizer — quantization/src/encoded_vectors_u8.rs
@@ -104,6 +114,27 @@ QAMD_API qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem,
                                     const qamd_vector_parameters *vp, const float *quantile,
                                     const float *alpha_offset, qamd_stop_fn stop, void *stop_user,
                                     void *stream, qamd_u8 **out);
+
+/* Streaming form of encode: the reference takes a clonable ITERATOR and walks it twice
+ * (encoded_vectors_u8.rs:34-40: pass 1 :57-71 min/max + quantile sample, pass 2 :73-118 quantize,
+ * rows appended one by one through EncodedStorageBuilder::push_vector_data,
+ * encoded_storage.rs:17-25), never holding the f32 data.  Same contract in bounded batches:
+ *   begin(vp{count = rows that will come}, quantile | alpha_offset, stop)
+ *   observe(batch) ...   every vector once, any batch sizes          (skip when alpha_offset given)
+ *   push(batch) ...      every vector again, same order: rows are appended
+ *   finish(&handle)      consumes the encoder; abort() drops it.
+ * stop_condition is polled once per observe/push call (-> QAMD_ERR_STOPPED).  The result is
+ * byte-identical to qamd_u8_encode on the concatenated data. */
+typedef struct qamd_u8_encoder qamd_u8_encoder;
+QAMD_API qamd_status qamd_u8_encoder_begin(const qamd_vector_parameters *vp, const float *quantile,
+                                           const float *alpha_offset, qamd_stop_fn stop, void *stop_user,
+                                           void *stream, qamd_u8_encoder **out);
+QAMD_API qamd_status qamd_u8_encoder_observe(qamd_u8_encoder *e, const float *batch, uint64_t n_rows,
+                                             qamd_mem batch_mem);
+QAMD_API qamd_status qamd_u8_encoder_push(qamd_u8_encoder *e, const float *batch, uint64_t n_rows,
+                                          qamd_mem batch_mem);
+QAMD_API qamd_status qamd_u8_encoder_finish(qamd_u8_encoder *e, qamd_u8 **out);
+QAMD_API void qamd_u8_encoder_abort(qamd_u8_encoder *e);
 
 /* Adopt rows already in the reference's storage format — what
  * EncodedStorage::get_vector_data serves (encoded_storage.rs:27-31): count rows of
@@ -194,6 +225,16 @@ QAMD_API qamd_status qamd_bin_encode(const float *data, qamd_mem data_mem,
                                      const qamd_vector_parameters *vp, qamd_bits_store store,
                                      qamd_stop_fn stop, void *stop_user, void *stream,
                                      qamd_bin **out);
+/* Streaming form (EncodedVectorsBin::encode walks its iterator once, :165-191): begin, push
+ * batches in row order, finish.  See qamd_u8_encoder_*. */
+typedef struct qamd_bin_encoder qamd_bin_encoder;
+QAMD_API qamd_status qamd_bin_encoder_begin(const qamd_vector_parameters *vp, qamd_bits_store store,
+                                            qamd_stop_fn stop, void *stop_user, void *stream,
+                                            qamd_bin_encoder **out);
+QAMD_API qamd_status qamd_bin_encoder_push(qamd_bin_encoder *e, const float *batch, uint64_t n_rows,
+                                           qamd_mem batch_mem);
+QAMD_API qamd_status qamd_bin_encoder_finish(qamd_bin_encoder *e, qamd_bin **out);
+QAMD_API void qamd_bin_encoder_abort(qamd_bin_encoder *e);
 QAMD_API qamd_status qamd_bin_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                         const qamd_vector_parameters *vp, qamd_bits_store store,
                                         void *stream, qamd_bin **out);
@@ -237,14 +278,36 @@ QAMD_API uint64_t qamd_pq_quantized_vector_size(const qamd_vector_parameters *vp
                                                 uint64_t chunk_size);
 /* EncodedVectorsPQ::encode (:56-107).  centroids: NULL => find_centroids (:278-342)
  * runs (count <= 256: the vectors themselves, exactly as :290-297; otherwise k-means on a
- * 10 000-row sample, kmeans.rs — its values are "parity unpinned", the reference's own
- * are random).  Non-NULL: 256 x dim f32, centroid-major (Metadata.centroids, :39-44),
- * host memory; encode_storage (:136-226) then runs with them (bit-exact path). */
+ * 10 000-row sample, kmeans.rs).  The reference picks the sample rows at random (:300-302) and
+ * re-seeds an empty cluster from thread_rng (kmeans.rs:111-118); here the sample is the evenly
+ * strided rows floor(k * count / S) and the re-seed a fixed hash.  Everything else -- assignment,
+ * f64 sums split over `max_kmeans_threads` contiguous row ranges and merged in worker order
+ * (kmeans.rs:77-107), f32 shift sum, stopping rule -- is the reference's arithmetic in the
+ * reference's order: given the same sample rows and no empty cluster the centroids are
+ * bit-identical.  Non-NULL centroids: 256 x dim f32, centroid-major (Metadata.centroids,
+ * :39-44), host memory; encode_storage (:136-226) then runs with them. */
 QAMD_API qamd_status qamd_pq_encode(const float *data, qamd_mem data_mem,
                                     const qamd_vector_parameters *vp, uint64_t chunk_size,
                                     const float *centroids, uint32_t max_kmeans_threads,
                                     qamd_stop_fn stop, void *stop_user, void *stream,
                                     qamd_pq **out);
+/* How the last k-means went: iterations of the slowest chunk (0: centroids were given or
+ * count <= 256) and the number of empty-cluster re-seeds (0 => centroid parity holds, see above). */
+QAMD_API qamd_status qamd_pq_kmeans_info(const qamd_pq *h, uint32_t *iterations, uint32_t *empty_clusters);
+/* Streaming form (the reference walks its iterator twice: find_centroids :278-342, then
+ * encode_storage :136-226): begin, observe every vector once (skipped when centroids are given),
+ * push every vector again in the same order, finish.  See qamd_u8_encoder_*. */
+typedef struct qamd_pq_encoder qamd_pq_encoder;
+QAMD_API qamd_status qamd_pq_encoder_begin(const qamd_vector_parameters *vp, uint64_t chunk_size,
+                                           const float *centroids, uint32_t max_kmeans_threads,
+                                           qamd_stop_fn stop, void *stop_user, void *stream,
+                                           qamd_pq_encoder **out);
+QAMD_API qamd_status qamd_pq_encoder_observe(qamd_pq_encoder *e, const float *batch, uint64_t n_rows,
+                                             qamd_mem batch_mem);
+QAMD_API qamd_status qamd_pq_encoder_push(qamd_pq_encoder *e, const float *batch, uint64_t n_rows,
+                                          qamd_mem batch_mem);
+QAMD_API qamd_status qamd_pq_encoder_finish(qamd_pq_encoder *e, qamd_pq **out);
+QAMD_API void qamd_pq_encoder_abort(qamd_pq_encoder *e);
 QAMD_API qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                        const qamd_vector_parameters *vp, uint64_t chunk_size,
                                        const float *centroids, void *stream, qamd_pq **out);
@@ -275,6 +338,108 @@ QAMD_API qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint
                                   int largest, uint32_t *out_ids, float *out_scores,
                                   qamd_mem out_mem, void *stream);
 QAMD_API void qamd_pq_free(qamd_pq *h);
+
+/* ===================================================================================
+ * Row-sharded stores: ONE process, several GPUs of a node behind one handle.
+ *
+ * No reference counterpart (the crate is single-device); the caller it serves is the one
+ * process of demos/src/ann_benchmark.rs:245-260 (score every row, keep the best 30:
+ * ann_benchmark_data.rs:151-167).  Shard g of G owns rows [g*N/G, (g+1)*N/G) as an ordinary
+ * handle on devices[g]; global row id = shard base + local id; metadata is replicated.
+ * `devices` may repeat a device (logical shards on one GPU).  Every call is synchronous: it
+ * fans out to one worker thread per shard (its own stream on the shard's device), waits, and does
+ * ONE exchange -- score_all: each shard's scores land in their slice of `out` (host: one D2H
+ * per GPU; device: peer copy of 4 B/row over xGMI to the device owning `out`); topk: G*k
+ * (id, score) pairs are peer-copied to devices[0] and merged by one kernel there with the
+ * single-handle ordering (best first, ties to the lower global id).  Results are bit-identical
+ * to the same call on a single handle holding all rows.  Host buffers or device buffers; a
+ * device output of topk must live on devices[0].  One call at a time per handle (calls from
+ * several threads serialise).
+ * =================================================================================== */
+typedef struct qamd_u8_sharded qamd_u8_sharded;
+typedef struct qamd_u8_sharded_query qamd_u8_sharded_query;
+typedef struct qamd_u8_sharded_query_batch qamd_u8_sharded_query_batch;
+/* encode (encoded_vectors_u8.rs:34-140): global min/max (or quantile interval) first, then
+ * every shard quantizes its own rows.  `data` is host memory or device memory of any one GPU. */
+QAMD_API qamd_status qamd_u8_sharded_encode(const float *data, qamd_mem data_mem,
+                                            const qamd_vector_parameters *vp, const float *quantile,
+                                            const float *alpha_offset, qamd_stop_fn stop, void *stop_user,
+                                            const int *devices, uint32_t n_shards, qamd_u8_sharded **out);
+QAMD_API qamd_status qamd_u8_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem,
+                                               const qamd_u8_metadata *meta, const int *devices,
+                                               uint32_t n_shards, qamd_u8_sharded **out);
+QAMD_API uint32_t qamd_u8_sharded_shard_count(const qamd_u8_sharded *h);
+/* Borrow shard g (owned by the sharded handle): its single-device handle, first global row, device. */
+QAMD_API qamd_status qamd_u8_sharded_shard(const qamd_u8_sharded *h, uint32_t g, const qamd_u8 **shard,
+                                           uint64_t *row_begin, int *device);
+QAMD_API qamd_status qamd_u8_sharded_get_metadata(const qamd_u8_sharded *h, qamd_u8_metadata *out);
+QAMD_API qamd_status qamd_u8_sharded_encode_query(qamd_u8_sharded *h, const float *query, uint64_t qdim,
+                                                  qamd_mem query_mem, qamd_u8_sharded_query **query_io);
+QAMD_API void qamd_u8_sharded_query_free(qamd_u8_sharded_query *q);
+QAMD_API qamd_status qamd_u8_sharded_score_all(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, float *out,
+                                               qamd_mem out_mem);
+QAMD_API qamd_status qamd_u8_sharded_topk(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, uint32_t k,
+                                          int largest, uint32_t *out_ids, float *out_scores,
+                                          qamd_mem out_mem);
+QAMD_API qamd_status qamd_u8_sharded_encode_query_batch(qamd_u8_sharded *h, const float *queries,
+                                                        uint64_t n_queries, uint64_t qdim,
+                                                        qamd_mem queries_mem,
+                                                        qamd_u8_sharded_query_batch **batch_io);
+QAMD_API void qamd_u8_sharded_query_batch_free(qamd_u8_sharded_query_batch *b);
+/* n_queries x k; shards x k <= 8192. */
+QAMD_API qamd_status qamd_u8_sharded_topk_batch(qamd_u8_sharded *h, const qamd_u8_sharded_query_batch *b,
+                                                uint32_t k, int largest, uint32_t *out_ids,
+                                                float *out_scores, qamd_mem out_mem);
+QAMD_API void qamd_u8_sharded_free(qamd_u8_sharded *h);
+
+typedef struct qamd_bin_sharded qamd_bin_sharded;
+typedef struct qamd_bin_sharded_query qamd_bin_sharded_query;
+QAMD_API qamd_status qamd_bin_sharded_encode(const float *data, qamd_mem data_mem,
+                                             const qamd_vector_parameters *vp, qamd_bits_store store,
+                                             qamd_stop_fn stop, void *stop_user, const int *devices,
+                                             uint32_t n_shards, qamd_bin_sharded **out);
+QAMD_API qamd_status qamd_bin_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem,
+                                                const qamd_vector_parameters *vp, qamd_bits_store store,
+                                                const int *devices, uint32_t n_shards,
+                                                qamd_bin_sharded **out);
+QAMD_API uint32_t qamd_bin_sharded_shard_count(const qamd_bin_sharded *h);
+QAMD_API qamd_status qamd_bin_sharded_shard(const qamd_bin_sharded *h, uint32_t g, const qamd_bin **shard,
+                                            uint64_t *row_begin, int *device);
+QAMD_API qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *query, uint64_t qdim,
+                                                   qamd_mem query_mem, qamd_bin_sharded_query **query_io);
+QAMD_API void qamd_bin_sharded_query_free(qamd_bin_sharded_query *q);
+QAMD_API qamd_status qamd_bin_sharded_score_all(qamd_bin_sharded *h, const qamd_bin_sharded_query *q,
+                                                float *out, qamd_mem out_mem);
+QAMD_API qamd_status qamd_bin_sharded_topk(qamd_bin_sharded *h, const qamd_bin_sharded_query *q, uint32_t k,
+                                           int largest, uint32_t *out_ids, float *out_scores,
+                                           qamd_mem out_mem);
+QAMD_API void qamd_bin_sharded_free(qamd_bin_sharded *h);
+
+typedef struct qamd_pq_sharded qamd_pq_sharded;
+typedef struct qamd_pq_sharded_query qamd_pq_sharded_query;
+/* centroids NULL: find_centroids runs once (on the device holding `data`, else devices[0]). */
+QAMD_API qamd_status qamd_pq_sharded_encode(const float *data, qamd_mem data_mem,
+                                            const qamd_vector_parameters *vp, uint64_t chunk_size,
+                                            const float *centroids, uint32_t max_kmeans_threads,
+                                            qamd_stop_fn stop, void *stop_user, const int *devices,
+                                            uint32_t n_shards, qamd_pq_sharded **out);
+QAMD_API qamd_status qamd_pq_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem,
+                                               const qamd_vector_parameters *vp, uint64_t chunk_size,
+                                               const float *centroids, const int *devices,
+                                               uint32_t n_shards, qamd_pq_sharded **out);
+QAMD_API uint32_t qamd_pq_sharded_shard_count(const qamd_pq_sharded *h);
+QAMD_API qamd_status qamd_pq_sharded_shard(const qamd_pq_sharded *h, uint32_t g, const qamd_pq **shard,
+                                           uint64_t *row_begin, int *device);
+QAMD_API qamd_status qamd_pq_sharded_get_centroids(const qamd_pq_sharded *h, float *centroids);
+QAMD_API qamd_status qamd_pq_sharded_encode_query(qamd_pq_sharded *h, const float *query, uint64_t qdim,
+                                                  qamd_mem query_mem, qamd_pq_sharded_query **query_io);
+QAMD_API void qamd_pq_sharded_query_free(qamd_pq_sharded_query *q);
+QAMD_API qamd_status qamd_pq_sharded_score_all(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, float *out,
+                                               qamd_mem out_mem);
+QAMD_API qamd_status qamd_pq_sharded_topk(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, uint32_t k,
+                                          int largest, uint32_t *out_ids, float *out_scores,
+                                          qamd_mem out_mem);
+QAMD_API void qamd_pq_sharded_free(qamd_pq_sharded *h);
 
 /* ===================================================================================
  * Selection over an existing score array (device memory), e.g. after a multi-GPU gather.

@@ -6,10 +6,16 @@ quantization_amd/csrc).  These classes are the host-side mirror of the reference
 HIP library and a GPU every call raises.
 """
 from ._lib import build, lib  # noqa: F401
-from .encoded_vectors import DistanceType, EncodingError, VectorParameters  # noqa: F401
+from .encoded_vectors import DistanceType, EncodingError, VectorParameters, get_device, set_device  # noqa: F401
 from .encoded_vectors_binary import BitsStoreType, EncodedBinVector, EncodedVectorsBin  # noqa: F401
 from .encoded_vectors_pq import EncodedQueryPQ, EncodedVectorsPQ  # noqa: F401
 from .encoded_vectors_u8 import EncodedQueryBatchU8, EncodedQueryU8, EncodedVectorsU8  # noqa: F401
+from .sharded_store import ShardedVectorsBin, ShardedVectorsPQ, ShardedVectorsU8  # noqa: F401
+
+
+def thread_release() -> None:
+    """Free what the calling thread has cached on the GPUs (see qamd_thread_release)."""
+    lib().qamd_thread_release()
 
 
 
@@ -34,7 +40,8 @@ def topk_scores(scores, n: int, k: int, largest: bool = True, out_ids=None, out_
 
 
 __all__ = [
-    "topk_scores",
+    "topk_scores", "set_device", "get_device", "thread_release",
+    "ShardedVectorsU8", "ShardedVectorsBin", "ShardedVectorsPQ",
     "DistanceType", "VectorParameters", "EncodingError",
     "EncodedVectorsU8", "EncodedQueryU8", "EncodedQueryBatchU8",
     "EncodedVectorsPQ", "EncodedQueryPQ",

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .encoded_vectors import check, in_buf, out_buf, stream_ptr
+from .encoded_vectors import check, check_same_device, in_buf, out_buf, stream_ptr
 
 
 class EncodedQueryBase:
@@ -30,19 +30,29 @@ class EncodedVectorsBase:
     _prefix = ""
     _query_cls = EncodedQueryBase
 
-    def __init__(self, handle: C.c_void_p):
+    def __init__(self, handle: C.c_void_p, device: int | None = None, owned: bool = True):
         self._h = handle
+        self._device = device  # where the store lives; device buffers of every call must match
+        self._owned = owned    # False: a shard borrowed from a sharded handle
+        self._count = None
 
     def _fn(self, name):
         return getattr(_lib.lib(), f"qamd_{self._prefix}_{name}")
 
     @property
+    def device(self) -> int | None:
+        return self._device
+
+    @property
     def count(self) -> int:
-        return self.vector_parameters.count
+        if self._count is None:  # immutable after construction: one ABI round trip, not one per query
+            self._count = int(self.vector_parameters.count)
+        return self._count
 
     def encode_query(self, query, reuse=None, stream=None):
         """EncodedVectors::encode_query.  `reuse` recycles an encoded-query object (no
         allocation in a query loop)."""
+        check_same_device(self._device, query)
         buf = in_buf(query, np.float32)
         n = int(np.prod(tuple(query.shape))) if hasattr(query, "shape") else len(query)
         h = reuse._h if reuse is not None else C.c_void_p()
@@ -65,12 +75,14 @@ class EncodedVectorsBase:
     def score_all(self, query, out=None, stream=None):
         """scores[i] = score_point(query, i) for every row: the batched form of the caller
         loop in demos/src/ann_benchmark.rs:247-252."""
+        check_same_device(self._device, out)
         buf, ret = out_buf(out, self.count, np.float32)
         check(self._fn("score_all")(self._h, query._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret
 
     def score_ids(self, query, ids, out=None, stream=None):
         """scores[k] = score_point(query, ids[k]) (random access, demos/benches/encode.rs)."""
+        check_same_device(self._device, ids, out)
         ib = in_buf(ids, np.uint32)
         n = int(ids.numel()) if hasattr(ids, "numel") else len(ids)
         buf, ret = out_buf(out, n, np.float32)
@@ -81,6 +93,7 @@ class EncodedVectorsBase:
     def topk(self, query, k: int, largest: bool = True, out_ids=None, out_scores=None, stream=None):
         """Best-k rows of the scan (demos/src/ann_benchmark_data.rs:151-167 keeps 30 in a heap),
         sorted best-first; ties go to the lower row id.  Returns (ids, scores)."""
+        check_same_device(self._device, out_ids, out_scores)
         ib, ids = out_buf(out_ids, k, np.uint32)
         sb, sc = out_buf(out_scores, k, np.float32)
         if ib.mem != sb.mem:
@@ -90,9 +103,9 @@ class EncodedVectorsBase:
         return ids, sc
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and getattr(self, "_owned", True):
             try:
                 self._fn("free")(self._h)
             except Exception:  # interpreter shutdown
                 pass
-            self._h = None
+        self._h = None

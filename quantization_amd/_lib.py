@@ -74,6 +74,8 @@ def lib() -> C.CDLL:
         "qamd_version": (C.c_char_p, []),
         "qamd_device_count": (i32, []),
         "qamd_set_device": (i32, [i32]),
+        "qamd_get_device": (i32, []),
+        "qamd_thread_release": (None, []),
         # u8
         "qamd_u8_quantized_vector_size": (u64, [VP]),
         "qamd_u8_actual_dim": (u64, [VP]),
@@ -98,6 +100,11 @@ def lib() -> C.CDLL:
         "qamd_u8_score_batch": (i32, [vp, vp, vp, i32, vp]),
         "qamd_u8_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_u8_scan_bytes_per_row": (u64, [vp]),
+        "qamd_u8_encoder_begin": (i32, [VP, f32p, f32p, STOP_FN, vp, vp, pp]),
+        "qamd_u8_encoder_observe": (i32, [vp, vp, u64, i32]),
+        "qamd_u8_encoder_push": (i32, [vp, vp, u64, i32]),
+        "qamd_u8_encoder_finish": (i32, [vp, pp]),
+        "qamd_u8_encoder_abort": (None, [vp]),
         # binary
         "qamd_bin_quantized_vector_size": (u64, [VP, i32]),
         "qamd_bin_encode": (i32, [vp, i32, VP, i32, STOP_FN, vp, vp, pp]),
@@ -114,6 +121,10 @@ def lib() -> C.CDLL:
         "qamd_bin_score_ids": (i32, [vp, vp, vp, u64, i32, vp, i32, vp]),
         "qamd_bin_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_bin_free": (None, [vp]),
+        "qamd_bin_encoder_begin": (i32, [VP, i32, STOP_FN, vp, vp, pp]),
+        "qamd_bin_encoder_push": (i32, [vp, vp, u64, i32]),
+        "qamd_bin_encoder_finish": (i32, [vp, pp]),
+        "qamd_bin_encoder_abort": (None, [vp]),
         # pq
         "qamd_pq_quantized_vector_size": (u64, [VP, u64]),
         "qamd_pq_encode": (i32, [vp, i32, VP, u64, vp, u32, STOP_FN, vp, vp, pp]),
@@ -131,10 +142,52 @@ def lib() -> C.CDLL:
         "qamd_pq_score_ids": (i32, [vp, vp, vp, u64, i32, vp, i32, vp]),
         "qamd_pq_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_pq_free": (None, [vp]),
+        "qamd_pq_kmeans_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32)]),
+        "qamd_pq_encoder_begin": (i32, [VP, u64, vp, u32, STOP_FN, vp, vp, pp]),
+        "qamd_pq_encoder_observe": (i32, [vp, vp, u64, i32]),
+        "qamd_pq_encoder_push": (i32, [vp, vp, u64, i32]),
+        "qamd_pq_encoder_finish": (i32, [vp, pp]),
+        "qamd_pq_encoder_abort": (None, [vp]),
+        # row-sharded stores (one process, several GPUs)
+        "qamd_u8_sharded_encode": (i32, [vp, i32, VP, f32p, f32p, STOP_FN, vp, C.POINTER(i32), u32, pp]),
+        "qamd_u8_sharded_from_rows": (i32, [vp, i32, C.POINTER(U8MetadataC), C.POINTER(i32), u32, pp]),
+        "qamd_u8_sharded_shard_count": (u32, [vp]),
+        "qamd_u8_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
+        "qamd_u8_sharded_get_metadata": (i32, [vp, C.POINTER(U8MetadataC)]),
+        "qamd_u8_sharded_encode_query": (i32, [vp, vp, u64, i32, pp]),
+        "qamd_u8_sharded_query_free": (None, [vp]),
+        "qamd_u8_sharded_score_all": (i32, [vp, vp, vp, i32]),
+        "qamd_u8_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_u8_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, pp]),
+        "qamd_u8_sharded_query_batch_free": (None, [vp]),
+        "qamd_u8_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_u8_sharded_free": (None, [vp]),
+        "qamd_bin_sharded_encode": (i32, [vp, i32, VP, i32, STOP_FN, vp, C.POINTER(i32), u32, pp]),
+        "qamd_bin_sharded_from_rows": (i32, [vp, i32, VP, i32, C.POINTER(i32), u32, pp]),
+        "qamd_bin_sharded_shard_count": (u32, [vp]),
+        "qamd_bin_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
+        "qamd_bin_sharded_encode_query": (i32, [vp, vp, u64, i32, pp]),
+        "qamd_bin_sharded_query_free": (None, [vp]),
+        "qamd_bin_sharded_score_all": (i32, [vp, vp, vp, i32]),
+        "qamd_bin_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_bin_sharded_free": (None, [vp]),
+        "qamd_pq_sharded_encode": (i32, [vp, i32, VP, u64, vp, u32, STOP_FN, vp, C.POINTER(i32), u32, pp]),
+        "qamd_pq_sharded_from_rows": (i32, [vp, i32, VP, u64, vp, C.POINTER(i32), u32, pp]),
+        "qamd_pq_sharded_shard_count": (u32, [vp]),
+        "qamd_pq_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
+        "qamd_pq_sharded_get_centroids": (i32, [vp, vp]),
+        "qamd_pq_sharded_encode_query": (i32, [vp, vp, u64, i32, pp]),
+        "qamd_pq_sharded_query_free": (None, [vp]),
+        "qamd_pq_sharded_score_all": (i32, [vp, vp, vp, i32]),
+        "qamd_pq_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_pq_sharded_free": (None, [vp]),
         "qamd_topk_scores": (i32, [vp, u64, u32, i32, vp, vp, i32, vp]),
         # measurement
         "qamd_stream_read": (i32, [vp, u64, vp, vp]),
     }
+    undeclared = set(sig) - set(declared_symbols())
+    if undeclared:  # the binding may only name what include/quantization_amd.h declares
+        raise RuntimeError(f"_lib.py binds symbols the header does not declare: {sorted(undeclared)}")
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch
         fn.restype = res

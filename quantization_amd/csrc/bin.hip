@@ -255,6 +255,7 @@ struct qamd_bin_query {
     int device = 0;
     uint64_t nb = 0, ds = 0, qdim_cap = 0;
     DevBuf buf;  // ds bytes (+ padding)
+    ReadyEvent ready;  // the last encode_query
 };
 
 namespace {
@@ -339,6 +340,24 @@ qamd_status upload_rows(qamd_bin *h, const uint8_t *rows, qamd_mem mem, hipStrea
     return copy_in(h->rows.ptr, wide.data(), QAMD_MEM_HOST, wide.size(), s);
 }
 
+// encode_vector (:193-208) for `nr` device-resident rows: rows r0 .. r0+nr of the store.
+qamd_status launch_bin_encode(qamd_bin *h, const float *src, uint64_t nr, uint64_t r0, hipStream_t s) {
+    const uint64_t dim = h->vp.dim;
+    if (nr == 0 || dim == 0) return QAMD_OK;
+    if (dim % 128 == 0 && h->ds * 8 == dim && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint64_t n4 = nr * dim / 4;
+        const unsigned grid = (unsigned)((n4 + 1024 * (kBlock / 64) - 1) / (1024 * (kBlock / 64)));
+        hipLaunchKernelGGL(bin_encode_flat_kernel, dim3(grid), dim3(kBlock), 0, s, reinterpret_cast<const float4 *>(src),
+                           n4, h->rows.as<uint32_t>() + r0 * (h->ds / 4));
+    } else {
+        int grid = grid_for(nr, kBlock / 64, 8);
+        hipLaunchKernelGGL(bin_encode_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
+                           (uint32_t)(h->ds / 4), h->rows.as<uint32_t>(), r0);
+    }
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -353,7 +372,7 @@ qamd_status qamd_bin_encode(const float *data, qamd_mem data_mem, const qamd_vec
     if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
     if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     hipStream_t s = as_stream(stream);
     std::unique_ptr<qamd_bin> h(new qamd_bin);
     h->device = current_device();
@@ -376,18 +395,7 @@ qamd_status qamd_bin_encode(const float *data, qamd_mem data_mem, const qamd_vec
                 QAMD_TRY(copy_in(stage.ptr, src, QAMD_MEM_HOST, nr * dim * 4, s));
                 src = stage.as<float>();
             }
-            if (dim % 128 == 0 && h->ds * 8 == dim && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-                const uint64_t n4 = nr * dim / 4;
-                const unsigned grid = (unsigned)((n4 + 1024 * (kBlock / 64) - 1) / (1024 * (kBlock / 64)));
-                hipLaunchKernelGGL(bin_encode_flat_kernel, dim3(grid), dim3(kBlock), 0, s,
-                                   reinterpret_cast<const float4 *>(src), n4,
-                                   h->rows.as<uint32_t>() + r0 * (h->ds / 4));
-            } else {
-                int grid = grid_for(nr, kBlock / 64, 8);
-                hipLaunchKernelGGL(bin_encode_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
-                                   (uint32_t)(h->ds / 4), h->rows.as<uint32_t>(), r0);
-            }
-            QAMD_HIP(hipGetLastError());
+            QAMD_TRY(launch_bin_encode(h.get(), src, nr, r0, s));
             if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
         }
         QAMD_HIP(hipStreamSynchronize(s));
@@ -402,7 +410,7 @@ qamd_status qamd_bin_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qam
                                qamd_bits_store store, void *stream, qamd_bin **out) {
     if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     std::unique_ptr<qamd_bin> h(new qamd_bin);
     h->device = current_device();
     h->vp = *vp;
@@ -420,7 +428,7 @@ qamd_status qamd_bin_export_rows(const qamd_bin *h, uint8_t *rows, qamd_mem rows
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
     if (h->count == 0 || h->nb == 0) return QAMD_OK;
     if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     if (h->nb == h->ds) return copy_out(rows, rows_mem, h->rows.ptr, h->count * h->nb, s);
     std::vector<uint8_t> wide(h->count * h->ds), host(h->count * h->nb);
@@ -467,7 +475,7 @@ qamd_status qamd_bin_load(const char *data_path, const char *meta_path, const qa
 qamd_status qamd_bin_encode_query(const qamd_bin *h, const float *query, uint64_t qdim, qamd_mem query_mem,
                                   void *stream, qamd_bin_query **query_io) {
     if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     const uint64_t nb = row_bytes_of(qdim, h->store), ds = device_stride_of(nb);
     qamd_bin_query *q = *query_io;
@@ -495,6 +503,7 @@ qamd_status qamd_bin_encode_query(const qamd_bin *h, const float *query, uint64_
                            (uint32_t)(ds / 4), q->buf.as<uint32_t>(), (uint64_t)0);
         QAMD_HIP(hipGetLastError());
     }
+    QAMD_TRY(q->ready.record(s));
     if (fresh) *query_io = fresh.release();
     return QAMD_OK;
 }
@@ -504,7 +513,8 @@ qamd_status qamd_bin_query_read(const qamd_bin_query *q, uint8_t *bits, uint64_t
     if (len) *len = q->nb;
     if (bits) {
         if (capacity < q->nb) return fail(QAMD_ERR_ARGUMENTS, "bits buffer too small");
-        QAMD_TRY(ensure_device(q->device));
+        QAMD_ON_DEVICE(q->device);
+        QAMD_TRY(q->ready.wait(nullptr));
         QAMD_TRY(copy_out(bits, QAMD_MEM_HOST, q->buf.ptr, q->nb, nullptr));
     }
     return QAMD_OK;
@@ -517,8 +527,9 @@ qamd_status qamd_bin_score_all(const qamd_bin *h, const qamd_bin_query *q, float
     QAMD_TRY(check_query(h, q));
     if (h->count == 0) return QAMD_OK;
     if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     if (out_mem == QAMD_MEM_DEVICE) return scan_into(h, q, out, s);
     float *tmp = nullptr;  // per-thread workspace: no hipMalloc / hipFree per query
     QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * 4, s, reinterpret_cast<void **>(&tmp)));
@@ -533,8 +544,9 @@ qamd_status qamd_bin_score_ids(const qamd_bin *h, const qamd_bin_query *q, const
     QAMD_TRY(check_query(h, q));
     if (n_ids == 0) return QAMD_OK;
     if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     DevBuf ids_tmp, out_tmp;
     const uint32_t *ids_dev = ids;
     // per-pair granularity (score_point and friends): ids and results through the calling
@@ -581,7 +593,7 @@ qamd_status qamd_bin_score_internal(const qamd_bin *h, uint32_t i, uint32_t j, f
     if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (i >= h->count || j >= h->count)
         return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     const uint32_t *qrow = h->rows.as<uint32_t>() + (uint64_t)i * (h->ds / 4);
     const HostScratch hs = host_scratch();
     if (hs.host) {
@@ -603,8 +615,9 @@ qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k
     QAMD_TRY(check_query(h, q));
     if (k == 0) return QAMD_OK;
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     if (!fused_capable(h)) {
         float *scores = nullptr;
         QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));
@@ -626,8 +639,88 @@ void qamd_bin_free(qamd_bin *h) { delete h; }
 
 }  // extern "C"
 
-// Developer-only accessors for the tuning harness (tune.hip); not part of include/.
+
+// ============================================================================= streaming encode
+// EncodedVectorsBin::encode (:165-191) walks its iterator ONCE, pushing one packed row per vector
+// (EncodedStorageBuilder::push_vector_data, encoded_storage.rs:17-25); here in bounded batches.
+struct qamd_bin_encoder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    qamd_stop_fn stop = nullptr;
+    void *stop_user = nullptr;
+    std::unique_ptr<qamd_bin> h;
+    uint64_t pushed = 0;
+    DevBuf stage;
+};
+
+extern "C" {
+
+qamd_status qamd_bin_encoder_begin(const qamd_vector_parameters *vp, qamd_bits_store store, qamd_stop_fn stop,
+                                   void *stop_user, void *stream, qamd_bin_encoder **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    QAMD_ON_DEVICE(current_device());
+    std::unique_ptr<qamd_bin_encoder> e(new qamd_bin_encoder);
+    e->device = current_device();
+    e->stream = as_stream(stream);
+    e->stop = stop;
+    e->stop_user = stop_user;
+    e->h.reset(new qamd_bin);
+    e->h->device = e->device;
+    e->h->vp = *vp;
+    e->h->store = store;
+    e->h->count = vp->count;
+    QAMD_TRY(alloc_store(e->h.get()));
+    *out = e.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_encoder_push(qamd_bin_encoder *e, const float *batch, uint64_t n_rows, qamd_mem batch_mem) {
+    if (!e || (!batch && n_rows && e->h->vp.dim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (e->stop && e->stop(e->stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :174-176
+    if (e->pushed + n_rows > e->h->count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)(e->pushed + n_rows), (unsigned long long)e->h->count);
+    QAMD_ON_DEVICE(e->device);
+    const uint64_t dim = e->h->vp.dim;
+    const uint64_t piece_rows = std::max<uint64_t>(1, (256ull << 20) / std::max<uint64_t>(dim * 4, 1));
+    for (uint64_t r = 0; r < n_rows && dim; r += piece_rows) {
+        const uint64_t nr = std::min(piece_rows, n_rows - r);
+        const void *src = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(batch + r * dim, batch_mem, nr * dim * 4, e->stage, e->stream, &src, &staged));
+        QAMD_TRY(launch_bin_encode(e->h.get(), static_cast<const float *>(src), nr, e->pushed + r, e->stream));
+        if (staged) QAMD_HIP(hipStreamSynchronize(e->stream));  // the staging buffer is reused
+    }
+    e->pushed += n_rows;
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_encoder_finish(qamd_bin_encoder *e, qamd_bin **out) {
+    if (!e || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_bin_encoder> own(e);
+    if (e->pushed != e->h->count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)e->pushed, (unsigned long long)e->h->count);
+    QAMD_ON_DEVICE(e->device);
+    QAMD_HIP(hipStreamSynchronize(e->stream));
+    *out = e->h.release();
+    return QAMD_OK;
+}
+
+void qamd_bin_encoder_abort(qamd_bin_encoder *e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    delete e;
+}
+
+}  // extern "C"
+
+#ifdef QAMD_DEV
+// Developer-only accessors for the tuning harness (tune.hip): libquantization_amd_dev.so only.
 extern "C" __attribute__((visibility("default"))) const void *qamd_dev_bin_rows(const qamd_bin *h) { return h->rows.ptr; }
 extern "C" __attribute__((visibility("default"))) const void *qamd_dev_bin_query_ptr(const qamd_bin_query *q) {
     return q->buf.ptr;
 }
+#endif

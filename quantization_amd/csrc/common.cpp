@@ -6,8 +6,10 @@
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <fstream>
 #include <mutex>
+#include <vector>
 
 namespace qamd {
 
@@ -28,16 +30,48 @@ qamd_status fail(qamd_status st, const char *fmt, ...) {
 
 int current_device() { return g_device; }
 
-qamd_status ensure_device(int device) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0)
-        return fail(QAMD_ERR_DEVICE, "no HIP device is visible (%s); this library has no CPU fallback",
-                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
-    if (device < 0 || device >= n)
-        return fail(QAMD_ERR_ARGUMENTS, "device %d out of range (have %d)", device, n);
-    QAMD_HIP(hipSetDevice(device));
-    return QAMD_OK;
+int device_count() {
+    static std::atomic<int> cached{-1};
+    int n = cached.load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return 0;  // not cached: a later call may find the runtime up
+    }
+    cached.store(n, std::memory_order_relaxed);
+    return n;
+}
+
+DeviceGuard::DeviceGuard(int device) {
+    const int n = device_count();
+    if (n <= 0) {
+        st_ = fail(QAMD_ERR_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+        return;
+    }
+    if (device < 0 || device >= n) {
+        st_ = fail(QAMD_ERR_ARGUMENTS, "device %d out of range (have %d)", device, n);
+        return;
+    }
+    hipError_t e = hipGetDevice(&prev_);
+    if (e == hipSuccess && prev_ != device) {
+        e = hipSetDevice(device);
+        switched_ = e == hipSuccess;
+    }
+    if (e != hipSuccess) st_ = fail(QAMD_ERR_DEVICE, "cannot select device %d: %s", device, hipGetErrorString(e));
+}
+
+DeviceGuard::~DeviceGuard() {
+    if (switched_) (void)hipSetDevice(prev_);
+}
+
+bool first_use_on_device(std::atomic<uint64_t> &mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const uint64_t bit = 1ull << dev;
+    if (mask.load(std::memory_order_acquire) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_acq_rel);
+    return true;
 }
 
 qamd_status DevBuf::alloc(size_t n, bool zero) {
@@ -96,6 +130,23 @@ void StreamBuf::release() {
     bytes = 0;
 }
 
+ReadyEvent::~ReadyEvent() {
+    if (ev) (void)hipEventDestroy(ev);
+}
+
+qamd_status ReadyEvent::record(hipStream_t s) {
+    if (!ev) QAMD_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    QAMD_HIP(hipEventRecord(ev, s));
+    stream = s;
+    set = true;
+    return QAMD_OK;
+}
+
+qamd_status ReadyEvent::wait(hipStream_t consumer) const {
+    if (set && consumer != stream) QAMD_HIP(hipStreamWaitEvent(consumer, ev, 0));
+    return QAMD_OK;
+}
+
 qamd_status copy_in(void *dev_dst, const void *src, qamd_mem src_mem, size_t bytes, hipStream_t s) {
     if (bytes == 0) return QAMD_OK;
     if (src_mem == QAMD_MEM_DEVICE) {
@@ -118,75 +169,153 @@ qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t by
     return QAMD_OK;
 }
 
-HostScratch host_scratch() {
-    static thread_local HostScratch hs = [] {
-        HostScratch r;
-        void *p = nullptr, *d = nullptr;
-        if (hipHostMalloc(&p, kHostScratchWords * 4, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
-            hipHostGetDevicePointer(&d, p, 0) == hipSuccess) {
-            r.host = static_cast<uint32_t *>(p);
-            r.dev = static_cast<uint32_t *>(d);
-        }
-        return r;
-    }();
-    return hs;
+qamd_status local_view(const void *src, qamd_mem mem, size_t bytes, DevBuf &stage, hipStream_t s, const void **out,
+                       bool *staged) {
+    *out = src;
+    *staged = false;
+    if (bytes == 0) return QAMD_OK;
+    bool remote = false;
+    if (mem == QAMD_MEM_DEVICE && device_count() > 1) {
+        hipPointerAttribute_t attr{};
+        int dev = 0;
+        if (hipPointerGetAttributes(&attr, src) == hipSuccess && hipGetDevice(&dev) == hipSuccess)
+            remote = attr.device != dev;
+        else
+            (void)hipGetLastError();
+    }
+    if (mem == QAMD_MEM_DEVICE && !remote) return QAMD_OK;
+    if (stage.bytes < bytes) QAMD_TRY(stage.alloc(bytes));
+    QAMD_HIP(hipMemcpyAsync(stage.ptr, src, bytes, mem == QAMD_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDefault, s));
+    if (mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));  // pageable source: the call owns it only now
+    *out = stage.ptr;
+    *staged = true;
+    return QAMD_OK;
 }
 
 namespace {
+
+constexpr int kMaxDevices = 64;
+
 struct ThreadWs {
     void *ptr = nullptr;
     size_t bytes = 0;
-    int dev = -1;
     hipEvent_t done = nullptr;
     bool pending = false;
+    uint64_t tags[3] = {0, 0, 0};
 };
-ThreadWs &thread_ws(ThreadWsSlot slot) {
-    static thread_local ThreadWs ws[WS_SLOTS];
-    return ws[slot];
+
+// Everything the calling thread owns on the GPUs: freed by qamd_thread_release() and by the
+// thread_local destructor (a thread that ends while the process lives; at process exit the main
+// thread's thread_locals are destroyed before the HIP runtime's own static teardown).
+struct ThreadState {
+    HostScratch scratch;
+    bool scratch_tried = false;
+    std::vector<ThreadWs> ws;  // [device][slot], grown on demand
+
+    ThreadWs &at(int dev, ThreadWsSlot slot) {
+        const size_t need = (size_t)(dev + 1) * WS_SLOTS;
+        if (ws.size() < need) ws.resize(need);
+        return ws[(size_t)dev * WS_SLOTS + slot];
+    }
+
+    void release() {
+        int prev = -1;
+        const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+        bool moved = false;
+        for (size_t i = 0; i < ws.size(); i++) {
+            ThreadWs &w = ws[i];
+            if (!w.ptr && !w.done) continue;
+            const int dev = (int)(i / WS_SLOTS);
+            if (hipSetDevice(dev) == hipSuccess) {
+                moved = true;
+                if (w.pending && w.done) (void)hipEventSynchronize(w.done);
+                if (w.ptr) (void)hipFree(w.ptr);
+                if (w.done) (void)hipEventDestroy(w.done);
+            }
+            w = ThreadWs{};
+        }
+        ws.clear();
+        if (moved && have_prev) (void)hipSetDevice(prev);
+        if (scratch.host) (void)hipHostFree(scratch.host);
+        scratch = HostScratch{};
+        scratch_tried = false;
+        (void)hipGetLastError();
+    }
+
+    ~ThreadState() { release(); }
+};
+
+ThreadState &thread_state() {
+    static thread_local ThreadState st;
+    return st;
 }
+
 }  // namespace
 
-qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out) {
-    ThreadWs &w = thread_ws(slot);
+HostScratch host_scratch() {
+    ThreadState &ts = thread_state();
+    if (!ts.scratch_tried) {
+        ts.scratch_tried = true;
+        void *p = nullptr, *d = nullptr;
+        if (hipHostMalloc(&p, kHostScratchWords * 4, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+            if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess) {
+                ts.scratch.host = static_cast<uint32_t *>(p);
+                ts.scratch.dev = static_cast<uint32_t *>(d);
+            } else {
+                (void)hipHostFree(p);
+            }
+        }
+    }
+    return ts.scratch;
+}
+
+qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out, uint64_t **tags) {
     int dev = 0;
     QAMD_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(QAMD_ERR_DEVICE, "device index %d not supported", dev);
+    ThreadWs &w = thread_state().at(dev, slot);
     if (bytes == 0) bytes = 16;
-    if (w.dev != dev || w.bytes < bytes) {
-        if (w.ptr && w.dev == dev) {
+    if (w.bytes < bytes) {
+        if (w.ptr) {
             if (w.pending) (void)hipEventSynchronize(w.done);
             (void)hipFree(w.ptr);
+            w.ptr = nullptr;
         }
-        w.ptr = nullptr;
         w.bytes = 0;
         w.pending = false;
-        if (w.dev != dev) w.done = nullptr;  // an event belongs to the device it was created on
+        w.tags[0] = w.tags[1] = w.tags[2] = 0;
         const size_t want = bytes + bytes / 4;  // head room: stores grow, k varies
         QAMD_HIP(hipMalloc(&w.ptr, want));
         w.bytes = want;
-        w.dev = dev;
         if (!w.done) QAMD_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     }
     if (w.pending) QAMD_HIP(hipStreamWaitEvent(s, w.done, 0));
     *out = w.ptr;
+    if (tags) *tags = w.tags;
     return QAMD_OK;
 }
 
 void thread_ws_release(ThreadWsSlot slot, hipStream_t s) {
-    ThreadWs &w = thread_ws(slot);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return;
+    ThreadWs &w = thread_state().at(dev, slot);
     if (w.ptr && w.done && hipEventRecord(w.done, s) == hipSuccess) w.pending = true;
 }
 
+void thread_release_all() { thread_state().release(); }
+
 const DeviceInfo &device_info() {
-    static DeviceInfo info;
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static DeviceInfo info[kMaxDevices];
+    static std::atomic<uint64_t> known{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (!(known.load(std::memory_order_acquire) & (1ull << dev))) {
         hipDeviceProp_t p;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
-            p.multiProcessorCount > 0)
-            info.cu_count = p.multiProcessorCount;
-    });
-    return info;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            info[dev].cu_count = p.multiProcessorCount;
+        known.fetch_or(1ull << dev, std::memory_order_acq_rel);
+    }
+    return info[dev];
 }
 
 // ---------------------------------------------------------------------------------- JSON
@@ -325,15 +454,17 @@ extern "C" {
 const char *qamd_last_error(void) { return qamd::last_error().c_str(); }
 const char *qamd_version(void) { return "quantization_amd 0.1 (gfx950)"; }
 
-int qamd_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
+int qamd_device_count(void) { return qamd::device_count(); }
 
 qamd_status qamd_set_device(int device) {
-    qamd_status st = qamd::ensure_device(device);
-    if (st == QAMD_OK) qamd::g_device = device;
-    return st;
+    const int n = qamd::device_count();
+    if (n <= 0) return qamd::fail(QAMD_ERR_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+    if (device < 0 || device >= n) return qamd::fail(QAMD_ERR_ARGUMENTS, "device %d out of range (have %d)", device, n);
+    qamd::g_device = device;
+    return QAMD_OK;
 }
+
+int qamd_get_device(void) { return qamd::g_device; }
+
+void qamd_thread_release(void) { qamd::thread_release_all(); }
 }

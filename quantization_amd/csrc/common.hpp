@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -33,8 +34,35 @@ qamd_status fail(qamd_status st, const char *fmt, ...) __attribute__((format(pri
         if (_s != QAMD_OK) return _s;     \
     } while (0)
 
-int current_device();  // device chosen by qamd_set_device on this thread
-qamd_status ensure_device(int device);
+int current_device();  // device chosen by qamd_set_device on this thread (default 0)
+int device_count();    // cached after the first successful hipGetDeviceCount
+
+// Makes `device` the calling thread's current HIP device for the lifetime of the guard and
+// restores the caller's device afterwards (a library must not move the current device under
+// its caller -- torch, or another handle's worker).  hipGetDevice is a thread-local read;
+// hipSetDevice runs only when the device really differs, so a thread that stays on one GPU
+// pays no runtime call beyond the read.
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    qamd_status status() const { return st_; }
+
+  private:
+    int prev_ = -1;
+    bool switched_ = false;
+    qamd_status st_ = QAMD_OK;
+};
+#define QAMD_ON_DEVICE(dev)                  \
+    ::qamd::DeviceGuard _qamd_dev_guard(dev); \
+    QAMD_TRY(_qamd_dev_guard.status())
+
+// True the first time it is called with this mask on the CURRENT device (per-device one-time
+// set-up such as hipFuncSetAttribute, which is a per-device property).  Benign when two threads
+// race: the set-up then runs twice.
+bool first_use_on_device(std::atomic<uint64_t> &mask);
 
 // Owning device allocation.
 struct DevBuf {
@@ -81,12 +109,29 @@ struct StreamBuf {
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };
 
+// Orders consumers of an encoded query after the kernel that wrote it.  encode_query only ENQUEUES
+// on the caller's stream, while score_point / score_internal / *_query_read run on the null stream
+// and a caller may score on another stream: side streams created non-blocking are not ordered
+// against the null stream, so the query remembers (stream, event) of its last encode and every
+// consumer on a DIFFERENT stream waits on that event first.
+struct ReadyEvent {
+    hipEvent_t ev = nullptr;
+    hipStream_t stream = nullptr;
+    bool set = false;
+    ReadyEvent() = default;
+    ReadyEvent(const ReadyEvent &) = delete;
+    ReadyEvent &operator=(const ReadyEvent &) = delete;
+    ~ReadyEvent();
+    qamd_status record(hipStream_t s);
+    qamd_status wait(hipStream_t consumer) const;
+};
+
 // Copy helpers: `mem` describes the caller side.
 qamd_status copy_in(void *dev_dst, const void *src, qamd_mem src_mem, size_t bytes, hipStream_t s);
 qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t bytes, hipStream_t s);
 
-// 8 KiB of pinned, device-mapped host memory per calling thread (allocated on first use, never
-// freed: thread exit may come after the HIP runtime is gone).  The per-pair API calls
+// 8 KiB of pinned, device-mapped host memory per calling thread (allocated on first use; freed by
+// qamd_thread_release() or at thread exit).  The per-pair API calls
 // (score_point, score_internal, small score_ids) put their row ids there and let the kernel
 // write the scores straight back: no allocation, no explicit copy, one launch + one sync.
 constexpr size_t kHostScratchWords = 2048 + 16;  // [0, 1024) ids, [1024, 2048) results, [2048] a status word
@@ -96,19 +141,33 @@ struct HostScratch {
 };
 HostScratch host_scratch();
 
-// Grow-only device workspaces per calling thread (and device), handed from call to call in
+// Grow-only device workspaces per calling thread AND device, handed from call to call in
 // stream order: release() records an event on the call's stream, the next acquire() makes its own
 // stream wait on it.  For the whole-store calls' scratch (score vector of a top-k, radix-select
 // state, PQ partial sums): hipMallocAsync + hipFreeAsync cost ~70 us per buffer and call on this
-// runtime, which is most of a top-k on a small store.  Never freed (see host_scratch).
-enum ThreadWsSlot { WS_SCORES = 0, WS_SELECT = 1, WS_PARTIAL = 2, WS_SLOTS = 3 };
-qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out);
+// runtime, which is most of a top-k on a small store.  A thread that alternates between stores
+// on several GPUs keeps one workspace per (slot, device).  Freed by qamd_thread_release() or when
+// the thread exits.
+enum ThreadWsSlot { WS_SCORES = 0, WS_SELECT = 1, WS_PARTIAL = 2, WS_FUSED = 3, WS_SLOTS = 4 };
+// `tags` (optional) points at three caller-owned words that live with the buffer and are zeroed
+// whenever it is (re)allocated: what the caller has cached inside it.
+qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out,
+                              uint64_t **tags = nullptr);
 void thread_ws_release(ThreadWsSlot slot, hipStream_t s);
+// Frees every workspace and the mapped host scratch of the calling thread (all devices).
+void thread_release_all();
+
+// A view of `bytes` of caller memory that kernels on the CURRENT device can read: device memory of
+// this device is used in place; host memory and memory of another device are copied into `stage`
+// (grown on demand) on stream `s`.  `*staged` tells the caller that `stage` is in use until the
+// work it enqueues on `s` has finished.
+qamd_status local_view(const void *src, qamd_mem mem, size_t bytes, DevBuf &stage, hipStream_t s, const void **out,
+                       bool *staged);
 
 struct DeviceInfo {
     int cu_count = 256;
 };
-const DeviceInfo &device_info();
+const DeviceInfo &device_info();  // of the current device
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 

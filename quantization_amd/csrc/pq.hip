@@ -411,21 +411,105 @@ __global__ __launch_bounds__(kBlock) void pq_restride_kernel(const uint8_t *__re
 // ------------------------------------------------------------------------------ k-means (kmeans.rs)
 // All chunks iterate in lockstep; a converged chunk (done[c] != 0) is frozen.
 // sample: [S][dim]; cen: [256][dim] (centroid-major, like Metadata.centroids).
-__global__ __launch_bounds__(kBlock) void km_accumulate_kernel(
-    const float *__restrict__ sample, uint32_t S, uint32_t dim, uint32_t chunk_size, uint32_t m,
-    const uint8_t *__restrict__ assign /*[S][m]*/, const int *__restrict__ done, double *__restrict__ acc /*[256][dim]*/,
-    uint32_t *__restrict__ cnt /*[m][256]*/) {
-    // update_centroids, kmeans.rs:49-100 (f64 sums); the assignment (update_indexes, :139-166) is
-    // the PQ encoder's nearest-centroid kernel, run on the sample with the current centroids
-    const uint32_t c = blockIdx.y;
+//
+// Deterministic and in the reference's summation order: update_centroids (kmeans.rs:49-137)
+// gives each of its `max_threads` workers a contiguous row range (chunk = S / T rows, the last
+// worker takes the remainder, :77-82), every worker adds its rows into f64 accumulators in row
+// order (:84-93), the partials are merged in worker order (:97-108), and the centroid shift is a
+// sequential f32 sum over [centroid][j] (:125-135).  The kernels below do exactly that: rows are
+// grouped per (chunk, centroid) in ascending row order, one thread per centroid value walks its
+// group with the same partial boundaries, one thread per chunk adds up the shifts.  Given the
+// same sample rows and no empty cluster the centroids equal the reference's bit for bit.
+
+// Step 1: per chunk, the rows of every centroid in ascending row order.
+//   order[c][.]: row ids grouped by centroid; start[c][kc] .. start[c][kc+1]: centroid kc's group.
+// One 256-thread workgroup per chunk; thread kc scans the chunk's assignment column (staged in
+// LDS, S bytes) twice: count, then fill.
+__global__ __launch_bounds__(kCentroids) void km_group_kernel(const uint8_t *__restrict__ assign /*[S][m]*/, uint32_t S,
+                                                             uint32_t m, const int *__restrict__ done,
+                                                             uint32_t *__restrict__ order /*[m][S]*/,
+                                                             uint32_t *__restrict__ start /*[m][257]*/) {
+    extern __shared__ uint8_t col[];  // S bytes
+    __shared__ uint32_t cum[kCentroids];
+    const uint32_t c = blockIdx.x, kc = threadIdx.x;
+    if (done[c]) return;  // uniform per workgroup
+    for (uint32_t s0 = kc; s0 < S; s0 += kCentroids) col[s0] = assign[(size_t)s0 * m + c];
+    __syncthreads();
+    uint32_t n = 0;
+    for (uint32_t s0 = 0; s0 < S; s0++) n += col[s0] == kc ? 1u : 0u;
+    cum[kc] = n;
+    __syncthreads();
+    for (int off = 1; off < kCentroids; off <<= 1) {  // inclusive scan
+        const uint32_t v = (int)kc >= off ? cum[kc - off] : 0;
+        __syncthreads();
+        cum[kc] += v;
+        __syncthreads();
+    }
+    uint32_t pos = cum[kc] - n;
+    start[(size_t)c * (kCentroids + 1) + kc] = pos;
+    if (kc == kCentroids - 1) start[(size_t)c * (kCentroids + 1) + kCentroids] = cum[kc];
+    uint32_t *dst = order + (size_t)c * S;
+    for (uint32_t s0 = 0; s0 < S; s0++)
+        if (col[s0] == kc) dst[pos++] = s0;
+}
+
+// Step 2: one thread per centroid value: f64 sums with the reference's partial boundaries, mean,
+// cast to f32 (:110-124), the shift |old - new| kept per value for step 3.
+__global__ __launch_bounds__(kBlock) void km_update_kernel(const float *__restrict__ sample, uint32_t S, uint32_t dim,
+                                                          uint32_t chunk_size, uint32_t m, uint32_t workers,
+                                                          float *__restrict__ cen, const int *__restrict__ done,
+                                                          const uint32_t *__restrict__ order,
+                                                          const uint32_t *__restrict__ start,
+                                                          float *__restrict__ shift /*[256][dim]*/,
+                                                          uint32_t *__restrict__ empties, uint32_t iter) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (uint32_t)kCentroids * dim) return;
+    const uint32_t kc = i / dim, j = i - kc * dim;
+    const uint32_t c = j / chunk_size;
     if (done[c]) return;
-    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= S) return;
+    const uint32_t *st = start + (size_t)c * (kCentroids + 1);
+    const uint32_t lo = st[kc], hi = st[kc + 1];
+    const uint32_t *rows = order + (size_t)c * S;
+    float nv;
+    if (hi == lo) {
+        // kmeans.rs:111-118 takes a thread_rng row; here a fixed hash of (chunk, centroid, iter) --
+        // the one step of the reference that cannot be reproduced (oracle: same rule, stated there)
+        uint32_t hsh = (c * 2654435761u) ^ (kc * 40503u) ^ (iter * 2246822519u);
+        hsh ^= hsh >> 15;
+        hsh *= 2246822519u;
+        hsh ^= hsh >> 13;
+        nv = sample[(size_t)(hsh % S) * dim + j];
+        if (j == c * chunk_size) atomicAdd(empties, 1u);
+    } else {
+        const uint32_t per = S / workers;  // :77
+        double acc = 0.0;
+        uint32_t p = lo;
+        for (uint32_t w = 0; w < workers; w++) {
+            const uint32_t row_end = w + 1 == workers ? S : per * (w + 1);
+            double part = 0.0;
+            while (p < hi && rows[p] < row_end) {
+                part += (double)sample[(size_t)rows[p] * dim + j];
+                p++;
+            }
+            acc += part;  // :101-107
+        }
+        nv = (float)(acc / (double)(hi - lo));
+    }
+    shift[i] = fabsf(cen[i] - nv);  // :127-133
+    cen[i] = nv;
+}
+
+// Step 3: the chunk's total shift, a sequential f32 sum over [centroid][j] (:125-135).
+__global__ __launch_bounds__(64) void km_shift_sum_kernel(const float *__restrict__ shift, uint32_t dim,
+                                                         uint32_t chunk_size, uint32_t m, const int *__restrict__ done,
+                                                         float *__restrict__ diff /*[m]*/) {
+    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= m || done[c]) return;
     const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
-    const uint32_t min_i = assign[(size_t)s * m + c];
-    const float *src = sample + (size_t)s * dim + lo;
-    atomicAdd(&cnt[c * kCentroids + min_i], 1u);
-    for (uint32_t j = 0; j < len; j++) atomicAdd(&acc[(size_t)min_i * dim + lo + j], (double)src[j]);
+    float sum = 0.0f;
+    for (uint32_t kc = 0; kc < (uint32_t)kCentroids; kc++)
+        for (uint32_t j = 0; j < len; j++) sum += shift[(size_t)kc * dim + lo + j];
+    diff[c] = sum;
 }
 
 // The k-means sample: n_out evenly strided rows of a device-resident [count][dim] array.
@@ -439,31 +523,16 @@ __global__ __launch_bounds__(kBlock) void km_gather_rows_kernel(const float *__r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void km_finalize_kernel(const float *__restrict__ sample, uint32_t S,
-                                                            uint32_t dim, uint32_t chunk_size, uint32_t m,
-                                                            float *__restrict__ cen, const int *__restrict__ done,
-                                                            double *__restrict__ acc, const uint32_t *__restrict__ cnt,
-                                                            float *__restrict__ diff /*[m]*/, uint32_t iter) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= (uint32_t)kCentroids * dim) return;
-    const uint32_t kc = i / dim, j = i - kc * dim;
-    const uint32_t c = j / chunk_size;
-    if (done[c]) return;
-    const uint32_t n = cnt[c * kCentroids + kc];
-    float nv;
-    if (n == 0) {
-        // kmeans.rs:111-118 takes a thread_rng row; here a fixed hash of (chunk, centroid, iter)
-        uint32_t hsh = (c * 2654435761u) ^ (kc * 40503u) ^ (iter * 2246822519u);
-        hsh ^= hsh >> 15;
-        hsh *= 2246822519u;
-        hsh ^= hsh >> 13;
-        nv = sample[(size_t)(hsh % S) * dim + j];
-    } else {
-        nv = (float)(acc[i] / (double)n);
+// Streaming form: the sample rows that fall into one batch (rows r_base .. of the whole data).
+__global__ __launch_bounds__(kBlock) void km_gather_batch_kernel(const float *__restrict__ batch, uint64_t r_base,
+                                                                uint32_t dim, uint64_t count, uint64_t n_out,
+                                                                uint64_t k0, uint64_t k1, float *__restrict__ out) {
+    const uint64_t total = (k1 - k0) * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t k = k0 + i / dim, j = i % dim;
+        const uint64_t r = (uint64_t)((unsigned __int128)k * count / n_out);
+        out[k * dim + j] = batch[(r - r_base) * dim + j];
     }
-    atomicAdd(&diff[c], fabsf(cen[i] - nv));  // kmeans.rs:125-135
-    cen[i] = nv;
-    acc[i] = 0.0;
 }
 
 int grid_for(uint64_t work_items, uint64_t per_block, int blocks_per_cu) {
@@ -486,6 +555,9 @@ struct qamd_pq {
     uint64_t count = 0;
     std::vector<float> centroids_host;  // [256][dim]
     DevBuf centroids;                   // same on device
+    uint32_t kmeans_workers = 1;        // max_kmeans_threads: fixes the f64 summation order (kmeans.rs:77-107)
+    uint32_t kmeans_iterations = 0;     // iterations the slowest chunk took (0: centroids were given)
+    uint32_t kmeans_empty_clusters = 0; // clusters re-seeded over all iterations (kmeans.rs:111-118)
     DevBuf rows;                        // [padded][ds]
 };
 
@@ -493,6 +565,7 @@ struct qamd_pq_query {
     int device = 0;
     uint64_t m = 0;
     DevBuf lut;  // m*256 f32
+    ReadyEvent ready;  // the last encode_query
 };
 
 namespace {
@@ -539,13 +612,13 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         const size_t lds = (size_t)std::min<uint32_t>(nvs * 16, m - piece0 * 16) * kCentroids * sizeof(float);
 #define QAMD_PQ_FAST(NVV)                                                                                   \
     case NVV: {                                                                                             \
-        static std::once_flag f;                                                                            \
-        std::call_once(f, [] {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, true>),  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, false>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);         \
-        });                                                                                                 \
+        static std::atomic<uint64_t> set_on{0};                                                             \
+        if (first_use_on_device(set_on)) {                                                                  \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, true>),  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));     \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, false>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));     \
+        }                                                                                                   \
         if (simple)                                                                                         \
             hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, FILTER, true>), dim3(grid), dim3(kScanBlock), lds, s, \
                                h->rows.as<uint4>(), pieces, piece0, lut_dev, m / 4, m, first, last, partial, \
@@ -581,13 +654,13 @@ qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *
     if (!ids_dev && fast_capable(h, n)) {
         return filt ? launch_fast<true>(h, lut_dev, out_dev, filt, s) : launch_fast<false>(h, lut_dev, out_dev, filt, s);
     } else if (in_lds) {
-        static std::once_flag once;  // opt in to > 64 KiB dynamic LDS once per kernel
-        std::call_once(once, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-        });
+        static std::atomic<uint64_t> set_on{0};  // opt in to > 64 KiB dynamic LDS once per kernel and device
+        if (first_use_on_device(set_on)) {
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        }
         const int grid = (int)std::min<uint64_t>(cu, (n + 255) / 256);
         if (vec16) QAMD_PQ_LAUNCH(true, true, grid, lds);
         else QAMD_PQ_LAUNCH(true, false, grid, lds);
@@ -630,11 +703,10 @@ qamd_status launch_assign(const float *src, uint64_t nr, uint64_t dim, uint64_t 
                           uint64_t r0, hipStream_t s) {
     const size_t lds = (size_t)kCentroids * chunk_size * sizeof(float);
     if (lds > kLdsBudget) return fail(QAMD_ERR_ARGUMENTS, "chunk_size %llu too large", (unsigned long long)chunk_size);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_encode_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    });
+    static std::atomic<uint64_t> set_on{0};
+    if (first_use_on_device(set_on))
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_encode_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     const uint32_t gx = (uint32_t)((nr + kBlock - 1) / kBlock);
     // few row blocks -> split the chunk loop over blockIdx.y to fill the chip
     uint32_t slices = 1;
@@ -690,14 +762,67 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
     return QAMD_OK;
 }
 
+// kmeans (kmeans.rs:7-47) for every chunk at once on a device-resident sample [S][dim].
+qamd_status train_from_sample(qamd_pq *h, const float *sample, uint32_t S, qamd_stop_fn stop, void *stop_user,
+                              hipStream_t s) {
+    const uint64_t dim = h->vp.dim;
+    const uint32_t m = (uint32_t)h->m;
+    const uint32_t workers = std::max<uint32_t>(1, h->kmeans_workers);
+    const size_t ncen = (size_t)kCentroids * dim;
+    DevBuf cen, shift, done, diff, assign, order, start, empties, pair_table;
+    QAMD_TRY(cen.alloc(ncen * 4));
+    QAMD_TRY(shift.alloc(ncen * 4));
+    QAMD_TRY(done.alloc((size_t)m * 4, true));
+    QAMD_TRY(diff.alloc((size_t)m * 4));
+    QAMD_TRY(assign.alloc((size_t)S * m));
+    QAMD_TRY(order.alloc((size_t)S * m * 4));
+    QAMD_TRY(start.alloc((size_t)m * (kCentroids + 1) * 4));
+    QAMD_TRY(empties.alloc(4, true));
+    // initial centroids = the first 256 sample rows (kmeans.rs:25)
+    QAMD_HIP(hipMemcpyAsync(cen.ptr, sample, ncen * 4, hipMemcpyDeviceToDevice, s));
+    const bool cs = cs_fast_shape(dim, h->chunk_size);
+    std::vector<int> done_h(m, 0);
+    std::vector<float> diff_h(m);
+    h->kmeans_iterations = 0;
+    for (int iter = 0; iter < kKmeansMaxIter; iter++) {
+        if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // kmeans.rs:29-31
+        // update_indexes (:139-166) = the PQ encoder's own nearest-centroid kernel on the sample
+        if (cs) QAMD_TRY(build_pair_table(cen.as<float>(), dim, h->chunk_size, m, pair_table, s));
+        QAMD_TRY(launch_assign(sample, S, dim, h->chunk_size, m, cen.as<float>(), &pair_table, assign.as<uint8_t>(), m,
+                               0, s));
+        hipLaunchKernelGGL(km_group_kernel, dim3(m), dim3(kCentroids), S, s, assign.as<uint8_t>(), S, m, done.as<int>(),
+                           order.as<uint32_t>(), start.as<uint32_t>());
+        hipLaunchKernelGGL(km_update_kernel, dim3((uint32_t)((ncen + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, sample, S,
+                           (uint32_t)dim, (uint32_t)h->chunk_size, m, workers, cen.as<float>(), done.as<int>(),
+                           order.as<uint32_t>(), start.as<uint32_t>(), shift.as<float>(), empties.as<uint32_t>(),
+                           (uint32_t)iter);
+        hipLaunchKernelGGL(km_shift_sum_kernel, dim3((m + 63) / 64), dim3(64), 0, s, shift.as<float>(), (uint32_t)dim,
+                           (uint32_t)h->chunk_size, m, done.as<int>(), diff.as<float>());
+        QAMD_HIP(hipGetLastError());
+        QAMD_TRY(copy_out(diff_h.data(), QAMD_MEM_HOST, diff.ptr, (size_t)m * 4, s));
+        h->kmeans_iterations = (uint32_t)iter + 1;
+        bool all = true;
+        for (uint32_t c = 0; c < m; c++) {
+            if (!done_h[c] && diff_h[c] < kKmeansAccuracy) done_h[c] = 1;  // :136
+            all = all && done_h[c];
+        }
+        if (all) break;
+        QAMD_TRY(copy_in(done.ptr, done_h.data(), QAMD_MEM_HOST, (size_t)m * 4, s));
+    }
+    QAMD_TRY(copy_out(&h->kmeans_empty_clusters, QAMD_MEM_HOST, empties.ptr, 4, s));
+    std::vector<float> cen_h(ncen);
+    QAMD_TRY(copy_out(cen_h.data(), QAMD_MEM_HOST, cen.ptr, ncen * 4, s));
+    return set_centroids(h, cen_h.data(), s);
+}
+
 // find_centroids (:278-342) for count > 256: k-means on a <= 10 000-row sample.
 qamd_status train_centroids(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_stop_fn stop, void *stop_user,
                             hipStream_t s) {
     const uint64_t dim = h->vp.dim, count = h->count;
     const uint32_t S = (uint32_t)std::min<uint64_t>(kKmeansSample, count);
-    const uint32_t m = (uint32_t)h->m;
     // The reference samples with a random Permutor and sorts the picks (:300-307); here an
-    // evenly strided subset in index order (deterministic; centroid values are parity-unpinned).
+    // evenly strided subset in index order (deterministic; given the same rows the centroids are
+    // the reference's, see the kernels).
     DevBuf sample;
     QAMD_TRY(sample.alloc((size_t)S * dim * 4));
     if (data_mem == QAMD_MEM_HOST) {  // gather on the host, one upload (not S small copies)
@@ -713,46 +838,7 @@ qamd_status train_centroids(qamd_pq *h, const float *data, qamd_mem data_mem, qa
         QAMD_HIP(hipGetLastError());
     }
     if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :303-305
-    const size_t ncen = (size_t)kCentroids * dim;
-    DevBuf cen, acc, cnt, done, diff;
-    QAMD_TRY(cen.alloc(ncen * 4));
-    QAMD_TRY(acc.alloc(ncen * 8, true));
-    QAMD_TRY(cnt.alloc((size_t)m * kCentroids * 4));
-    QAMD_TRY(done.alloc((size_t)m * 4, true));
-    QAMD_TRY(diff.alloc((size_t)m * 4));
-    // initial centroids = the first 256 sample rows (kmeans.rs:25)
-    QAMD_HIP(hipMemcpyAsync(cen.ptr, sample.ptr, ncen * 4, hipMemcpyDeviceToDevice, s));
-    DevBuf assign, pair_table;
-    QAMD_TRY(assign.alloc((size_t)S * m));
-    const bool cs = cs_fast_shape(dim, h->chunk_size);
-    std::vector<int> done_h(m, 0);
-    std::vector<float> diff_h(m);
-    for (int iter = 0; iter < kKmeansMaxIter; iter++) {
-        if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // kmeans.rs:29-31
-        QAMD_HIP(hipMemsetAsync(cnt.ptr, 0, (size_t)m * kCentroids * 4, s));
-        QAMD_HIP(hipMemsetAsync(diff.ptr, 0, (size_t)m * 4, s));
-        if (cs) QAMD_TRY(build_pair_table(cen.as<float>(), dim, h->chunk_size, m, pair_table, s));
-        QAMD_TRY(launch_assign(sample.as<float>(), S, dim, h->chunk_size, m, cen.as<float>(), &pair_table,
-                               assign.as<uint8_t>(), m, 0, s));
-        hipLaunchKernelGGL(km_accumulate_kernel, dim3((S + kBlock - 1) / kBlock, m), dim3(kBlock), 0, s,
-                           sample.as<float>(), S, (uint32_t)dim, (uint32_t)h->chunk_size, m, assign.as<uint8_t>(),
-                           done.as<int>(), acc.as<double>(), cnt.as<uint32_t>());
-        hipLaunchKernelGGL(km_finalize_kernel, dim3((uint32_t)((ncen + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                           sample.as<float>(), S, (uint32_t)dim, (uint32_t)h->chunk_size, m, cen.as<float>(),
-                           done.as<int>(), acc.as<double>(), cnt.as<uint32_t>(), diff.as<float>(), (uint32_t)iter);
-        QAMD_HIP(hipGetLastError());
-        QAMD_TRY(copy_out(diff_h.data(), QAMD_MEM_HOST, diff.ptr, (size_t)m * 4, s));
-        bool all = true;
-        for (uint32_t c = 0; c < m; c++) {
-            if (!done_h[c] && diff_h[c] < kKmeansAccuracy) done_h[c] = 1;
-            all = all && done_h[c];
-        }
-        if (all) break;
-        QAMD_TRY(copy_in(done.ptr, done_h.data(), QAMD_MEM_HOST, (size_t)m * 4, s));
-    }
-    std::vector<float> cen_h(ncen);
-    QAMD_TRY(copy_out(cen_h.data(), QAMD_MEM_HOST, cen.ptr, ncen * 4, s));
-    return set_centroids(h, cen_h.data(), s);
+    return train_from_sample(h, sample.as<float>(), S, stop, stop_user, s);
 }
 
 std::string centroids_json(const qamd_pq *h) {
@@ -780,18 +866,19 @@ uint64_t qamd_pq_quantized_vector_size(const qamd_vector_parameters *vp, uint64_
 qamd_status qamd_pq_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
                            uint64_t chunk_size, const float *centroids, uint32_t max_kmeans_threads,
                            qamd_stop_fn stop, void *stop_user, void *stream, qamd_pq **out) {
-    (void)max_kmeans_threads;  // CPU thread count in the reference; the GPU needs none
     if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
     if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
     if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     hipStream_t s = as_stream(stream);
     std::unique_ptr<qamd_pq> h(new qamd_pq);
     h->device = current_device();
     h->vp = *vp;
     h->chunk_size = chunk_size;
     h->count = vp->count;
+    // the reference's worker count only matters here through the order of its f64 partial sums
+    h->kmeans_workers = std::max<uint32_t>(1, max_kmeans_threads);
     QAMD_TRY(alloc_store(h.get()));
     const uint64_t dim = vp->dim, count = vp->count;
     if (centroids) {
@@ -818,7 +905,7 @@ qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd
     if (!vp || !out || !centroids) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
     if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     hipStream_t s = as_stream(stream);
     std::unique_ptr<qamd_pq> h(new qamd_pq);
     h->device = current_device();
@@ -854,7 +941,7 @@ qamd_status qamd_pq_export_rows(const qamd_pq *h, uint8_t *rows, qamd_mem rows_m
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
     if (h->count == 0 || h->m == 0) return QAMD_OK;
     if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     if (h->m == h->ds) return copy_out(rows, rows_mem, h->rows.ptr, h->count * h->m, s);
     DevBuf stage;
@@ -963,7 +1050,7 @@ qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t 
     if (qdim != h->vp.dim)  // the reference slices query[range] and would panic (:529)
         return fail(QAMD_ERR_ARGUMENTS, "query has %llu dims, store has %llu", (unsigned long long)qdim,
                     (unsigned long long)h->vp.dim);
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     qamd_pq_query *q = *query_io;
     std::unique_ptr<qamd_pq_query> fresh;
@@ -991,6 +1078,7 @@ qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t 
         QAMD_HIP(hipGetLastError());
         if (query_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));  // qtmp is freed on return
     }
+    QAMD_TRY(q->ready.record(s));
     if (fresh) *query_io = fresh.release();
     return QAMD_OK;
 }
@@ -1001,7 +1089,8 @@ qamd_status qamd_pq_query_read(const qamd_pq_query *q, float *lut, uint64_t capa
     if (len) *len = n;
     if (lut) {
         if (capacity < n) return fail(QAMD_ERR_ARGUMENTS, "lut buffer too small");
-        QAMD_TRY(ensure_device(q->device));
+        QAMD_ON_DEVICE(q->device);
+        QAMD_TRY(q->ready.wait(nullptr));
         QAMD_TRY(copy_out(lut, QAMD_MEM_HOST, q->lut.ptr, n * 4, nullptr));
     }
     return QAMD_OK;
@@ -1014,8 +1103,9 @@ qamd_status qamd_pq_score_all(const qamd_pq *h, const qamd_pq_query *q, float *o
     QAMD_TRY(check_query(h, q));
     if (h->count == 0) return QAMD_OK;
     if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     if (out_mem == QAMD_MEM_DEVICE) return scan_launch(h, q->lut.as<float>(), nullptr, h->count, out, s);
     float *tmp = nullptr;  // per-thread workspace: no hipMalloc / hipFree per query
     QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * 4, s, reinterpret_cast<void **>(&tmp)));
@@ -1030,8 +1120,9 @@ qamd_status qamd_pq_score_ids(const qamd_pq *h, const qamd_pq_query *q, const ui
     QAMD_TRY(check_query(h, q));
     if (n_ids == 0) return QAMD_OK;
     if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     DevBuf ids_tmp, out_tmp;
     const uint32_t *ids_dev = ids;
     // per-pair granularity (score_point and friends): ids and results through the calling
@@ -1078,7 +1169,7 @@ qamd_status qamd_pq_score_internal(const qamd_pq *h, uint32_t i, uint32_t j, flo
     if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (i >= h->count || j >= h->count)
         return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     const HostScratch hs = host_scratch();
     DevBuf tmp;
     float *res = hs.host ? reinterpret_cast<float *>(hs.dev + 1024) : nullptr;
@@ -1103,8 +1194,9 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
     QAMD_TRY(check_query(h, q));
     if (k == 0) return QAMD_OK;
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     const float *lut = q->lut.as<float>();
     if (!fast_capable(h, h->count)) {
         float *scores = nullptr;
@@ -1127,4 +1219,198 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
 
 void qamd_pq_free(qamd_pq *h) { delete h; }
 
+qamd_status qamd_pq_kmeans_info(const qamd_pq *h, uint32_t *iterations, uint32_t *empty_clusters) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (iterations) *iterations = h->kmeans_iterations;
+    if (empty_clusters) *empty_clusters = h->kmeans_empty_clusters;
+    return QAMD_OK;
+}
+
 }  // extern "C"
+
+// ============================================================================= streaming encode
+// EncodedVectorsPQ::encode (:56-107) walks its clonable iterator twice: find_centroids (:278-342,
+// the <= 10 000 sampled rows) and encode_storage (:136-226, one code row per vector, pushed in row
+// order).  observe() is the first walk, push() the second, in bounded batches; same kernels and the
+// same sample rows as qamd_pq_encode, so the result is byte-identical to the one-shot call.
+struct qamd_pq_encoder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    qamd_stop_fn stop = nullptr;
+    void *stop_user = nullptr;
+    std::unique_ptr<qamd_pq> h;
+    bool have_centroids = false;
+    uint64_t observed = 0, pushed = 0;
+    uint32_t S = 0;  // sample rows kept by observe()
+    DevBuf sample, stage, pair_table;
+};
+
+namespace {
+
+qamd_status pq_encoder_close_pass1(qamd_pq_encoder *e) {
+    if (e->have_centroids) return QAMD_OK;
+    qamd_pq *h = e->h.get();
+    const uint64_t dim = h->vp.dim, count = h->count;
+    if (e->observed != count)
+        return fail(QAMD_ERR_ARGUMENTS, "observe pass saw %llu of %llu vectors before the first push",
+                    (unsigned long long)e->observed, (unsigned long long)count);
+    if (count <= (uint64_t)kCentroids) {  // :290-297: the vectors themselves, zero-filled up to 256
+        std::vector<float> cen((size_t)kCentroids * dim, 0.0f);
+        if (count && dim) QAMD_TRY(copy_out(cen.data(), QAMD_MEM_HOST, e->sample.ptr, count * dim * 4, e->stream));
+        QAMD_TRY(set_centroids(h, cen.data(), e->stream));
+    } else {
+        if (e->stop && e->stop(e->stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :303-305
+        QAMD_TRY(train_from_sample(h, e->sample.as<float>(), e->S, e->stop, e->stop_user, e->stream));
+    }
+    e->sample.release();
+    e->have_centroids = true;
+    return QAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+qamd_status qamd_pq_encoder_begin(const qamd_vector_parameters *vp, uint64_t chunk_size, const float *centroids,
+                                  uint32_t max_kmeans_threads, qamd_stop_fn stop, void *stop_user, void *stream,
+                                  qamd_pq_encoder **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    QAMD_ON_DEVICE(current_device());
+    std::unique_ptr<qamd_pq_encoder> e(new qamd_pq_encoder);
+    e->device = current_device();
+    e->stream = as_stream(stream);
+    e->stop = stop;
+    e->stop_user = stop_user;
+    e->h.reset(new qamd_pq);
+    qamd_pq *h = e->h.get();
+    h->device = e->device;
+    h->vp = *vp;
+    h->chunk_size = chunk_size;
+    h->count = vp->count;
+    h->kmeans_workers = std::max<uint32_t>(1, max_kmeans_threads);
+    QAMD_TRY(alloc_store(h));
+    if (centroids) {
+        QAMD_TRY(set_centroids(h, centroids, e->stream));
+        e->have_centroids = true;
+    } else {
+        e->S = (uint32_t)std::min<uint64_t>(kKmeansSample, vp->count);
+        QAMD_TRY(e->sample.alloc(std::max<uint64_t>((uint64_t)e->S * vp->dim, 4) * 4));
+    }
+    *out = e.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_encoder_observe(qamd_pq_encoder *e, const float *batch, uint64_t n_rows, qamd_mem batch_mem) {
+    if (!e || (!batch && n_rows && e->h->vp.dim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (e->stop && e->stop(e->stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
+    if (e->have_centroids) {
+        e->observed += n_rows;
+        return QAMD_OK;
+    }
+    const uint64_t dim = e->h->vp.dim, count = e->h->count;
+    if (e->pushed) return fail(QAMD_ERR_ARGUMENTS, "observe after push");
+    if (e->observed + n_rows > count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)(e->observed + n_rows), (unsigned long long)count);
+    QAMD_ON_DEVICE(e->device);
+    const uint64_t piece_rows = std::max<uint64_t>(1, (256ull << 20) / std::max<uint64_t>(dim * 4, 1));
+    for (uint64_t r = 0; r < n_rows && dim && e->S; r += piece_rows) {
+        const uint64_t nr = std::min(piece_rows, n_rows - r), base = e->observed + r;
+        // sample slots whose row floor(k * count / S) falls into [base, base + nr)
+        const uint64_t k0 = (uint64_t)(((unsigned __int128)base * e->S + count - 1) / count);
+        const uint64_t k1 = std::min<uint64_t>(e->S, (uint64_t)(((unsigned __int128)(base + nr) * e->S + count - 1) / count));
+        if (k1 <= k0) continue;
+        const void *src = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(batch + r * dim, batch_mem, nr * dim * 4, e->stage, e->stream, &src, &staged));
+        hipLaunchKernelGGL(km_gather_batch_kernel, dim3(grid_for((k1 - k0) * dim, kBlock * 4, 8)), dim3(kBlock), 0,
+                           e->stream, static_cast<const float *>(src), base, (uint32_t)dim, count, (uint64_t)e->S, k0, k1,
+                           e->sample.as<float>());
+        QAMD_HIP(hipGetLastError());
+        if (staged) QAMD_HIP(hipStreamSynchronize(e->stream));  // the staging buffer is reused
+    }
+    e->observed += n_rows;
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_encoder_push(qamd_pq_encoder *e, const float *batch, uint64_t n_rows, qamd_mem batch_mem) {
+    if (!e || (!batch && n_rows && e->h->vp.dim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (e->stop && e->stop(e->stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :198-200
+    qamd_pq *h = e->h.get();
+    if (e->pushed + n_rows > h->count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)(e->pushed + n_rows), (unsigned long long)h->count);
+    QAMD_ON_DEVICE(e->device);
+    QAMD_TRY(pq_encoder_close_pass1(e));
+    const uint64_t dim = h->vp.dim;
+    if (dim && !e->pair_table.ptr && cs_fast_shape(dim, h->chunk_size))
+        QAMD_TRY(build_pair_table(h->centroids.as<float>(), dim, h->chunk_size, h->m, e->pair_table, e->stream));
+    const uint64_t piece_rows = std::max<uint64_t>(1, (256ull << 20) / std::max<uint64_t>(dim * 4, 1));
+    for (uint64_t r = 0; r < n_rows && dim; r += piece_rows) {
+        const uint64_t nr = std::min(piece_rows, n_rows - r);
+        const void *src = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(batch + r * dim, batch_mem, nr * dim * 4, e->stage, e->stream, &src, &staged));
+        QAMD_TRY(launch_assign(static_cast<const float *>(src), nr, dim, h->chunk_size, h->m, h->centroids.as<float>(),
+                               &e->pair_table, h->rows.as<uint8_t>(), h->ds, e->pushed + r, e->stream));
+        if (staged) QAMD_HIP(hipStreamSynchronize(e->stream));
+    }
+    e->pushed += n_rows;
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_encoder_finish(qamd_pq_encoder *e, qamd_pq **out) {
+    if (!e || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_pq_encoder> own(e);
+    if (e->pushed != e->h->count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)e->pushed, (unsigned long long)e->h->count);
+    QAMD_ON_DEVICE(e->device);
+    QAMD_TRY(pq_encoder_close_pass1(e));  // count == 0, or a caller that never pushed an empty store
+    QAMD_HIP(hipStreamSynchronize(e->stream));
+    if (e->stop && e->stop(e->stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :95-106
+    *out = e->h.release();
+    return QAMD_OK;
+}
+
+void qamd_pq_encoder_abort(qamd_pq_encoder *e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    delete e;
+}
+
+}  // extern "C"
+
+namespace qamd {
+
+// find_centroids (:278-342) on its own: what the sharded encoder (sharded.hip) runs once before
+// every shard encodes with the result.  Runs on the current device.
+qamd_status pq_train_centroids(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                               uint64_t chunk_size, uint32_t max_kmeans_threads, qamd_stop_fn stop, void *stop_user,
+                               hipStream_t s, std::vector<float> &centroids, uint32_t *iterations, uint32_t *empties) {
+    qamd_pq tmp;
+    tmp.vp = *vp;
+    tmp.chunk_size = chunk_size;
+    tmp.count = vp->count;
+    tmp.m = chunks_of(vp->dim, chunk_size);
+    tmp.kmeans_workers = std::max<uint32_t>(1, max_kmeans_threads);
+    const uint64_t dim = vp->dim, count = vp->count;
+    if (count <= (uint64_t)kCentroids) {  // :290-297
+        centroids.assign((size_t)kCentroids * dim, 0.0f);
+        if (count && dim) {
+            if (data_mem == QAMD_MEM_HOST) memcpy(centroids.data(), data, count * dim * 4);
+            else QAMD_TRY(copy_out(centroids.data(), QAMD_MEM_HOST, data, count * dim * 4, s));
+        }
+    } else {
+        QAMD_TRY(train_centroids(&tmp, data, data_mem, stop, stop_user, s));
+        centroids = tmp.centroids_host;
+    }
+    if (iterations) *iterations = tmp.kmeans_iterations;
+    if (empties) *empties = tmp.kmeans_empty_clusters;
+    return QAMD_OK;
+}
+
+}  // namespace qamd

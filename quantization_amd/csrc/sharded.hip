@@ -1,0 +1,887 @@
+// Row-sharded stores: ONE process drives several GPUs of a node through one handle.
+//
+// The reference has no multi-device path; its caller is one process looping score_point over the
+// whole store (demos/src/ann_benchmark.rs:245-260) and keeping the best 30 in a heap
+// (demos/src/ann_benchmark_data.rs:151-167).  Rows are independent, the metadata (alpha/offset/
+// multiplier, centroids) is global and tiny, the query is replicated: so shard g of G owns the
+// contiguous row range [g*N/G, (g+1)*N/G) as an ordinary single-device handle on devices[g], and a
+// global row id is shard base + local id.  `devices[]` may name one device several times (logical
+// shards: how the single-GPU tests exercise the index arithmetic and the merge).
+//
+// Execution: one persistent worker thread per shard, bound to the shard's device with its own
+// stream; a call posts one job per worker (so the G scans / top-ks run concurrently, each
+// worker owning its per-thread workspaces) and waits.  Then exactly one exchange:
+//   score_all : every shard's scores go straight to their slice of the output — host output: one
+//               D2H copy per GPU over its own PCIe link; device output (on devices[0]): a peer copy
+//               over xGMI (hipMemcpyAsync, 4 B/row), the single-process form of the score gather.
+//   topk      : per-shard exact top-k (k pairs), peer copy of the G*k pairs to devices[0], ONE
+//               merge kernel there (bitonic sort on (score key, global id): the single-handle tie
+//               rule), result out through mapped host memory — no per-query host merge.
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.hpp"
+#include "topk_device.hpp"
+#include "u8_internal.hpp"
+
+using namespace qamd;
+
+namespace qamd {
+// pq.hip: find_centroids only (the sharded encoder trains once, then every shard encodes with the result)
+qamd_status pq_train_centroids(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                               uint64_t chunk_size, uint32_t max_kmeans_threads, qamd_stop_fn stop, void *stop_user,
+                               hipStream_t s, std::vector<float> &centroids, uint32_t *iterations, uint32_t *empties);
+}  // namespace qamd
+
+namespace {
+
+// ------------------------------------------------------------------------------------ workers
+struct Worker {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<qamd_status()> job;
+    bool has_job = false, quit = false, finished = false;
+    qamd_status result = QAMD_OK;
+    std::string error;
+
+    void loop() {
+        (void)hipSetDevice(device);
+        (void)qamd_set_device(device);  // handles this thread creates live on the shard's device
+        (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        for (;;) {
+            std::function<qamd_status()> fn;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return has_job || quit; });
+                if (quit) break;
+                fn = std::move(job);
+                has_job = false;
+            }
+            qamd_status st = fn();
+            std::string err = st == QAMD_OK ? std::string() : last_error();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                result = st;
+                error = std::move(err);
+                finished = true;
+            }
+            cv.notify_all();
+        }
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        thread_release_all();  // this thread's workspaces go with it
+    }
+
+    void post(std::function<qamd_status()> fn) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(fn);
+            has_job = true;
+            finished = false;
+        }
+        cv.notify_all();
+    }
+
+    qamd_status wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return finished; });
+        if (result != QAMD_OK) last_error() = error;
+        return result;
+    }
+};
+
+struct Pool {
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::mutex call;  // one sharded call at a time per handle
+
+    qamd_status start(const int *devices, uint32_t n) {
+        const int have = device_count();
+        if (have <= 0) return fail(QAMD_ERR_DEVICE, "no HIP device is visible; this library has no CPU fallback");
+        for (uint32_t g = 0; g < n; g++)
+            if (devices[g] < 0 || devices[g] >= have)
+                return fail(QAMD_ERR_ARGUMENTS, "shard %u: device %d out of range (have %d)", g, devices[g], have);
+        for (uint32_t g = 0; g < n; g++) {
+            std::unique_ptr<Worker> w(new Worker);
+            w->device = devices[g];
+            Worker *raw = w.get();
+            w->th = std::thread([raw] { raw->loop(); });
+            workers.push_back(std::move(w));
+        }
+        return QAMD_OK;
+    }
+
+    // fn(g, worker) on every shard's worker concurrently; first failure wins.
+    qamd_status run(const std::function<qamd_status(uint32_t, Worker &)> &fn) {
+        for (uint32_t g = 0; g < workers.size(); g++) {
+            Worker *w = workers[g].get();
+            w->post([&fn, g, w] { return fn(g, *w); });
+        }
+        qamd_status st = QAMD_OK;
+        std::string err;
+        for (auto &w : workers) {
+            const qamd_status r = w->wait();
+            if (r != QAMD_OK && st == QAMD_OK) {
+                st = r;
+                err = last_error();
+            }
+        }
+        if (st != QAMD_OK) last_error() = err;
+        return st;
+    }
+
+    ~Pool() {
+        for (auto &w : workers) {
+            {
+                std::lock_guard<std::mutex> lk(w->m);
+                w->quit = true;
+            }
+            w->cv.notify_all();
+        }
+        for (auto &w : workers)
+            if (w->th.joinable()) w->th.join();
+    }
+};
+
+// ------------------------------------------------------------------------------------ merge
+// One workgroup per query: the G per-shard lists (k pairs each, local ids) become the global best
+// k.  Keys are (order-preserving score bits << 32 | global id), all distinct, so the result is the
+// single-handle one: best first, ties to the lower global row id.
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const uint32_t *__restrict__ ids /*[G][Q][k]*/,
+                                                         const float *__restrict__ scores /*[G][Q][k]*/,
+                                                         const uint64_t *__restrict__ bases /*[G]*/, uint32_t G, uint32_t Q,
+                                                         uint32_t k, int largest, uint32_t N /* pow2 >= G*k */,
+                                                         uint32_t *__restrict__ out_ids /*[Q][k]*/,
+                                                         float *__restrict__ out_scores) {
+    extern __shared__ unsigned long long keys[];  // N
+    const uint32_t q = blockIdx.x, t = threadIdx.x, total = G * k;
+    for (uint32_t i = t; i < N; i += 1024) {
+        unsigned long long key = ~0ull;
+        if (i < total) {
+            const uint32_t g = i / k, j = i - g * k;
+            const size_t at = ((size_t)g * Q + q) * k + j;
+            const uint32_t id = ids[at];
+            if (id != 0xFFFFFFFFu)  // a shard shorter than k pads its list
+                key = ((unsigned long long)topk_ordered_bits(scores[at], largest != 0) << 32) | (uint32_t)(bases[g] + id);
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= N; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = t; i < N / 2; i += 1024) {
+                const uint32_t a = 2 * i - (i & (stride - 1)), b = a + stride;
+                const bool up = (a & size) == 0;
+                const unsigned long long x = keys[a], y = keys[b];
+                if ((x > y) == up) {
+                    keys[a] = y;
+                    keys[b] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = t; i < k; i += 1024) {
+        const unsigned long long key = i < N ? keys[i] : ~0ull;
+        if (key != ~0ull) {
+            out_ids[(size_t)q * k + i] = (uint32_t)(key & 0xFFFFFFFFull);
+            out_scores[(size_t)q * k + i] = topk_score_of_key((uint32_t)(key >> 32), largest != 0);
+        } else {
+            out_ids[(size_t)q * k + i] = 0xFFFFFFFFu;
+            out_scores[(size_t)q * k + i] = largest ? -__builtin_huge_valf() : __builtin_huge_valf();
+        }
+    }
+}
+
+uint32_t pow2_at_least(uint32_t v) {
+    uint32_t n = 64;
+    while (n < v) n <<= 1;
+    return n;
+}
+
+void shard_bounds(uint64_t count, uint32_t G, std::vector<uint64_t> &base) {
+    base.resize(G + 1);
+    for (uint32_t g = 0; g <= G; g++) base[g] = (uint64_t)((unsigned __int128)g * count / G);
+}
+
+// Which device owns `ptr` (device memory), or -1.
+int device_of(const void *ptr) {
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return attr.device;
+}
+
+// ------------------------------------------------------------------------------------ generic store
+// Ops: the single-device C ABI of one quantizer (identical shapes for u8 / bin / pq).
+template <class H, class Qy> struct Ops {
+    qamd_status (*encode_query)(const H *, const float *, uint64_t, qamd_mem, void *, Qy **);
+    void (*query_free)(Qy *);
+    qamd_status (*score_all)(const H *, const Qy *, float *, qamd_mem, void *);
+    qamd_status (*topk)(const H *, const Qy *, uint32_t, int, uint32_t *, float *, qamd_mem, void *);
+    void (*free_store)(H *);
+};
+
+template <class H, class Qy> struct ShardedQuery {
+    std::vector<Qy *> per_shard;
+    const Ops<H, Qy> *ops = nullptr;
+    ~ShardedQuery() {
+        for (Qy *q : per_shard)
+            if (q) ops->query_free(q);
+    }
+};
+
+template <class H, class Qy> struct Sharded {
+    const Ops<H, Qy> *ops = nullptr;
+    uint64_t count = 0;
+    std::vector<int> devices;
+    std::vector<uint64_t> base;  // G + 1 row bounds
+    std::vector<H *> shards;
+    Pool pool;
+    // root (devices[0]) side of the top-k exchange
+    hipStream_t root_stream = nullptr;
+    DevBuf gather, bases_dev, result;  // [G][Q][k] ids | [G][Q][k] scores ; [G] u64 ; [Q][k] ids | scores
+    size_t gather_cap = 0, result_cap = 0;
+    // per shard, on the shard's device: its k pairs / its scores before the peer copy
+    std::vector<DevBuf> local_pairs, local_scores, query_stage;
+
+    uint32_t G() const { return (uint32_t)shards.size(); }
+    int root() const { return devices[0]; }
+
+    qamd_status init(const int *devs, uint32_t n, uint64_t total) {
+        if (!devs || n == 0 || n > 64) return fail(QAMD_ERR_ARGUMENTS, "need 1..64 shards");
+        if (total > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+        count = total;
+        devices.assign(devs, devs + n);
+        shard_bounds(total, n, base);
+        shards.assign(n, nullptr);
+        local_pairs.resize(n);
+        local_scores.resize(n);
+        query_stage.resize(n);
+        QAMD_TRY(pool.start(devs, n));
+        QAMD_ON_DEVICE(root());
+        QAMD_HIP(hipStreamCreateWithFlags(&root_stream, hipStreamNonBlocking));
+        QAMD_TRY(bases_dev.alloc(n * sizeof(uint64_t)));
+        QAMD_TRY(copy_in(bases_dev.ptr, base.data(), QAMD_MEM_HOST, n * sizeof(uint64_t), root_stream));
+        return QAMD_OK;
+    }
+
+    ~Sharded() {
+        for (H *h : shards)
+            if (h) ops->free_store(h);
+        if (root_stream) {
+            DeviceGuard g(root());
+            (void)hipStreamSynchronize(root_stream);
+            (void)hipStreamDestroy(root_stream);
+        }
+    }
+
+    qamd_status encode_query(const float *query, uint64_t qdim, qamd_mem mem, ShardedQuery<H, Qy> **io) {
+        std::unique_ptr<ShardedQuery<H, Qy>> fresh;
+        ShardedQuery<H, Qy> *q = *io;
+        if (!q) {
+            fresh.reset(new ShardedQuery<H, Qy>);
+            q = fresh.get();
+            q->ops = ops;
+            q->per_shard.assign(G(), nullptr);
+        }
+        if (q->per_shard.size() != G()) return fail(QAMD_ERR_ARGUMENTS, "query belongs to another sharded store");
+        const int src_dev = mem == QAMD_MEM_DEVICE ? device_of(query) : -1;
+        std::lock_guard<std::mutex> lk(pool.call);
+        QAMD_TRY(pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+            const float *src = query;
+            if (mem == QAMD_MEM_DEVICE && src_dev != w.device && qdim) {  // a device query lives on ONE GPU
+                if (query_stage[g].bytes < qdim * 4) QAMD_TRY(query_stage[g].alloc(qdim * 4));
+                QAMD_HIP(hipMemcpyAsync(query_stage[g].ptr, query, qdim * 4, hipMemcpyDefault, w.stream));
+                src = query_stage[g].template as<float>();
+            }
+            QAMD_TRY(qamd_set_device(w.device));
+            QAMD_TRY(ops->encode_query(shards[g], src, qdim, mem, w.stream, &q->per_shard[g]));
+            QAMD_HIP(hipStreamSynchronize(w.stream));
+            return QAMD_OK;
+        }));
+        if (fresh) *io = fresh.release();
+        return QAMD_OK;
+    }
+
+    qamd_status check(const ShardedQuery<H, Qy> *q) const {
+        if (!q || q->per_shard.size() != shards.size()) return fail(QAMD_ERR_ARGUMENTS, "null or foreign sharded query");
+        for (Qy *p : q->per_shard)
+            if (!p) return fail(QAMD_ERR_ARGUMENTS, "sharded query was never encoded");
+        return QAMD_OK;
+    }
+
+    // out[base_g + i] = score_point(q, i of shard g).  Device output lives on devices[0].
+    qamd_status score_all(const ShardedQuery<H, Qy> *q, float *out, qamd_mem out_mem) {
+        QAMD_TRY(check(q));
+        if (count == 0) return QAMD_OK;
+        if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
+        const int out_dev = out_mem == QAMD_MEM_DEVICE ? device_of(out) : -1;
+        std::lock_guard<std::mutex> lk(pool.call);
+        return pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+            const uint64_t n = base[g + 1] - base[g];
+            if (n == 0) return QAMD_OK;
+            float *dst = out + base[g];
+            if (out_mem == QAMD_MEM_HOST || out_dev == w.device) {
+                QAMD_TRY(ops->score_all(shards[g], q->per_shard[g], dst, out_mem, w.stream));
+            } else {  // the per-shard score gather over xGMI: scan locally, peer-copy 4 B/row
+                if (local_scores[g].bytes < n * 4) QAMD_TRY(local_scores[g].alloc(n * 4));
+                QAMD_TRY(ops->score_all(shards[g], q->per_shard[g], local_scores[g].template as<float>(), QAMD_MEM_DEVICE,
+                                        w.stream));
+                QAMD_HIP(hipMemcpyAsync(dst, local_scores[g].ptr, n * 4, hipMemcpyDefault, w.stream));
+            }
+            QAMD_HIP(hipStreamSynchronize(w.stream));
+            return QAMD_OK;
+        });
+    }
+
+    qamd_status ensure_exchange(uint32_t Q, uint32_t k) {
+        const size_t need = (size_t)G() * Q * k * 8, res = (size_t)Q * k * 8;
+        if (gather_cap < need) {
+            QAMD_TRY(gather.alloc(need + need / 4));
+            gather_cap = need + need / 4;
+        }
+        if (result_cap < res) {
+            QAMD_TRY(result.alloc(res + res / 4));
+            result_cap = res + res / 4;
+        }
+        return QAMD_OK;
+    }
+
+    // Runs the merge of [G][Q][k] gathered pairs on devices[0] and delivers [Q][k] ids / scores.
+    qamd_status merge_and_deliver(uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                                  qamd_mem out_mem) {
+        const uint32_t N = pow2_at_least(G() * k);
+        if ((size_t)N * 8 > 64 * 1024) return fail(QAMD_ERR_ARGUMENTS, "shards x k = %u exceeds 8192 merge slots", G() * k);
+        const uint32_t *g_ids = gather.as<uint32_t>();
+        const float *g_sc = reinterpret_cast<const float *>(g_ids + (size_t)G() * Q * k);
+        const HostScratch hs = (out_mem == QAMD_MEM_HOST && Q == 1) ? host_scratch() : HostScratch{};
+        uint32_t *ids_dev = out_mem == QAMD_MEM_DEVICE ? out_ids : hs.host ? hs.dev : result.as<uint32_t>();
+        float *sc_dev = out_mem == QAMD_MEM_DEVICE ? out_scores
+                        : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
+                                                : reinterpret_cast<float *>(result.as<uint32_t>() + (size_t)Q * k);
+        hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(1024), (size_t)N * 8, root_stream, g_ids, g_sc,
+                           bases_dev.as<uint64_t>(), G(), Q, k, largest, N, ids_dev, sc_dev);
+        QAMD_HIP(hipGetLastError());
+        if (out_mem == QAMD_MEM_HOST && !hs.host) {
+            QAMD_HIP(hipMemcpyAsync(out_ids, ids_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, root_stream));
+            QAMD_HIP(hipMemcpyAsync(out_scores, sc_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, root_stream));
+        }
+        QAMD_HIP(hipStreamSynchronize(root_stream));
+        if (hs.host) {
+            memcpy(out_ids, hs.host, (size_t)k * 4);
+            memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
+        }
+        return QAMD_OK;
+    }
+
+    // Shard g's [Q][k] pairs -> slot g of the gather buffer on devices[0] (after the shard's top-k).
+    // `fn` runs the shard's own top-k with device outputs (ids, scores) on the worker's stream.
+    qamd_status topk_common(uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem,
+                            const std::function<qamd_status(uint32_t, Worker &, uint32_t *, float *)> &fn) {
+        if (k == 0 || Q == 0) return QAMD_OK;
+        if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
+        if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
+        if (out_mem == QAMD_MEM_DEVICE && device_of(out_ids) != root())
+            return fail(QAMD_ERR_ARGUMENTS, "device outputs of a sharded top-k must live on devices[0] (%d)", root());
+        std::lock_guard<std::mutex> lk(pool.call);
+        QAMD_ON_DEVICE(root());
+        QAMD_TRY(ensure_exchange(Q, k));
+        uint32_t *g_ids = gather.as<uint32_t>();
+        float *g_sc = reinterpret_cast<float *>(g_ids + (size_t)G() * Q * k);
+        const size_t per = (size_t)Q * k;
+        QAMD_TRY(pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+            uint32_t *slot_ids = g_ids + g * per;
+            float *slot_sc = g_sc + g * per;
+            if (w.device == root()) {  // same GPU: the shard's top-k writes its slot directly
+                QAMD_TRY(fn(g, w, slot_ids, slot_sc));
+            } else {  // k pairs per query over xGMI
+                if (local_pairs[g].bytes < per * 8) QAMD_TRY(local_pairs[g].alloc(per * 8));
+                uint32_t *l_ids = local_pairs[g].template as<uint32_t>();
+                float *l_sc = reinterpret_cast<float *>(l_ids + per);
+                QAMD_TRY(fn(g, w, l_ids, l_sc));
+                QAMD_HIP(hipMemcpyAsync(slot_ids, l_ids, per * 4, hipMemcpyDefault, w.stream));
+                QAMD_HIP(hipMemcpyAsync(slot_sc, l_sc, per * 4, hipMemcpyDefault, w.stream));
+            }
+            QAMD_HIP(hipStreamSynchronize(w.stream));
+            return QAMD_OK;
+        }));
+        return merge_and_deliver(Q, k, largest, out_ids, out_scores, out_mem);
+    }
+
+    qamd_status topk(const ShardedQuery<H, Qy> *q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                     qamd_mem out_mem) {
+        QAMD_TRY(check(q));
+        return topk_common(1, k, largest, out_ids, out_scores, out_mem,
+                           [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
+                               return ops->topk(shards[g], q->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE, w.stream);
+                           });
+    }
+};
+
+// A shard's slice of caller memory as something its own device can take: host memory and memory of
+// the shard's device pass through; memory of ANOTHER device is staged whole (peer copy).
+qamd_status shard_source(const void *src, qamd_mem mem, size_t bytes, int device, DevBuf &stage, hipStream_t s,
+                         const void **out) {
+    *out = src;
+    if (mem == QAMD_MEM_HOST || bytes == 0 || device_of(src) == device) return QAMD_OK;
+    QAMD_TRY(stage.alloc(bytes));
+    QAMD_HIP(hipMemcpyAsync(stage.ptr, src, bytes, hipMemcpyDefault, s));
+    QAMD_HIP(hipStreamSynchronize(s));
+    *out = stage.ptr;
+    return QAMD_OK;
+}
+
+const Ops<qamd_u8, qamd_u8_query> kU8Ops = {qamd_u8_encode_query, qamd_u8_query_free, qamd_u8_score_all, qamd_u8_topk,
+                                            qamd_u8_free};
+const Ops<qamd_bin, qamd_bin_query> kBinOps = {qamd_bin_encode_query, qamd_bin_query_free, qamd_bin_score_all,
+                                               qamd_bin_topk, qamd_bin_free};
+const Ops<qamd_pq, qamd_pq_query> kPqOps = {qamd_pq_encode_query, qamd_pq_query_free, qamd_pq_score_all, qamd_pq_topk,
+                                            qamd_pq_free};
+
+}  // namespace
+
+struct qamd_u8_sharded : Sharded<qamd_u8, qamd_u8_query> {
+    qamd_u8_metadata meta{};
+};
+struct qamd_u8_sharded_query : ShardedQuery<qamd_u8, qamd_u8_query> {};
+struct qamd_u8_sharded_query_batch {
+    std::vector<qamd_u8_query_batch *> per_shard;
+    uint64_t n_queries = 0;
+    ~qamd_u8_sharded_query_batch() {
+        for (auto *b : per_shard)
+            if (b) qamd_u8_query_batch_free(b);
+    }
+};
+struct qamd_bin_sharded : Sharded<qamd_bin, qamd_bin_query> {
+    qamd_vector_parameters vp{};
+    int store = 0;
+};
+struct qamd_bin_sharded_query : ShardedQuery<qamd_bin, qamd_bin_query> {};
+struct qamd_pq_sharded : Sharded<qamd_pq, qamd_pq_query> {
+    qamd_vector_parameters vp{};
+    uint64_t chunk_size = 0;
+    std::vector<float> centroids;
+};
+struct qamd_pq_sharded_query : ShardedQuery<qamd_pq, qamd_pq_query> {};
+
+extern "C" {
+
+// ===================================================================================== u8
+qamd_status qamd_u8_sharded_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                                   const float *quantile, const float *alpha_offset, qamd_stop_fn stop, void *stop_user,
+                                   const int *devices, uint32_t n_shards, qamd_u8_sharded **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
+    std::unique_ptr<qamd_u8_sharded> h(new qamd_u8_sharded);
+    h->ops = &kU8Ops;
+    QAMD_TRY(h->init(devices, n_shards, vp->count));
+    const uint64_t dim = vp->dim;
+    float ao[2] = {0.0f, 0.0f};
+    if (alpha_offset) {
+        ao[0] = alpha_offset[0];
+        ao[1] = alpha_offset[1];
+    } else if (vp->count) {
+        // PASS 1 (encoded_vectors_u8.rs:57): every shard folds min/max over its own rows, the host
+        // folds the G results -- min and max do not depend on the order.
+        std::vector<float> mn(n_shards, 3.40282347e+38f), mx(n_shards, -3.40282347e+38f);
+        QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+            const uint64_t n = h->base[g + 1] - h->base[g];
+            if (n == 0 || dim == 0) return QAMD_OK;
+            if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
+            return u8_minmax_range(data + h->base[g] * dim, data_mem, n, dim, w.stream, &mn[g], &mx[g]);
+        }));
+        float lo = 3.40282347e+38f, hi = -3.40282347e+38f;
+        for (uint32_t g = 0; g < n_shards; g++) {
+            if (mn[g] < lo) lo = mn[g];
+            if (mx[g] > hi) hi = mx[g];
+        }
+        ao[0] = (hi - lo) / 127.0f;  // :228-232
+        ao[1] = lo;
+        if (quantile) {  // PASS 1b (:58-71): one device sees the whole sample
+            bool found = false;
+            float qmn = 0.0f, qmx = 0.0f;
+            const int qdev = data_mem == QAMD_MEM_DEVICE ? device_of(data) : h->root();
+            QAMD_ON_DEVICE(qdev < 0 ? h->root() : qdev);
+            QAMD_TRY(u8_quantile_interval(data, data_mem, vp->count, dim, *quantile, nullptr, &found, &qmn, &qmx));
+            if (found) {
+                ao[0] = (qmx - qmn) / 127.0f;
+                ao[1] = qmn;
+            }
+        }
+    }
+    // PASS 2 (:73-118): every shard quantizes its own rows with the global (alpha, offset).
+    QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+        qamd_vector_parameters svp = *vp;
+        svp.count = h->base[g + 1] - h->base[g];
+        QAMD_TRY(qamd_set_device(w.device));
+        qamd_u8_encoder *e = nullptr;
+        QAMD_TRY(qamd_u8_encoder_begin(&svp, nullptr, vp->count ? ao : nullptr, stop, stop_user, w.stream, &e));
+        qamd_status st = qamd_u8_encoder_push(e, data + h->base[g] * dim, svp.count, data_mem);
+        if (st != QAMD_OK) {
+            qamd_u8_encoder_abort(e);
+            return st;
+        }
+        return qamd_u8_encoder_finish(e, &h->shards[g]);
+    }));
+    QAMD_TRY(qamd_u8_get_metadata(h->shards[0], &h->meta));
+    if (vp->count && h->shards[0]->count == 0) {  // an empty first shard holds the empty-store metadata
+        for (uint32_t g = 0; g < n_shards; g++)
+            if (h->shards[g]->count) {
+                QAMD_TRY(qamd_u8_get_metadata(h->shards[g], &h->meta));
+                break;
+            }
+    }
+    h->meta.vector_parameters = *vp;
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_u8_metadata *meta,
+                                      const int *devices, uint32_t n_shards, qamd_u8_sharded **out) {
+    if (!meta || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_u8_sharded> h(new qamd_u8_sharded);
+    h->ops = &kU8Ops;
+    h->meta = *meta;
+    QAMD_TRY(h->init(devices, n_shards, meta->vector_parameters.count));
+    const uint64_t stride = meta->actual_dim + 4;
+    QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+        qamd_u8_metadata sm = *meta;
+        sm.vector_parameters.count = h->base[g + 1] - h->base[g];
+        DevBuf stage;
+        const void *src = nullptr;
+        QAMD_TRY(shard_source(rows ? rows + h->base[g] * stride : nullptr, rows_mem, sm.vector_parameters.count * stride,
+                              w.device, stage, w.stream, &src));
+        QAMD_TRY(qamd_set_device(w.device));
+        return qamd_u8_from_rows(static_cast<const uint8_t *>(src), rows_mem, &sm, w.stream, &h->shards[g]);
+    }));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+uint32_t qamd_u8_sharded_shard_count(const qamd_u8_sharded *h) { return h ? h->G() : 0; }
+
+qamd_status qamd_u8_sharded_shard(const qamd_u8_sharded *h, uint32_t g, const qamd_u8 **shard, uint64_t *row_begin,
+                                  int *device) {
+    if (!h || g >= h->G()) return fail(QAMD_ERR_ARGUMENTS, "no such shard");
+    if (shard) *shard = h->shards[g];
+    if (row_begin) *row_begin = h->base[g];
+    if (device) *device = h->devices[g];
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_sharded_get_metadata(const qamd_u8_sharded *h, qamd_u8_metadata *out) {
+    if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    *out = h->meta;
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_sharded_encode_query(qamd_u8_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem,
+                                         qamd_u8_sharded_query **query_io) {
+    if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    ShardedQuery<qamd_u8, qamd_u8_query> *q = *query_io;
+    const bool fresh = q == nullptr;
+    if (fresh) {
+        auto *nq = new qamd_u8_sharded_query;
+        nq->ops = &kU8Ops;
+        nq->per_shard.assign(h->G(), nullptr);
+        q = nq;
+    }
+    qamd_status st = h->encode_query(query, qdim, query_mem, &q);
+    if (st != QAMD_OK) {
+        if (fresh) delete static_cast<qamd_u8_sharded_query *>(q);
+        return st;
+    }
+    *query_io = static_cast<qamd_u8_sharded_query *>(q);
+    return QAMD_OK;
+}
+
+void qamd_u8_sharded_query_free(qamd_u8_sharded_query *q) { delete q; }
+
+qamd_status qamd_u8_sharded_score_all(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, float *out, qamd_mem out_mem) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return h->score_all(q, out, out_mem);
+}
+
+qamd_status qamd_u8_sharded_topk(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, uint32_t k, int largest,
+                                 uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+}
+
+qamd_status qamd_u8_sharded_encode_query_batch(qamd_u8_sharded *h, const float *queries, uint64_t n_queries, uint64_t qdim,
+                                               qamd_mem queries_mem, qamd_u8_sharded_query_batch **batch_io) {
+    if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_u8_sharded_query_batch> fresh;
+    qamd_u8_sharded_query_batch *b = *batch_io;
+    if (!b) {
+        fresh.reset(new qamd_u8_sharded_query_batch);
+        b = fresh.get();
+        b->per_shard.assign(h->G(), nullptr);
+    }
+    if (b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "batch belongs to another sharded store");
+    const int src_dev = queries_mem == QAMD_MEM_DEVICE ? device_of(queries) : -1;
+    const size_t bytes = (size_t)n_queries * qdim * 4;
+    {
+        std::lock_guard<std::mutex> lk(h->pool.call);
+        QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+            const float *src = queries;
+            if (queries_mem == QAMD_MEM_DEVICE && src_dev != w.device && bytes) {
+                if (h->query_stage[g].bytes < bytes) QAMD_TRY(h->query_stage[g].alloc(bytes));
+                QAMD_HIP(hipMemcpyAsync(h->query_stage[g].ptr, queries, bytes, hipMemcpyDefault, w.stream));
+                src = h->query_stage[g].as<float>();
+            }
+            QAMD_TRY(qamd_set_device(w.device));
+            QAMD_TRY(qamd_u8_encode_query_batch(h->shards[g], src, n_queries, qdim, queries_mem, w.stream, &b->per_shard[g]));
+            QAMD_HIP(hipStreamSynchronize(w.stream));
+            return QAMD_OK;
+        }));
+    }
+    b->n_queries = n_queries;
+    if (fresh) *batch_io = fresh.release();
+    return QAMD_OK;
+}
+
+void qamd_u8_sharded_query_batch_free(qamd_u8_sharded_query_batch *b) { delete b; }
+
+qamd_status qamd_u8_sharded_topk_batch(qamd_u8_sharded *h, const qamd_u8_sharded_query_batch *b, uint32_t k, int largest,
+                                       uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+    if (!h || !b || b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "null or foreign argument");
+    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem,
+                          [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
+                              return qamd_u8_topk_batch(h->shards[g], b->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE,
+                                                        w.stream);
+                          });
+}
+
+void qamd_u8_sharded_free(qamd_u8_sharded *h) { delete h; }
+
+// ===================================================================================== binary
+qamd_status qamd_bin_sharded_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                                    qamd_bits_store store, qamd_stop_fn stop, void *stop_user, const int *devices,
+                                    uint32_t n_shards, qamd_bin_sharded **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
+    std::unique_ptr<qamd_bin_sharded> h(new qamd_bin_sharded);
+    h->ops = &kBinOps;
+    h->vp = *vp;
+    h->store = store;
+    QAMD_TRY(h->init(devices, n_shards, vp->count));
+    QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+        qamd_vector_parameters svp = *vp;
+        svp.count = h->base[g + 1] - h->base[g];
+        QAMD_TRY(qamd_set_device(w.device));
+        qamd_bin_encoder *e = nullptr;
+        QAMD_TRY(qamd_bin_encoder_begin(&svp, store, stop, stop_user, w.stream, &e));
+        qamd_status st = qamd_bin_encoder_push(e, data + h->base[g] * vp->dim, svp.count, data_mem);
+        if (st != QAMD_OK) {
+            qamd_bin_encoder_abort(e);
+            return st;
+        }
+        return qamd_bin_encoder_finish(e, &h->shards[g]);
+    }));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_vector_parameters *vp,
+                                       qamd_bits_store store, const int *devices, uint32_t n_shards,
+                                       qamd_bin_sharded **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_bin_sharded> h(new qamd_bin_sharded);
+    h->ops = &kBinOps;
+    h->vp = *vp;
+    h->store = store;
+    QAMD_TRY(h->init(devices, n_shards, vp->count));
+    const uint64_t stride = qamd_bin_quantized_vector_size(vp, store);
+    QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+        qamd_vector_parameters svp = *vp;
+        svp.count = h->base[g + 1] - h->base[g];
+        DevBuf stage;
+        const void *src = nullptr;
+        QAMD_TRY(shard_source(rows ? rows + h->base[g] * stride : nullptr, rows_mem, svp.count * stride, w.device, stage,
+                              w.stream, &src));
+        QAMD_TRY(qamd_set_device(w.device));
+        return qamd_bin_from_rows(static_cast<const uint8_t *>(src), rows_mem, &svp, store, w.stream, &h->shards[g]);
+    }));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+uint32_t qamd_bin_sharded_shard_count(const qamd_bin_sharded *h) { return h ? h->G() : 0; }
+
+qamd_status qamd_bin_sharded_shard(const qamd_bin_sharded *h, uint32_t g, const qamd_bin **shard, uint64_t *row_begin,
+                                   int *device) {
+    if (!h || g >= h->G()) return fail(QAMD_ERR_ARGUMENTS, "no such shard");
+    if (shard) *shard = h->shards[g];
+    if (row_begin) *row_begin = h->base[g];
+    if (device) *device = h->devices[g];
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem,
+                                          qamd_bin_sharded_query **query_io) {
+    if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    ShardedQuery<qamd_bin, qamd_bin_query> *q = *query_io;
+    const bool fresh = q == nullptr;
+    if (fresh) {
+        auto *nq = new qamd_bin_sharded_query;
+        nq->ops = &kBinOps;
+        nq->per_shard.assign(h->G(), nullptr);
+        q = nq;
+    }
+    qamd_status st = h->encode_query(query, qdim, query_mem, &q);
+    if (st != QAMD_OK) {
+        if (fresh) delete static_cast<qamd_bin_sharded_query *>(q);
+        return st;
+    }
+    *query_io = static_cast<qamd_bin_sharded_query *>(q);
+    return QAMD_OK;
+}
+
+void qamd_bin_sharded_query_free(qamd_bin_sharded_query *q) { delete q; }
+
+qamd_status qamd_bin_sharded_score_all(qamd_bin_sharded *h, const qamd_bin_sharded_query *q, float *out,
+                                       qamd_mem out_mem) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return h->score_all(q, out, out_mem);
+}
+
+qamd_status qamd_bin_sharded_topk(qamd_bin_sharded *h, const qamd_bin_sharded_query *q, uint32_t k, int largest,
+                                  uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+}
+
+void qamd_bin_sharded_free(qamd_bin_sharded *h) { delete h; }
+
+// ===================================================================================== PQ
+qamd_status qamd_pq_sharded_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                                   uint64_t chunk_size, const float *centroids, uint32_t max_kmeans_threads,
+                                   qamd_stop_fn stop, void *stop_user, const int *devices, uint32_t n_shards,
+                                   qamd_pq_sharded **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
+    if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
+    std::unique_ptr<qamd_pq_sharded> h(new qamd_pq_sharded);
+    h->ops = &kPqOps;
+    h->vp = *vp;
+    h->chunk_size = chunk_size;
+    QAMD_TRY(h->init(devices, n_shards, vp->count));
+    if (centroids) {
+        h->centroids.assign(centroids, centroids + (size_t)QAMD_PQ_CENTROIDS * vp->dim);
+    } else {  // find_centroids (:278-342) once, on the device that holds the data (or devices[0])
+        const int tdev = data_mem == QAMD_MEM_DEVICE ? device_of(data) : h->root();
+        QAMD_ON_DEVICE(tdev < 0 ? h->root() : tdev);
+        QAMD_TRY(pq_train_centroids(data, data_mem, vp, chunk_size, max_kmeans_threads, stop, stop_user, nullptr,
+                                    h->centroids, nullptr, nullptr));
+    }
+    QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+        qamd_vector_parameters svp = *vp;
+        svp.count = h->base[g + 1] - h->base[g];
+        QAMD_TRY(qamd_set_device(w.device));
+        qamd_pq_encoder *e = nullptr;
+        QAMD_TRY(qamd_pq_encoder_begin(&svp, chunk_size, h->centroids.data(), max_kmeans_threads, stop, stop_user, w.stream,
+                                       &e));
+        qamd_status st = qamd_pq_encoder_push(e, data + h->base[g] * vp->dim, svp.count, data_mem);
+        if (st != QAMD_OK) {
+            qamd_pq_encoder_abort(e);
+            return st;
+        }
+        return qamd_pq_encoder_finish(e, &h->shards[g]);
+    }));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_vector_parameters *vp,
+                                      uint64_t chunk_size, const float *centroids, const int *devices, uint32_t n_shards,
+                                      qamd_pq_sharded **out) {
+    if (!vp || !out || !centroids) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
+    std::unique_ptr<qamd_pq_sharded> h(new qamd_pq_sharded);
+    h->ops = &kPqOps;
+    h->vp = *vp;
+    h->chunk_size = chunk_size;
+    h->centroids.assign(centroids, centroids + (size_t)QAMD_PQ_CENTROIDS * vp->dim);
+    QAMD_TRY(h->init(devices, n_shards, vp->count));
+    const uint64_t stride = qamd_pq_quantized_vector_size(vp, chunk_size);
+    QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+        qamd_vector_parameters svp = *vp;
+        svp.count = h->base[g + 1] - h->base[g];
+        DevBuf stage;
+        const void *src = nullptr;
+        QAMD_TRY(shard_source(rows ? rows + h->base[g] * stride : nullptr, rows_mem, svp.count * stride, w.device, stage,
+                              w.stream, &src));
+        QAMD_TRY(qamd_set_device(w.device));
+        return qamd_pq_from_rows(static_cast<const uint8_t *>(src), rows_mem, &svp, chunk_size, h->centroids.data(),
+                                 w.stream, &h->shards[g]);
+    }));
+    *out = h.release();
+    return QAMD_OK;
+}
+
+uint32_t qamd_pq_sharded_shard_count(const qamd_pq_sharded *h) { return h ? h->G() : 0; }
+
+qamd_status qamd_pq_sharded_shard(const qamd_pq_sharded *h, uint32_t g, const qamd_pq **shard, uint64_t *row_begin,
+                                  int *device) {
+    if (!h || g >= h->G()) return fail(QAMD_ERR_ARGUMENTS, "no such shard");
+    if (shard) *shard = h->shards[g];
+    if (row_begin) *row_begin = h->base[g];
+    if (device) *device = h->devices[g];
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_sharded_get_centroids(const qamd_pq_sharded *h, float *centroids) {
+    if (!h || !centroids) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    memcpy(centroids, h->centroids.data(), h->centroids.size() * sizeof(float));
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_sharded_encode_query(qamd_pq_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem,
+                                         qamd_pq_sharded_query **query_io) {
+    if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    ShardedQuery<qamd_pq, qamd_pq_query> *q = *query_io;
+    const bool fresh = q == nullptr;
+    if (fresh) {
+        auto *nq = new qamd_pq_sharded_query;
+        nq->ops = &kPqOps;
+        nq->per_shard.assign(h->G(), nullptr);
+        q = nq;
+    }
+    qamd_status st = h->encode_query(query, qdim, query_mem, &q);
+    if (st != QAMD_OK) {
+        if (fresh) delete static_cast<qamd_pq_sharded_query *>(q);
+        return st;
+    }
+    *query_io = static_cast<qamd_pq_sharded_query *>(q);
+    return QAMD_OK;
+}
+
+void qamd_pq_sharded_query_free(qamd_pq_sharded_query *q) { delete q; }
+
+qamd_status qamd_pq_sharded_score_all(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, float *out, qamd_mem out_mem) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return h->score_all(q, out, out_mem);
+}
+
+qamd_status qamd_pq_sharded_topk(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, uint32_t k, int largest,
+                                 uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+}
+
+void qamd_pq_sharded_free(qamd_pq_sharded *h) { delete h; }
+
+}  // extern "C"

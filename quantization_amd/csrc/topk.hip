@@ -359,20 +359,11 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
                  off_ids = off_sample + (size_t)S * 4, off_out = off_ids + (size_t)S * 4,
                  ws_bytes = off_out + (size_t)k * 8 + 256;
     if (use_fused) {
-        // Workspace (~1 MB) cached per calling thread and device: this path always synchronises
-        // before it returns, so the next call may reuse it; hipMallocAsync + hipFreeAsync per call
-        // cost ~70 us of a 1.2 ms top-k on this runtime.  (Never freed: see host_scratch.)
-        static thread_local struct { char *p; size_t bytes; int dev; uint64_t ids_n; uint32_t ids_S; size_t ids_off; } cache = {nullptr, 0, -1, 0, 0, 0};
-        int dev = 0;
-        QAMD_HIP(hipGetDevice(&dev));
-        if (cache.dev != dev || cache.bytes < ws_bytes) {
-            if (cache.p && cache.dev == dev) (void)hipFree(cache.p);
-            cache = {nullptr, 0, -1, 0, 0, 0};
-            void *fresh = nullptr;
-            QAMD_HIP(hipMalloc(&fresh, ws_bytes));
-            cache = {static_cast<char *>(fresh), ws_bytes, dev, 0, 0, 0};
-        }
-        ws = cache.p;
+        // Workspace (~1 MB) kept per calling thread and device (WS_FUSED): this path always
+        // synchronises before it returns, so the next call may reuse it; hipMallocAsync +
+        // hipFreeAsync per call cost ~70 us of a 1.2 ms top-k on this runtime.
+        uint64_t *tags = nullptr;  // [0] n, [1] S, [2] off_ids + 1 of the sample ids cached in the buffer
+        QAMD_TRY(thread_ws_acquire(WS_FUSED, ws_bytes, stream, reinterpret_cast<void **>(&ws), &tags));
         FusedState *st = reinterpret_cast<FusedState *>(ws + off_state);
         unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + off_cand);
         float *sample = reinterpret_cast<float *>(ws + off_sample);
@@ -387,11 +378,11 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
                         : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
                                                 : reinterpret_cast<float *>(ws + off_out) + k;
         // the sample ids depend on (n, S) only: the cached workspace keeps them from call to call
-        if (cache.ids_n != n || cache.ids_S != S || cache.ids_off != off_ids) {
+        if (tags[0] != n || tags[1] != S || tags[2] != off_ids + 1) {
             hipLaunchKernelGGL(sample_ids_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, ids, S, n);
-            cache.ids_n = n;
-            cache.ids_S = S;
-            cache.ids_off = off_ids;
+            tags[0] = n;
+            tags[1] = S;
+            tags[2] = off_ids + 1;
         }
         qamd_status stt = scan.score_ids(ids, S, sample, stream);
         if (stt == QAMD_OK) {
@@ -417,7 +408,8 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
                 }
             }
         }
-        if (getenv("QAMD_DEBUG_TOPK")) {
+        static const bool debug_topk = getenv("QAMD_DEBUG_TOPK") != nullptr;
+        if (debug_topk) {
             struct { uint32_t pivot_key, status, total; } dbg{};
             (void)hipMemcpy(&dbg, st, sizeof dbg, hipMemcpyDeviceToHost);
             fprintf(stderr, "[qamd topk] n=%llu k=%u r=%u pivot_key=%08x candidates=%u status=%u\n",
@@ -481,6 +473,6 @@ extern "C" qamd_status qamd_topk_scores(const float *scores_dev, uint64_t n, uin
                                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
     if (k == 0) return QAMD_OK;
     if (!scores_dev || !out_ids || !out_scores) return qamd::fail(QAMD_ERR_ARGUMENTS, "null argument");
-    QAMD_TRY(qamd::ensure_device(qamd::current_device()));
+    QAMD_ON_DEVICE(qamd::current_device());
     return qamd::topk_finish(scores_dev, n, k, largest, out_ids, out_scores, out_mem, qamd::as_stream(stream));
 }

@@ -110,7 +110,7 @@ struct Variant {
 extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_u8_sweep(
     const void *codes, const void *offsets, const void *qbuf, float multiplier, uint32_t n_rows, float *out_dev,
     int rounds, char *report, size_t cap) {
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     const uint4 *c = static_cast<const uint4 *>(codes);
     const float *o = static_cast<const float *>(offsets);
     const uint4 *qc = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(qbuf) + 16);
@@ -230,7 +230,7 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_bin_sweep
                                                                                 float dim_f, uint32_t n_rows,
                                                                                 float *out_dev, int rounds,
                                                                                 char *report, size_t cap) {
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     const uint4 *r = static_cast<const uint4 *>(rows);
     const uint4 *q = static_cast<const uint4 *>(qbits);
     std::vector<Variant> vs;

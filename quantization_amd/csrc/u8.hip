@@ -841,6 +841,8 @@ __global__ __launch_bounds__(kBlock) void gather_strided_rows_kernel(const float
     }
 }
 
+bool quantile_cut(uint64_t slice, uint64_t dim, float quantile, uint64_t &cut);
+
 // find_quantile_interval (quantile.rs:21-71).  The reference keeps, after two
 // select_nth_unstable calls, the values of sorted rank (cut, len - cut) exclusive and returns
 // their min and max: sorted[cut + 1] and sorted[len - cut - 1], i.e. the (cut+2)-th smallest
@@ -852,11 +854,8 @@ qamd_status quantile_interval_device(const float *data, qamd_mem data_mem, uint6
     found = false;
     const uint64_t slice = std::min<uint64_t>(count, kQuantileSample);
     const uint64_t len = slice * dim;
-    if (len < 4) return QAMD_OK;  // :48-50
-    uint64_t cut = std::min<uint64_t>((len - 1) / 2, (uint64_t)((float)slice * (1.0f - quantile) / 2.0f));  // :52-55
-    cut = std::max<uint64_t>(cut, 1);
-    const uint64_t lo = cut + 1, hi = len - cut;
-    if (hi <= lo || hi - lo < 2) return QAMD_OK;  // :63-65
+    uint64_t cut = 0;
+    if (!quantile_cut(slice, dim, quantile, cut)) return QAMD_OK;
     DevBuf sample;
     const float *vals = data;
     if (data_mem == QAMD_MEM_HOST) {
@@ -883,6 +882,125 @@ qamd_status quantile_interval_device(const float *data, qamd_mem data_mem, uint6
     return QAMD_OK;
 }
 
+
+// PASS 1 accumulator (quantile.rs:5-19): global min / max over any number of device-resident
+// batches, kept on the device (64 sharded slot pairs) until result() reads it back once.
+struct MinMaxAcc {
+    DevBuf slots, partial;
+    std::vector<float> hp;
+    int mm_grid = 0;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;  // folded from the scalar-form launches
+
+    qamd_status init(hipStream_t s) {
+        QAMD_TRY(slots.alloc(kMinmaxSlots * kMinmaxSlotStride * sizeof(uint32_t)));
+        std::vector<uint32_t> init(kMinmaxSlots * kMinmaxSlotStride, 0u);
+        for (int b = 0; b < kMinmaxSlots; b++) {
+            init[b * kMinmaxSlotStride] = 0xFFFFFFFFu;  // min slot: largest key
+            init[b * kMinmaxSlotStride + 1] = 0u;       // max slot: smallest key
+        }
+        QAMD_TRY(copy_in(slots.ptr, init.data(), QAMD_MEM_HOST, init.size() * 4, s));
+        mm_grid = device_info().cu_count * 4;
+        QAMD_TRY(partial.alloc((size_t)mm_grid * 2 * sizeof(float)));
+        hp.resize((size_t)mm_grid * 2);
+        return QAMD_OK;
+    }
+
+    // src: device memory, nvals f32.  Synchronises only for the scalar-form (unaligned / tail) launches.
+    qamd_status feed(const float *src, uint64_t nvals, hipStream_t s) {
+        if (nvals == 0) return QAMD_OK;
+        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && nvals >= 4) {
+            const uint64_t n4 = nvals / 4;
+            const unsigned grid = (unsigned)((n4 + 1024 * (kScanBlock / 64) - 1) / (1024 * (kScanBlock / 64)));
+            hipLaunchKernelGGL(minmax_stream_kernel, dim3(grid), dim3(kScanBlock), 0, s,
+                               reinterpret_cast<const float4 *>(src), n4, slots.as<uint32_t>());
+            if (nvals % 4) {  // the 1..3 trailing values
+                hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(kBlock), 0, s, src + n4 * 4, nvals % 4,
+                                   partial.as<float>());
+                QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, 8, s));
+                if (hp[0] < mn) mn = hp[0];
+                if (hp[1] > mx) mx = hp[1];
+            }
+        } else {  // unaligned input: grid-stride scalar form
+            hipLaunchKernelGGL(minmax_kernel, dim3(mm_grid), dim3(kBlock), 0, s, src, nvals, partial.as<float>());
+            QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, hp.size() * 4, s));
+            for (int b = 0; b < mm_grid; b++) {
+                if (hp[2 * b] < mn) mn = hp[2 * b];
+                if (hp[2 * b + 1] > mx) mx = hp[2 * b + 1];
+            }
+        }
+        QAMD_HIP(hipGetLastError());
+        return QAMD_OK;
+    }
+
+    qamd_status result(hipStream_t s, float &out_mn, float &out_mx) {
+        std::vector<uint32_t> all_slots(kMinmaxSlots * kMinmaxSlotStride);
+        QAMD_TRY(copy_out(all_slots.data(), QAMD_MEM_HOST, slots.ptr, all_slots.size() * 4, s));
+        auto key_to_f32 = [](uint32_t k) {
+            uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+            float f;
+            memcpy(&f, &u, 4);
+            return f;
+        };
+        for (int b = 0; b < kMinmaxSlots; b++) {
+            const uint32_t kmn = all_slots[b * kMinmaxSlotStride], kmx = all_slots[b * kMinmaxSlotStride + 1];
+            if (kmn != 0xFFFFFFFFu) {
+                const float v = key_to_f32(kmn);
+                if (v < mn) mn = v;
+            }
+            if (kmx != 0u) {
+                const float v = key_to_f32(kmx);
+                if (v > mx) mx = v;
+            }
+        }
+        out_mn = mn;
+        out_mx = mx;
+        return QAMD_OK;
+    }
+};
+
+// PASS 2 for `nr` device-resident rows (encoded_vectors_u8.rs:73-118): rows r0 .. r0+nr of the store.
+qamd_status launch_quantize(qamd_u8 *h, const float *src, uint64_t nr, uint64_t r0, float alpha, float offset,
+                            hipStream_t s) {
+    if (nr == 0) return QAMD_OK;
+    const qamd_vector_parameters &vp = h->meta.vector_parameters;
+    const uint64_t dim = vp.dim;
+    if (dim % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint64_t waves = (nr + 3) / 4;
+        const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
+        const uint32_t per_lane = (uint32_t)((h->meta.actual_dim / 4 + 15) / 16);  // float4 per lane
+#define QAMD_Q16(IT)                                                                                          \
+    hipLaunchKernelGGL(quantize16_kernel<IT>, dim3(grid), dim3(kScanBlock), 0, s, src, nr, (uint32_t)dim,     \
+                       (uint32_t)h->meta.actual_dim, alpha, offset, vp.distance_type, vp.invert,              \
+                       h->codes.as<uint32_t>(), h->offsets.as<float>(), r0)
+        if (per_lane <= 2) QAMD_Q16(2);
+        else if (per_lane <= 4) QAMD_Q16(4);
+        else if (per_lane <= 6) QAMD_Q16(6);
+        else if (per_lane <= 8) QAMD_Q16(8);
+        else if (per_lane <= 12) QAMD_Q16(12);
+        else if (per_lane <= 16) QAMD_Q16(16);
+        else QAMD_Q16(0);
+#undef QAMD_Q16
+    } else {
+        int grid = grid_for(nr, kBlock / 64, 8);
+        hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
+                           (uint32_t)h->meta.actual_dim, alpha, offset, vp.distance_type, vp.invert,
+                           h->codes.as<uint32_t>(), h->offsets.as<float>(), r0);
+    }
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+// quantile.rs:52-61 bounds shared by the one-shot and the streaming encoder: false = the
+// reference keeps the plain min/max interval.
+bool quantile_cut(uint64_t slice, uint64_t dim, float quantile, uint64_t &cut) {
+    const uint64_t len = slice * dim;
+    if (len < 4) return false;  // :48-50
+    cut = std::min<uint64_t>((len - 1) / 2, (uint64_t)((float)slice * (1.0f - quantile) / 2.0f));  // :52-55
+    cut = std::max<uint64_t>(cut, 1);
+    const uint64_t lo = cut + 1, hi = len - cut;
+    return !(hi <= lo || hi - lo < 2);  // :63-65
+}
+
 }  // namespace
 
 // ================================================================================== C ABI
@@ -902,7 +1020,7 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
         return fail(QAMD_ERR_ARGUMENTS, "bad distance_type %d", vp->distance_type);
     if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
     if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     hipStream_t s = as_stream(stream);
     std::unique_ptr<qamd_u8> h(new qamd_u8);
     h->device = current_device();
@@ -959,70 +1077,18 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
         offset = alpha_offset[1];
     } else {
         // PASS 1 (:57): global min/max, accumulated on the device across batches.
-        DevBuf slots;
-        QAMD_TRY(slots.alloc(kMinmaxSlots * kMinmaxSlotStride * sizeof(uint32_t)));
-        std::vector<uint32_t> init(kMinmaxSlots * kMinmaxSlotStride, 0u);
-        for (int b = 0; b < kMinmaxSlots; b++) {
-            init[b * kMinmaxSlotStride] = 0xFFFFFFFFu;  // min slot: largest key
-            init[b * kMinmaxSlotStride + 1] = 0u;       // max slot: smallest key
-        }
-        QAMD_TRY(copy_in(slots.ptr, init.data(), QAMD_MEM_HOST, init.size() * 4, s));
-        const int mm_grid = device_info().cu_count * 4;
-        DevBuf partial;
-        QAMD_TRY(partial.alloc((size_t)mm_grid * 2 * sizeof(float)));
-        std::vector<float> hp((size_t)mm_grid * 2);
-        float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+        MinMaxAcc acc;
+        QAMD_TRY(acc.init(s));
         for (uint64_t r0 = 0; r0 < count; r0 += batch_rows) {
             if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
             const uint64_t nr = std::min(batch_rows, count - r0);
             const float *src = nullptr;
             QAMD_TRY(batch_src(r0, nr, src));
-            const uint64_t nvals = nr * dim;
-            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && nvals >= 4) {
-                const uint64_t n4 = nvals / 4;
-                const unsigned grid = (unsigned)((n4 + 1024 * (kScanBlock / 64) - 1) / (1024 * (kScanBlock / 64)));
-                hipLaunchKernelGGL(minmax_stream_kernel, dim3(grid), dim3(kScanBlock), 0, s,
-                                   reinterpret_cast<const float4 *>(src), n4, slots.as<uint32_t>());
-                if (nvals % 4) {  // the 1..3 trailing values
-                    hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(kBlock), 0, s, src + n4 * 4, nvals % 4,
-                                       partial.as<float>());
-                    QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, 8, s));
-                    if (hp[0] < mn) mn = hp[0];
-                    if (hp[1] > mx) mx = hp[1];
-                }
-            } else {  // unaligned input: grid-stride scalar form
-                hipLaunchKernelGGL(minmax_kernel, dim3(mm_grid), dim3(kBlock), 0, s, src, nvals, partial.as<float>());
-                QAMD_TRY(copy_out(hp.data(), QAMD_MEM_HOST, partial.ptr, hp.size() * 4, s));
-                for (int b = 0; b < mm_grid; b++) {
-                    if (hp[2 * b] < mn) mn = hp[2 * b];
-                    if (hp[2 * b + 1] > mx) mx = hp[2 * b + 1];
-                }
-            }
-            QAMD_HIP(hipGetLastError());
+            QAMD_TRY(acc.feed(src, nr * dim, s));
             if (data_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));  // staging buffer is reused
         }
-        std::vector<uint32_t> all_slots(kMinmaxSlots * kMinmaxSlotStride), keys(128);
-        QAMD_TRY(copy_out(all_slots.data(), QAMD_MEM_HOST, slots.ptr, all_slots.size() * 4, s));
-        for (int b = 0; b < kMinmaxSlots; b++) {
-            keys[2 * b] = all_slots[b * kMinmaxSlotStride];
-            keys[2 * b + 1] = all_slots[b * kMinmaxSlotStride + 1];
-        }
-        auto key_to_f32 = [](uint32_t k) {
-            uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-            float f;
-            memcpy(&f, &u, 4);
-            return f;
-        };
-        for (int b = 0; b < 64; b++) {
-            if (keys[2 * b] != 0xFFFFFFFFu) {
-                const float v = key_to_f32(keys[2 * b]);
-                if (v < mn) mn = v;
-            }
-            if (keys[2 * b + 1] != 0u) {
-                const float v = key_to_f32(keys[2 * b + 1]);
-                if (v > mx) mx = v;
-            }
-        }
+        float mn, mx;
+        QAMD_TRY(acc.result(s, mn, mx));
         alpha = (mx - mn) / 127.0f;  // :228-232
         offset = mn;
         // PASS 1b (:58-71): quantile interval on <= 100 000 sampled vectors.
@@ -1043,29 +1109,7 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
         const uint64_t nr = std::min(batch_rows, count - r0);
         const float *src = nullptr;
         QAMD_TRY(batch_src(r0, nr, src));
-        if (dim % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-            const uint64_t waves = (nr + 3) / 4;
-            const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
-            const uint32_t per_lane = (uint32_t)((h->meta.actual_dim / 4 + 15) / 16);  // float4 per lane
-#define QAMD_Q16(IT)                                                                                          \
-    hipLaunchKernelGGL(quantize16_kernel<IT>, dim3(grid), dim3(kScanBlock), 0, s, src, nr, (uint32_t)dim,     \
-                       (uint32_t)h->meta.actual_dim, alpha, offset, vp->distance_type, vp->invert,            \
-                       h->codes.as<uint32_t>(), h->offsets.as<float>(), r0)
-            if (per_lane <= 2) QAMD_Q16(2);
-            else if (per_lane <= 4) QAMD_Q16(4);
-            else if (per_lane <= 6) QAMD_Q16(6);
-            else if (per_lane <= 8) QAMD_Q16(8);
-            else if (per_lane <= 12) QAMD_Q16(12);
-            else if (per_lane <= 16) QAMD_Q16(16);
-            else QAMD_Q16(0);
-#undef QAMD_Q16
-        } else {
-            int grid = grid_for(nr, kBlock / 64, 8);
-            hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(kBlock), 0, s, src, nr, (uint32_t)dim,
-                               (uint32_t)h->meta.actual_dim, alpha, offset, vp->distance_type, vp->invert,
-                               h->codes.as<uint32_t>(), h->offsets.as<float>(), r0);
-        }
-        QAMD_HIP(hipGetLastError());
+        QAMD_TRY(launch_quantize(h.get(), src, nr, r0, alpha, offset, s));
         if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
     }
     QAMD_HIP(hipStreamSynchronize(s));
@@ -1085,7 +1129,7 @@ qamd_status qamd_u8_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd
                     (unsigned long long)meta->actual_dim, (unsigned long long)vp.dim);
     if (vp.count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
     if (vp.count > 0 && !rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     hipStream_t s = as_stream(stream);
     std::unique_ptr<qamd_u8> h(new qamd_u8);
     h->device = current_device();
@@ -1121,7 +1165,7 @@ qamd_status qamd_u8_export_rows(const qamd_u8 *h, uint8_t *rows, qamd_mem rows_m
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
     if (h->count == 0) return QAMD_OK;
     if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     const uint64_t stride = h->meta.actual_dim + 4;
     const uint32_t row_dwords = (uint32_t)(stride / 4);
@@ -1217,7 +1261,7 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
                                  void *stream, qamd_u8_query **query_io) {
     if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     const uint64_t ad = actual_dim_of(qdim);
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     qamd_u8_query *q = *query_io;
     std::unique_ptr<qamd_u8_query> fresh;
@@ -1243,6 +1287,7 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
     hipLaunchKernelGGL(encode_query_kernel, dim3(1), dim3(64), 0, s, q_dev, (uint32_t)qdim, (uint32_t)ad,
                        h->meta.alpha, h->meta.offset, vp.distance_type, vp.invert, q->buf.as<uint8_t>());
     QAMD_HIP(hipGetLastError());
+    QAMD_TRY(q->ready.record(s));
     if (fresh) *query_io = fresh.release();
     return QAMD_OK;
 }
@@ -1250,8 +1295,9 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
 qamd_status qamd_u8_query_read(const qamd_u8_query *q, float *offset, uint8_t *codes, uint64_t capacity,
                                uint64_t *codes_len) {
     if (!q) return fail(QAMD_ERR_ARGUMENTS, "null query");
-    QAMD_TRY(ensure_device(q->device));
+    QAMD_ON_DEVICE(q->device);
     if (codes_len) *codes_len = q->actual_dim;
+    QAMD_TRY(q->ready.wait(nullptr));
     if (offset) QAMD_TRY(copy_out(offset, QAMD_MEM_HOST, q->buf.ptr, 4, nullptr));
     if (codes) {
         if (capacity < q->actual_dim) return fail(QAMD_ERR_ARGUMENTS, "codes buffer too small");
@@ -1267,8 +1313,9 @@ qamd_status qamd_u8_score_all(const qamd_u8 *h, const qamd_u8_query *q, float *o
     QAMD_TRY(check_query(h, q));
     if (h->count == 0) return QAMD_OK;
     if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     if (out_mem == QAMD_MEM_DEVICE) return scan_into(h, q, out, s);
     float *tmp = nullptr;  // per-thread workspace: no hipMalloc / hipFree per query
     QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * sizeof(float), s, reinterpret_cast<void **>(&tmp)));
@@ -1283,8 +1330,9 @@ qamd_status qamd_u8_score_ids(const qamd_u8 *h, const qamd_u8_query *q, const ui
     QAMD_TRY(check_query(h, q));
     if (n_ids == 0) return QAMD_OK;
     if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     DevBuf ids_tmp, out_tmp;
     const uint32_t *ids_dev = ids;
     // per-pair granularity (score_point and friends): ids and results through the calling
@@ -1333,7 +1381,7 @@ qamd_status qamd_u8_score_internal(const qamd_u8 *h, uint32_t i, uint32_t j, flo
     if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (i >= h->count || j >= h->count)
         return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     // :389-395  diff = actual_dim*offset*offset (negated if invert)
     float diff = (float)h->meta.actual_dim * h->meta.offset * h->meta.offset;
     if (h->meta.vector_parameters.invert) diff = -diff;
@@ -1359,8 +1407,9 @@ qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, i
     QAMD_TRY(check_query(h, q));
     if (k == 0) return QAMD_OK;
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(q->ready.wait(s));
     const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
     FusedScan scan;
     scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_into(h, q, scores, st); };
@@ -1393,7 +1442,243 @@ qamd_status qamd_u8_set_lane_mode(qamd_u8 *h, int mode) {
 
 }  // extern "C"
 
+
+// ============================================================================= streaming encode
+// The reference encodes from a clonable ITERATOR and walks it twice (encoded_vectors_u8.rs:34-40:
+// pass 1 :57-71 find_min_max_from_iter + quantile sample, pass 2 :73-118 quantize + push_vector_data),
+// never holding the f32 data.  This is that contract in bounded batches: observe() = pass 1,
+// push() = pass 2 (rows appended in call order, as EncodedStorageBuilder::push_vector_data,
+// encoded_storage.rs:17-25).  Same kernels and the same sample rows as qamd_u8_encode, so the store
+// is byte-identical to the one-shot call.
+namespace {
+
+// Rows of a batch that belong to the evenly strided quantile sample: sample slot k holds global row
+// floor(k * count / slice).
+__global__ __launch_bounds__(kBlock) void gather_sample_batch_kernel(const float *__restrict__ batch, uint64_t r_base,
+                                                                    uint32_t dim, uint64_t count, uint64_t slice,
+                                                                    uint64_t k0, uint64_t k1, float *__restrict__ sample) {
+    const uint64_t total = (k1 - k0) * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t k = k0 + i / dim, j = i % dim;
+        const uint64_t r = (uint64_t)((unsigned __int128)k * count / slice);
+        sample[k * dim + j] = batch[(r - r_base) * dim + j];
+    }
+}
+
+uint64_t first_sample_at_or_after(uint64_t row, uint64_t count, uint64_t slice) {
+    // smallest k with floor(k * count / slice) >= row  <=>  k * count >= row * slice
+    const unsigned __int128 need = (unsigned __int128)row * slice;
+    return (uint64_t)((need + count - 1) / count);
+}
+
+constexpr uint64_t kStagePieceBytes = 256ull << 20;
+
+}  // namespace
+
+struct qamd_u8_encoder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    qamd_vector_parameters vp{};
+    bool has_quantile = false, has_interval = false;
+    float quantile = 0.0f, alpha = 0.0f, offset = 0.0f;
+    qamd_stop_fn stop = nullptr;
+    void *stop_user = nullptr;
+    std::unique_ptr<qamd_u8> h;
+    MinMaxAcc acc;
+    bool acc_ready = false;
+    uint64_t observed = 0, pushed = 0;
+    uint64_t slice = 0;  // quantile sample rows (0: no sample kept)
+    DevBuf sample, stage;
+};
+
+namespace {
+
+qamd_status encoder_close_pass1(qamd_u8_encoder *e) {
+    if (e->has_interval) return QAMD_OK;
+    const uint64_t count = e->vp.count, dim = e->vp.dim;
+    if (e->observed != count)
+        return fail(QAMD_ERR_ARGUMENTS, "observe pass saw %llu of %llu vectors before the first push",
+                    (unsigned long long)e->observed, (unsigned long long)count);
+    float mn, mx;
+    QAMD_TRY(e->acc.result(e->stream, mn, mx));
+    e->alpha = (mx - mn) / 127.0f;  // :228-232
+    e->offset = mn;
+    if (e->slice) {
+        uint64_t cut = 0;
+        if (quantile_cut(e->slice, dim, e->quantile, cut)) {
+            float qmn = 0.0f, qmx = 0.0f;
+            const uint64_t len = e->slice * dim;
+            QAMD_TRY(select_kth_f32(e->sample.as<float>(), len, cut + 2, false, &qmn, e->stream));
+            QAMD_TRY(select_kth_f32(e->sample.as<float>(), len, cut + 1, true, &qmx, e->stream));
+            e->alpha = (qmx - qmn) / 127.0f;
+            e->offset = qmn;
+        }
+        e->sample.release();
+    }
+    e->has_interval = true;
+    return QAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+qamd_status qamd_u8_encoder_begin(const qamd_vector_parameters *vp, const float *quantile, const float *alpha_offset,
+                                  qamd_stop_fn stop, void *stop_user, void *stream, qamd_u8_encoder **out) {
+    if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (vp->distance_type < 0 || vp->distance_type > 2)
+        return fail(QAMD_ERR_ARGUMENTS, "bad distance_type %d", vp->distance_type);
+    if (vp->count > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "count exceeds u32 row ids");
+    QAMD_ON_DEVICE(current_device());
+    std::unique_ptr<qamd_u8_encoder> e(new qamd_u8_encoder);
+    e->device = current_device();
+    e->stream = as_stream(stream);
+    e->vp = *vp;
+    e->stop = stop;
+    e->stop_user = stop_user;
+    e->h.reset(new qamd_u8);
+    e->h->device = e->device;
+    e->h->count = vp->count;
+    e->h->meta.actual_dim = actual_dim_of(vp->dim);
+    e->h->meta.vector_parameters = *vp;
+    QAMD_TRY(alloc_store(e->h.get()));
+    if (alpha_offset) {
+        e->alpha = alpha_offset[0];
+        e->offset = alpha_offset[1];
+        e->has_interval = true;
+    } else if (vp->count) {
+        QAMD_TRY(e->acc.init(e->stream));
+        e->acc_ready = true;
+        if (quantile && !(vp->count < 127 || *quantile >= 1.0f)) {  // quantile.rs:27-29
+            e->has_quantile = true;
+            e->quantile = *quantile;
+            e->slice = std::min<uint64_t>(vp->count, kQuantileSample);
+            QAMD_TRY(e->sample.alloc(std::max<uint64_t>(e->slice * vp->dim, 4) * sizeof(float)));
+        }
+    }
+    *out = e.release();
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_encoder_observe(qamd_u8_encoder *e, const float *batch, uint64_t n_rows, qamd_mem batch_mem) {
+    if (!e || (!batch && n_rows && e->vp.dim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (e->stop && e->stop(e->stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");
+    if (e->has_interval) {  // alpha_offset given (or pass 1 closed): nothing to learn
+        e->observed += n_rows;
+        return QAMD_OK;
+    }
+    if (e->pushed) return fail(QAMD_ERR_ARGUMENTS, "observe after push");
+    if (e->observed + n_rows > e->vp.count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)(e->observed + n_rows), (unsigned long long)e->vp.count);
+    QAMD_ON_DEVICE(e->device);
+    const uint64_t dim = e->vp.dim, count = e->vp.count;
+    if (dim == 0) {
+        e->observed += n_rows;
+        return QAMD_OK;
+    }
+    const uint64_t piece_rows = std::max<uint64_t>(1, kStagePieceBytes / (dim * 4));
+    for (uint64_t r = 0; r < n_rows; r += piece_rows) {
+        const uint64_t nr = std::min(piece_rows, n_rows - r);
+        const void *src = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(batch + r * dim, batch_mem, nr * dim * 4, e->stage, e->stream, &src, &staged));
+        QAMD_TRY(e->acc.feed(static_cast<const float *>(src), nr * dim, e->stream));
+        if (e->slice) {
+            const uint64_t base = e->observed + r;
+            const uint64_t k0 = first_sample_at_or_after(base, count, e->slice);
+            const uint64_t k1 = std::min<uint64_t>(e->slice, first_sample_at_or_after(base + nr, count, e->slice));
+            if (k1 > k0) {
+                hipLaunchKernelGGL(gather_sample_batch_kernel, dim3(grid_for((k1 - k0) * dim, kBlock * 4, 8)), dim3(kBlock),
+                                   0, e->stream, static_cast<const float *>(src), base, (uint32_t)dim, count, e->slice, k0,
+                                   k1, e->sample.as<float>());
+                QAMD_HIP(hipGetLastError());
+            }
+        }
+        if (staged) QAMD_HIP(hipStreamSynchronize(e->stream));  // the staging buffer is reused
+    }
+    e->observed += n_rows;
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_encoder_push(qamd_u8_encoder *e, const float *batch, uint64_t n_rows, qamd_mem batch_mem) {
+    if (!e || (!batch && n_rows && e->vp.dim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (e->stop && e->stop(e->stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // :74-76
+    if (e->pushed + n_rows > e->vp.count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)(e->pushed + n_rows), (unsigned long long)e->vp.count);
+    QAMD_ON_DEVICE(e->device);
+    QAMD_TRY(encoder_close_pass1(e));
+    const uint64_t dim = e->vp.dim;
+    const uint64_t piece_rows = std::max<uint64_t>(1, kStagePieceBytes / (dim * 4 + 1));
+    for (uint64_t r = 0; r < n_rows; r += piece_rows) {
+        const uint64_t nr = std::min(piece_rows, n_rows - r);
+        const void *src = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(batch + r * dim, batch_mem, nr * dim * 4, e->stage, e->stream, &src, &staged));
+        QAMD_TRY(launch_quantize(e->h.get(), static_cast<const float *>(src), nr, e->pushed + r, e->alpha, e->offset,
+                                 e->stream));
+        if (staged) QAMD_HIP(hipStreamSynchronize(e->stream));
+    }
+    e->pushed += n_rows;
+    return QAMD_OK;
+}
+
+qamd_status qamd_u8_encoder_finish(qamd_u8_encoder *e, qamd_u8 **out) {
+    if (!e || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_u8_encoder> own(e);  // consumed whatever happens
+    if (e->pushed != e->vp.count)
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu",
+                    (unsigned long long)e->pushed, (unsigned long long)e->vp.count);
+    QAMD_ON_DEVICE(e->device);
+    QAMD_HIP(hipStreamSynchronize(e->stream));
+    if (e->vp.count == 0) {  // :43-54
+        e->h->meta.alpha = e->h->meta.offset = e->h->meta.multiplier = 0.0f;
+    } else {
+        e->h->meta.alpha = e->alpha;
+        e->h->meta.offset = e->offset;
+        e->h->meta.multiplier = host_multiplier(e->alpha, e->vp.distance_type, e->vp.invert);
+    }
+    *out = e->h.release();
+    return QAMD_OK;
+}
+
+void qamd_u8_encoder_abort(qamd_u8_encoder *e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipStreamSynchronize(e->stream);  // kernels may still be writing into the store being dropped
+    delete e;
+}
+
+}  // extern "C"
+
 namespace qamd {
+
+// Pass-1 pieces for the sharded encoder (sharded.hip): min/max of a row range read from wherever it
+// lives (host, this device, another device), and the quantile interval of a whole data set.
+qamd_status u8_minmax_range(const float *data, qamd_mem mem, uint64_t n_rows, uint64_t dim, hipStream_t s, float *mn,
+                            float *mx) {
+    MinMaxAcc acc;
+    QAMD_TRY(acc.init(s));
+    DevBuf stage;
+    const uint64_t piece_rows = std::max<uint64_t>(1, kStagePieceBytes / std::max<uint64_t>(dim * 4, 1));
+    for (uint64_t r = 0; r < n_rows && dim; r += piece_rows) {
+        const uint64_t nr = std::min(piece_rows, n_rows - r);
+        const void *src = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(data + r * dim, mem, nr * dim * 4, stage, s, &src, &staged));
+        QAMD_TRY(acc.feed(static_cast<const float *>(src), nr * dim, s));
+        if (staged) QAMD_HIP(hipStreamSynchronize(s));
+    }
+    return acc.result(s, *mn, *mx);
+}
+
+qamd_status u8_quantile_interval(const float *data, qamd_mem mem, uint64_t count, uint64_t dim, float quantile,
+                                 hipStream_t s, bool *found, float *mn, float *mx) {
+    *found = false;
+    if (count < 127 || quantile >= 1.0f) return QAMD_OK;  // quantile.rs:27-29
+    return quantile_interval_device(data, mem, count, dim, quantile, s, *found, *mn, *mx);
+}
 
 qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev, uint64_t n_queries, uint64_t qdim,
                                      uint8_t *codes_dev, uint64_t code_pitch, float *offsets_dev, hipStream_t stream) {
@@ -1436,7 +1721,8 @@ qamd_status u8_score_single(const qamd_u8 *h, const uint8_t *codes_dev, const fl
 
 }  // namespace qamd
 
-// Developer-only accessors for the tuning harness (tune.hip); not part of include/.
+#ifdef QAMD_DEV
+// Developer-only accessors for the tuning harness (tune.hip): libquantization_amd_dev.so only.
 extern "C" __attribute__((visibility("default"))) void qamd_dev_u8_ptrs(const qamd_u8 *h, const void **codes,
                                                                         const void **offsets) {
     *codes = h->codes.ptr;
@@ -1445,3 +1731,4 @@ extern "C" __attribute__((visibility("default"))) void qamd_dev_u8_ptrs(const qa
 extern "C" __attribute__((visibility("default"))) const void *qamd_dev_u8_query_ptr(const qamd_u8_query *q) {
     return q->buf.ptr;
 }
+#endif

@@ -70,7 +70,12 @@ struct BatchFilter {
 
 // Developer timeline (tools/gemm_timeline.py): when set, lane 0 of every wave of the first 4096
 // workgroups stores s_memtime at the phase boundaries, 16 slots per wave.
+#ifdef QAMD_DEV  // libquantization_amd_dev.so only (make dev): the in-kernel timeline hook of tools/gemm_timeline.py
 __device__ unsigned long long *g_gemm_stamps = nullptr;
+#define QAMD_GEMM_STAMPS() g_gemm_stamps
+#else            // product build: no hook, the stamp branches fold away
+#define QAMD_GEMM_STAMPS() (static_cast<unsigned long long *>(nullptr))
+#endif
 #ifdef QAMD_GEMM_ABLATION  // developer builds only (make EXTRA=-DQAMD_GEMM_ABLATION): the shipped library has no such switch
 __device__ unsigned int g_gemm_dbg = 0;  // TIMING EXPERIMENTS ONLY (results are wrong when set): bit0 skip A DMA, bit1 skip B DMA
 #endif
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
     const int wq = wave / WR, wr = wave % WR;
     const int r = lane & 31, h = lane >> 5;
 
-    unsigned long long *stamps = g_gemm_stamps;
+    unsigned long long *stamps = QAMD_GEMM_STAMPS();
     if (stamps) stamps = (blockIdx.x < kStampBlocks && lane == 0) ? stamps + ((uint64_t)blockIdx.x * (T / 64) + wave) * 16 : nullptr;
     auto stamp = [&](int slot) {
         if (stamps) stamps[slot] = __builtin_amdgcn_s_memtime();
@@ -391,13 +396,13 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     const uint32_t nkt = __builtin_amdgcn_readfirstlane((ad + PP_KT - 1) / PP_KT);
     const uint32_t total = my_tiles * nkt;  // K-tiles in this workgroup's stream
 
-    unsigned long long *stamps = g_gemm_stamps;
+    unsigned long long *stamps = QAMD_GEMM_STAMPS();
     if (stamps) stamps = (blockIdx.x < kStampBlocks && lane == 0) ? stamps + ((uint64_t)blockIdx.x * 8 + wave) * 16 : nullptr;
     auto stamp = [&](int slot) {
         if (stamps) stamps[slot] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    const bool dbg = g_gemm_stamps != nullptr;  // wave-uniform
+    const bool dbg = QAMD_GEMM_STAMPS() != nullptr;  // wave-uniform
     unsigned long long dbg_flagged = 0;         // (query group, row) lanes sent to the exact epilogue
 
     // The workgroup's query tile never changes: its per-query constants are staged once.
@@ -836,11 +841,10 @@ qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, cons
     const uint64_t blocks = r_tiles * q_tiles;
     if (blocks > 0x7FFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "batch too large for one launch");
     constexpr size_t lds_bytes = (size_t)2 * (TQ_ + TR_) * (BK_ + 16);
-    static std::once_flag once;  // one flag per instantiation
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    });
+    static std::atomic<uint64_t> set_on{0};  // per instantiation and device: the attribute is a device property
+    if (first_use_on_device(set_on))
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL((u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>), dim3((unsigned)blocks), dim3(64 * WQ * WR), lds_bytes,
                        s, codes, v_offsets, b->codes.as<uint8_t>(), (uint32_t)b->pitch, b->offsets.as<float>(), h->meta.multiplier,
                        (uint32_t)n_rows, (uint32_t)b->n_queries, (uint32_t)h->meta.actual_dim, q_tiles, out, out_pitch,
@@ -861,11 +865,10 @@ template <int MODE, bool LOW, int MI, int MJ>
 qamd_status launch_gemm_pp_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW, MI, MJ>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PpShape<MI, MJ>::LDS));
-    });
+    static std::atomic<uint64_t> set_on{0};
+    if (first_use_on_device(set_on))
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW, MI, MJ>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PpShape<MI, MJ>::LDS)));
     constexpr uint64_t TQW = 64 * MI;  // queries per workgroup tile
     constexpr size_t lds_bytes = PpShape<MI, MJ>::LDS;
     const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
@@ -948,16 +951,18 @@ QAMD_API qamd_status qamd_dev_gemm_debug(unsigned int flags) {
 }
 #endif
 
+#ifdef QAMD_DEV
 // Developer hook: device buffer of kStampBlocks * 8 * 16 u64 (or null to switch the timeline off).
 QAMD_API qamd_status qamd_dev_gemm_stamps(void *dev_buffer) {
     QAMD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &dev_buffer, sizeof(void *)));
     return QAMD_OK;
 }
+#endif
 
 qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, uint64_t n_queries, uint64_t qdim,
                                        qamd_mem queries_mem, void *stream, qamd_u8_query_batch **batch_io) {
     if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     const uint64_t ad = qdim + (16 - qdim % 16) % 16;
     qamd_u8_query_batch *b = *batch_io;
@@ -1002,7 +1007,7 @@ qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, 
     QAMD_TRY(check_batch(h, b));
     if (h->count == 0 || b->n_queries == 0) return QAMD_OK;
     if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     const uint64_t total = b->n_queries * h->count;
     DevBuf tmp;
@@ -1030,7 +1035,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     if (k == 0 || b->n_queries == 0) return QAMD_OK;
     if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
-    QAMD_TRY(ensure_device(h->device));
+    QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     const uint64_t Q = b->n_queries, n = h->count;
     // Pivot rank r of S sampled rows: the number of rows at least as good as the pivot is about

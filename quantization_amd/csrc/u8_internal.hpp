@@ -18,7 +18,16 @@ struct qamd_u8_query {
     int device = 0;
     uint64_t actual_dim = 0;
     qamd::DevBuf buf;  // [0..4) offset f32, [16..16+actual_dim) codes
+    qamd::ReadyEvent ready;  // the last encode_query (stream order for consumers on other streams)
 };
+
+// Pass-1 pieces used by the sharded encoder; defined in u8.hip.
+namespace qamd {
+qamd_status u8_minmax_range(const float *data, qamd_mem mem, uint64_t n_rows, uint64_t dim, hipStream_t s, float *mn,
+                            float *mx);
+qamd_status u8_quantile_interval(const float *data, qamd_mem mem, uint64_t count, uint64_t dim, float quantile,
+                                 hipStream_t s, bool *found, float *mn, float *mx);
+}  // namespace qamd
 
 // encode_query for one query per wave (device-resident f32 queries); defined in u8.hip.
 namespace qamd {

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(512) void stream_read_kernel(const u32x4 *__restric
 
 extern "C" qamd_status qamd_stream_read(const void *dev_ptr, uint64_t bytes, void *scratch, void *stream) {
     if (!dev_ptr || !scratch) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    QAMD_TRY(ensure_device(current_device()));
+    QAMD_ON_DEVICE(current_device());
     const uint64_t n16 = bytes / 16;
     const unsigned grid = (unsigned)((n16 / 1024 + 7) / 8);  // 8 waves per workgroup, one tile per wave
     hipLaunchKernelGGL(stream_read_kernel, dim3(grid ? grid : 1), dim3(512), 0, as_stream(stream),

@@ -70,6 +70,54 @@ def check(status: int) -> None:
         raise err
 
 
+def set_device(device: int) -> None:
+    """Device of the handles this THREAD creates afterwards from host data (default 0).  Handles
+    built from a CUDA tensor live on that tensor's device whatever this says."""
+    check(_lib.lib().qamd_set_device(int(device)))
+
+
+def get_device() -> int:
+    return int(_lib.lib().qamd_get_device())
+
+
+def device_of(x) -> int | None:
+    """Device index of a CUDA tensor, None for host data."""
+    if _is_torch(x) and x.is_cuda:
+        return x.device.index if x.device.index is not None else 0
+    return None
+
+
+class creating_on:
+    """`with creating_on(data): ...` -- handles created inside live on `data`'s device when it is a
+    CUDA tensor (the thread's qamd device is switched and restored), else on the thread's device."""
+
+    def __init__(self, *buffers):
+        self.want = next((d for d in map(device_of, buffers) if d is not None), None)
+        self.prev = None
+
+    def __enter__(self):
+        if self.want is not None:
+            self.prev = get_device()
+            if self.prev != self.want:
+                set_device(self.want)
+        return self.want if self.want is not None else get_device()
+
+    def __exit__(self, *exc):
+        if self.prev is not None and self.prev != self.want:
+            set_device(self.prev)
+        return False
+
+
+def check_same_device(handle_device: int | None, *buffers) -> None:
+    """A device buffer must belong to the handle's device (include/quantization_amd.h conventions)."""
+    if handle_device is None:
+        return
+    for b in buffers:
+        d = device_of(b)
+        if d is not None and d != handle_device:
+            raise ValueError(f"buffer is on cuda:{d} but the encoded store lives on cuda:{handle_device}")
+
+
 def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 

@@ -9,8 +9,8 @@ import numpy as np
 
 from . import _lib
 from ._base import EncodedQueryBase, EncodedVectorsBase
-from .encoded_vectors import (VectorParameters, check, flatten_rows, in_buf, make_stop, out_buf,
-                              stream_ptr, validate)
+from .encoded_vectors import (EncodingError, VectorParameters, check, check_same_device, creating_on,
+                              flatten_rows, get_device, in_buf, make_stop, out_buf, stream_ptr, validate)
 
 
 class BitsStoreType(enum.IntEnum):
@@ -40,8 +40,9 @@ class EncodedVectorsBin(EncodedVectorsBase):
     _prefix = "bin"
     _query_cls = EncodedBinVector
 
-    def __init__(self, handle, vector_parameters: VectorParameters, store: BitsStoreType):
-        super().__init__(handle)
+    def __init__(self, handle, vector_parameters: VectorParameters, store: BitsStoreType, device=None,
+                 owned: bool = True):
+        super().__init__(handle, device, owned)
         self._vp = vector_parameters
         self._store = BitsStoreType(store)
 
@@ -63,9 +64,38 @@ class EncodedVectorsBin(EncodedVectorsBase):
         buf = in_buf(data, np.float32)
         stop = make_stop(stop_condition)
         out = C.c_void_p()
-        check(_lib.lib().qamd_bin_encode(buf.ptr, buf.mem, C.byref(vp), int(store), stop, None,
-                                         stream_ptr(stream), C.byref(out)))
-        return cls(out, vector_parameters, store)
+        with creating_on(data) as dev:
+            check(_lib.lib().qamd_bin_encode(buf.ptr, buf.mem, C.byref(vp), int(store), stop, None,
+                                             stream_ptr(stream), C.byref(out)))
+        return cls(out, vector_parameters, store, dev)
+
+    @classmethod
+    def encode_stream(cls, make_batches, vector_parameters: VectorParameters, stop_condition=None, *,
+                      store: BitsStoreType = BitsStoreType.U8, stream=None) -> "EncodedVectorsBin":
+        """encode from the reference's iterator contract (:165-191 walks it once): `make_batches()`
+        returns an iterator over [n_i, dim] f32 batches; rows are appended in order."""
+        L = _lib.lib()
+        vp = vector_parameters.to_c()
+        stop = make_stop(stop_condition)
+        first = next(iter(make_batches()), None)
+        enc = C.c_void_p()
+        with creating_on(first) as dev:
+            check(L.qamd_bin_encoder_begin(C.byref(vp), int(store), stop, None, stream_ptr(stream), C.byref(enc)))
+        try:
+            for batch in make_batches():
+                if len(batch.shape) != 2 or (batch.shape[0] and batch.shape[1] != vector_parameters.dim):
+                    raise EncodingError(_lib.ERR_ARGUMENTS, f"Vector length {batch.shape[-1]} does not match "
+                                                            f"vector parameters dim {vector_parameters.dim}")
+                check_same_device(dev, batch)
+                buf = in_buf(batch, np.float32)
+                check(L.qamd_bin_encoder_push(enc, buf.ptr, int(batch.shape[0]), buf.mem))
+            out = C.c_void_p()
+            h, enc = enc, None
+            check(L.qamd_bin_encoder_finish(h, C.byref(out)))
+        finally:
+            if enc is not None:
+                L.qamd_bin_encoder_abort(enc)
+        return cls(out, vector_parameters, store, dev)
 
     @classmethod
     def from_storage(cls, rows, vector_parameters: VectorParameters,
@@ -73,9 +103,10 @@ class EncodedVectorsBin(EncodedVectorsBase):
         vp = vector_parameters.to_c()
         buf = in_buf(rows, np.uint8)
         out = C.c_void_p()
-        check(_lib.lib().qamd_bin_from_rows(buf.ptr, buf.mem, C.byref(vp), int(store), stream_ptr(stream),
-                                            C.byref(out)))
-        return cls(out, vector_parameters, store)
+        with creating_on(rows) as dev:
+            check(_lib.lib().qamd_bin_from_rows(buf.ptr, buf.mem, C.byref(vp), int(store), stream_ptr(stream),
+                                                C.byref(out)))
+        return cls(out, vector_parameters, store, dev)
 
     @classmethod
     def load(cls, data_path, meta_path, vector_parameters: VectorParameters,
@@ -90,7 +121,7 @@ class EncodedVectorsBin(EncodedVectorsBase):
         from .encoded_vectors import DistanceType
         eff = VectorParameters(vector_parameters.dim, vector_parameters.count,
                                DistanceType[m["distance_type"]], bool(m["invert"]))
-        return cls(out, eff, store)
+        return cls(out, eff, store, get_device())
 
     def save(self, data_path, meta_path) -> None:
         """EncodedVectors::save (:260-268)."""
@@ -106,6 +137,7 @@ class EncodedVectorsBin(EncodedVectorsBase):
     def storage_bytes(self, out=None, stream=None):
         n = self._vp.count
         nb = self.get_quantized_vector_size_from_params(self._vp, self._store)
+        check_same_device(self._device, out)
         buf, ret = out_buf(out, n * nb, np.uint8)
         check(_lib.lib().qamd_bin_export_rows(self._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret.reshape(n, nb) if isinstance(ret, np.ndarray) else ret

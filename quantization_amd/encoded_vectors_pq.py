@@ -8,8 +8,9 @@ import numpy as np
 
 from . import _lib
 from ._base import EncodedQueryBase, EncodedVectorsBase
-from .encoded_vectors import (DistanceType, VectorParameters, check, flatten_rows, in_buf, make_stop,
-                              out_buf, stream_ptr, validate)
+from .encoded_vectors import (DistanceType, EncodingError, VectorParameters, check, check_same_device,
+                              creating_on, flatten_rows, get_device, in_buf, make_stop, out_buf, stream_ptr,
+                              validate)
 
 KMEANS_SAMPLE_SIZE = 10_000   # :22
 KMEANS_MAX_ITERATIONS = 100   # :23
@@ -36,8 +37,9 @@ class EncodedVectorsPQ(EncodedVectorsBase):
     _prefix = "pq"
     _query_cls = EncodedQueryPQ
 
-    def __init__(self, handle, vector_parameters: VectorParameters, chunk_size: int):
-        super().__init__(handle)
+    def __init__(self, handle, vector_parameters: VectorParameters, chunk_size: int, device=None,
+                 owned: bool = True):
+        super().__init__(handle, device, owned)
         self._vp = vector_parameters
         self._chunk_size = int(chunk_size)
 
@@ -66,8 +68,10 @@ class EncodedVectorsPQ(EncodedVectorsBase):
     @classmethod
     def encode(cls, data, vector_parameters: VectorParameters, chunk_size: int, max_kmeans_threads: int = 1,
                stop_condition=None, *, centroids=None, stream=None) -> "EncodedVectorsPQ":
-        """EncodedVectorsPQ::encode (:56-107).  `centroids` (256 x dim) skips find_centroids —
-        the conditional-parity form, since the reference's k-means is randomised."""
+        """EncodedVectorsPQ::encode (:56-107).  `centroids` (256 x dim) skips find_centroids.
+        Without them k-means runs on the evenly strided <= 10 000-row sample; `max_kmeans_threads`
+        fixes the order of the f64 partial sums exactly as the reference's worker count does
+        (kmeans.rs:77-107)."""
         data = flatten_rows(data, vector_parameters.dim)
         validate(data, vector_parameters)
         vp = vector_parameters.to_c()
@@ -79,10 +83,56 @@ class EncodedVectorsPQ(EncodedVectorsBase):
                 raise ValueError("centroids must be [256, dim]")
         stop = make_stop(stop_condition)
         out = C.c_void_p()
-        check(_lib.lib().qamd_pq_encode(buf.ptr, buf.mem, C.byref(vp), int(chunk_size),
-                                        C.c_void_p(cen.ctypes.data) if cen is not None else None,
-                                        int(max_kmeans_threads), stop, None, stream_ptr(stream), C.byref(out)))
-        return cls(out, vector_parameters, chunk_size)
+        with creating_on(data) as dev:
+            check(_lib.lib().qamd_pq_encode(buf.ptr, buf.mem, C.byref(vp), int(chunk_size),
+                                            C.c_void_p(cen.ctypes.data) if cen is not None else None,
+                                            int(max_kmeans_threads), stop, None, stream_ptr(stream), C.byref(out)))
+        return cls(out, vector_parameters, chunk_size, dev)
+
+    @classmethod
+    def encode_stream(cls, make_batches, vector_parameters: VectorParameters, chunk_size: int,
+                      max_kmeans_threads: int = 1, stop_condition=None, *, centroids=None,
+                      stream=None) -> "EncodedVectorsPQ":
+        """encode from the reference's clonable-iterator contract (:56-107 walks it twice:
+        find_centroids, then encode_storage).  `make_batches()` returns a fresh iterator over
+        [n_i, dim] f32 batches each call.  Byte-identical to `encode` on the concatenated batches."""
+        L = _lib.lib()
+        vp = vector_parameters.to_c()
+        cen = None
+        if centroids is not None:
+            cen = np.ascontiguousarray(centroids, dtype=np.float32)
+            if cen.shape != (CENTROIDS_COUNT, vector_parameters.dim):
+                raise ValueError("centroids must be [256, dim]")
+        stop = make_stop(stop_condition)
+        first = next(iter(make_batches()), None)
+        enc = C.c_void_p()
+        with creating_on(first) as dev:
+            check(L.qamd_pq_encoder_begin(C.byref(vp), int(chunk_size),
+                                          C.c_void_p(cen.ctypes.data) if cen is not None else None,
+                                          int(max_kmeans_threads), stop, None, stream_ptr(stream), C.byref(enc)))
+        try:
+            for fn in ((L.qamd_pq_encoder_observe,) if cen is None else ()) + (L.qamd_pq_encoder_push,):
+                for batch in make_batches():
+                    if len(batch.shape) != 2 or (batch.shape[0] and batch.shape[1] != vector_parameters.dim):
+                        raise EncodingError(_lib.ERR_ARGUMENTS, f"Vector length {batch.shape[-1]} does not match "
+                                                                f"vector parameters dim {vector_parameters.dim}")
+                    check_same_device(dev, batch)
+                    buf = in_buf(batch, np.float32)
+                    check(fn(enc, buf.ptr, int(batch.shape[0]), buf.mem))
+            out = C.c_void_p()
+            h, enc = enc, None
+            check(L.qamd_pq_encoder_finish(h, C.byref(out)))
+        finally:
+            if enc is not None:
+                L.qamd_pq_encoder_abort(enc)
+        return cls(out, vector_parameters, chunk_size, dev)
+
+    def kmeans_info(self) -> tuple[int, int]:
+        """(iterations of the slowest chunk, empty-cluster re-seeds) of the training that built this
+        store; (0, 0) when centroids were given."""
+        it, em = C.c_uint32(), C.c_uint32()
+        check(_lib.lib().qamd_pq_kmeans_info(self._h, C.byref(it), C.byref(em)))
+        return int(it.value), int(em.value)
 
     @classmethod
     def from_storage(cls, rows, vector_parameters: VectorParameters, chunk_size: int, centroids,
@@ -91,9 +141,10 @@ class EncodedVectorsPQ(EncodedVectorsBase):
         buf = in_buf(rows, np.uint8)
         cen = np.ascontiguousarray(centroids, dtype=np.float32)
         out = C.c_void_p()
-        check(_lib.lib().qamd_pq_from_rows(buf.ptr, buf.mem, C.byref(vp), int(chunk_size),
-                                           C.c_void_p(cen.ctypes.data), stream_ptr(stream), C.byref(out)))
-        return cls(out, vector_parameters, chunk_size)
+        with creating_on(rows) as dev:
+            check(_lib.lib().qamd_pq_from_rows(buf.ptr, buf.mem, C.byref(vp), int(chunk_size),
+                                               C.c_void_p(cen.ctypes.data), stream_ptr(stream), C.byref(out)))
+        return cls(out, vector_parameters, chunk_size, dev)
 
     @classmethod
     def load(cls, data_path, meta_path, vector_parameters: VectorParameters) -> "EncodedVectorsPQ":
@@ -108,7 +159,7 @@ class EncodedVectorsPQ(EncodedVectorsBase):
         chunk = (div[0]["end"] - div[0]["start"]) if div else 1
         eff = VectorParameters(int(m["dim"]), vector_parameters.count, DistanceType[m["distance_type"]],
                                bool(m["invert"]))
-        return cls(out, eff, chunk)
+        return cls(out, eff, chunk, get_device())
 
     def save(self, data_path, meta_path) -> None:
         """EncodedVectors::save (:498-506)."""
@@ -123,6 +174,7 @@ class EncodedVectorsPQ(EncodedVectorsBase):
     def storage_bytes(self, out=None, stream=None):
         n = self._vp.count
         m = self.get_quantized_vector_size(self._vp, self._chunk_size)
+        check_same_device(self._device, out)
         buf, ret = out_buf(out, n * m, np.uint8)
         check(_lib.lib().qamd_pq_export_rows(self._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret.reshape(n, m) if isinstance(ret, np.ndarray) else ret

@@ -13,8 +13,9 @@ import numpy as np
 
 from . import _lib
 from ._base import EncodedQueryBase, EncodedVectorsBase
-from .encoded_vectors import (DistanceType, VectorParameters, check, flatten_rows, in_buf,
-                              make_stop, out_buf, stream_ptr, validate)
+from .encoded_vectors import (DistanceType, EncodingError, VectorParameters, check, check_same_device,
+                              creating_on, flatten_rows, get_device, in_buf, make_stop, out_buf, stream_ptr,
+                              validate)
 
 ALIGNMENT = 16  # encoded_vectors_u8.rs:12
 
@@ -75,11 +76,48 @@ class EncodedVectorsU8(EncodedVectorsBase):
         ao = (C.c_float * 2)(*alpha_offset) if alpha_offset is not None else None
         stop = make_stop(stop_condition)
         out = C.c_void_p()
-        check(_lib.lib().qamd_u8_encode(buf.ptr, buf.mem, C.byref(vp),
-                                        C.byref(q) if q is not None else None,
-                                        C.cast(ao, C.POINTER(C.c_float)) if ao is not None else None,
-                                        stop, None, stream_ptr(stream), C.byref(out)))
-        return cls(out)
+        with creating_on(data) as dev:
+            check(_lib.lib().qamd_u8_encode(buf.ptr, buf.mem, C.byref(vp),
+                                            C.byref(q) if q is not None else None,
+                                            C.cast(ao, C.POINTER(C.c_float)) if ao is not None else None,
+                                            stop, None, stream_ptr(stream), C.byref(out)))
+        return cls(out, dev)
+
+    @classmethod
+    def encode_stream(cls, make_batches, vector_parameters: VectorParameters, quantile: float | None = None,
+                      stop_condition=None, *, alpha_offset: tuple[float, float] | None = None,
+                      stream=None) -> "EncodedVectorsU8":
+        """The reference's own contract: `encode` takes a CLONABLE ITERATOR and walks it twice
+        (:34-40, pass 1 :57-71, pass 2 :73-118).  `make_batches()` returns a fresh iterator over
+        [n_i, dim] f32 batches (numpy or CUDA tensors) each time it is called; the f32 data is never
+        held as a whole.  Byte-identical to `encode` on the concatenated batches."""
+        L = _lib.lib()
+        vp = vector_parameters.to_c()
+        q = C.c_float(quantile) if quantile is not None else None
+        ao = (C.c_float * 2)(*alpha_offset) if alpha_offset is not None else None
+        stop = make_stop(stop_condition)
+        first = next(iter(make_batches()), None)
+        enc = C.c_void_p()
+        with creating_on(first) as dev:
+            check(L.qamd_u8_encoder_begin(C.byref(vp), C.byref(q) if q is not None else None,
+                                          C.cast(ao, C.POINTER(C.c_float)) if ao is not None else None,
+                                          stop, None, stream_ptr(stream), C.byref(enc)))
+        try:
+            for fn in ((L.qamd_u8_encoder_observe,) if alpha_offset is None else ()) + (L.qamd_u8_encoder_push,):
+                for batch in make_batches():
+                    if len(batch.shape) != 2 or (batch.shape[0] and batch.shape[1] != vector_parameters.dim):
+                        raise EncodingError(_lib.ERR_ARGUMENTS, f"Vector length {batch.shape[-1]} does not match "
+                                                                f"vector parameters dim {vector_parameters.dim}")
+                    check_same_device(dev, batch)
+                    buf = in_buf(batch, np.float32)
+                    check(fn(enc, buf.ptr, int(batch.shape[0]), buf.mem))
+            out = C.c_void_p()
+            h, enc = enc, None
+            check(L.qamd_u8_encoder_finish(h, C.byref(out)))
+        finally:
+            if enc is not None:
+                L.qamd_u8_encoder_abort(enc)
+        return cls(out, dev)
 
     @classmethod
     def from_storage(cls, rows, metadata: dict, stream=None) -> "EncodedVectorsU8":
@@ -94,8 +132,9 @@ class EncodedVectorsU8(EncodedVectorsBase):
                                 float(metadata["offset"]), float(metadata["multiplier"]), vp.to_c())
         buf = in_buf(rows, np.uint8)
         out = C.c_void_p()
-        check(_lib.lib().qamd_u8_from_rows(buf.ptr, buf.mem, C.byref(meta), stream_ptr(stream), C.byref(out)))
-        return cls(out)
+        with creating_on(rows) as dev:
+            check(_lib.lib().qamd_u8_from_rows(buf.ptr, buf.mem, C.byref(meta), stream_ptr(stream), C.byref(out)))
+        return cls(out, dev)
 
     @classmethod
     def load(cls, data_path, meta_path, vector_parameters: VectorParameters) -> "EncodedVectorsU8":
@@ -103,7 +142,7 @@ class EncodedVectorsU8(EncodedVectorsBase):
         vp = vector_parameters.to_c()
         out = C.c_void_p()
         check(_lib.lib().qamd_u8_load(os.fsencode(data_path), os.fsencode(meta_path), C.byref(vp), C.byref(out)))
-        return cls(out)
+        return cls(out, get_device())
 
     def save(self, data_path, meta_path) -> None:
         """EncodedVectors::save (:263-271): raw rows + serde_json metadata."""
@@ -137,6 +176,7 @@ class EncodedVectorsU8(EncodedVectorsBase):
         [count, actual_dim + 4] u8."""
         md = self.metadata
         n, stride = md["vector_parameters"].count, md["actual_dim"] + 4
+        check_same_device(self._device, out)
         buf, ret = out_buf(out, n * stride, np.uint8)
         check(_lib.lib().qamd_u8_export_rows(self._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret.reshape(n, stride) if isinstance(ret, np.ndarray) else ret
@@ -149,6 +189,7 @@ class EncodedVectorsU8(EncodedVectorsBase):
     def encode_query_batch(self, queries, reuse: EncodedQueryBatchU8 | None = None, stream=None) -> EncodedQueryBatchU8:
         """encode_query for a [n_queries, dim] block of queries (ann_benchmark.rs:245-260's outer loop)."""
         nq, qdim = int(queries.shape[0]), int(queries.shape[1])
+        check_same_device(self._device, queries)
         buf = in_buf(queries, np.float32)
         h = reuse._h if reuse is not None else C.c_void_p()
         check(_lib.lib().qamd_u8_encode_query_batch(self._h, buf.ptr, nq, qdim, buf.mem, stream_ptr(stream), C.byref(h)))
@@ -159,7 +200,8 @@ class EncodedVectorsU8(EncodedVectorsBase):
 
     def score_batch(self, batch: EncodedQueryBatchU8, out=None, stream=None):
         """scores[q, i] = score_point(query q, i) — bit-identical to score_all per query."""
-        n = self.vector_parameters.count
+        n = self.count
+        check_same_device(self._device, out)
         buf, ret = out_buf(out, batch.n_queries * n, np.float32)
         check(_lib.lib().qamd_u8_score_batch(self._h, batch._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret.reshape(batch.n_queries, n) if isinstance(ret, np.ndarray) else ret
@@ -168,6 +210,7 @@ class EncodedVectorsU8(EncodedVectorsBase):
                    stream=None):
         """Per-query best-k (ann_benchmark_data.rs:151-167), [n_queries, k] ids and scores."""
         nq = batch.n_queries
+        check_same_device(self._device, out_ids, out_scores)
         ib, ids = out_buf(out_ids, nq * k, np.uint32)
         sb, sc = out_buf(out_scores, nq * k, np.float32)
         if ib.mem != sb.mem:
