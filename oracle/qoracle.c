@@ -20,8 +20,13 @@
  * the reference tests' known-answer / tolerance properties
  * (quantization/tests/test_binary.rs:14-71, test_simple.rs:15-49,
  * test_pq.rs:16-50) which tests/test_oracle_reference_spec.py re-runs on it.
- * k-means centroid VALUES are "parity unpinned" (random sample + thread_rng in
- * the reference, kmeans.rs:111-118, encoded_vectors_pq.rs:300-302).
+ * k-means (qo_kmeans / qo_find_centroids) restates kmeans.rs:7-167 and
+ * encoded_vectors_pq.rs:278-342 GIVEN the sampled row indices; the two random
+ * draws of the reference (the Permutor sample, :300-302, and the thread_rng
+ * re-seed of an empty cluster, kmeans.rs:111-118) are inputs / a stated fixed
+ * rule here, so centroid values are pinned only conditionally on them.
+ * qo_topk_heap restates the caller's 30-entry heap
+ * (demos/src/ann_benchmark_data.rs:20-33,151-167) over Rust std's BinaryHeap.
  */
 #include <math.h>
 #include <stddef.h>
@@ -608,6 +613,226 @@ QO_EXPORT float qo_pq_score_internal(const uint8_t *rows, uint64_t dim, uint64_t
                          centroids + (uint64_t)cj[c] * dim + lo, hi - lo);
     }
     return invert ? -s : s;
+}
+
+/* ------------------------------------------------------------------------ */
+/* k-means: kmeans.rs:7-167.  data: [n][dim] (one chunk's sub-vectors of the sample).
+ *   - centroids start as the first `centroids_count` rows (:25)
+ *   - per iteration: update_indexes (:139-166: argmin of the sequential f32 sum of (a-b).powi(2),
+ *     strict '<', f32::MAX start), then update_centroids (:49-137): `max_threads` workers take
+ *     contiguous row ranges of n / max_threads rows, the last one the remainder (:77-82), each adds
+ *     its rows into f64 accumulators in row order (:84-93), the partials are merged in worker order
+ *     into a zeroed accumulator (:97-108), mean in f64 (:119-121), cast to f32 and the shift
+ *     sum_f32 |old - new| over [centroid][j] in order (:125-135); stop when < accuracy (:136).
+ *   - an EMPTY cluster takes a thread_rng row in the reference (:111-118) — not reproducible.
+ *     Here: row (hash(chunk_index, centroid, iteration) % n) with the hash below (the product uses
+ *     the same rule); *empties counts how often that happened, so a test can require 0.
+ * trace (optional): [max_iterations][n] u32, the assignments of every iteration that ran. */
+static uint32_t qo_reseed_hash(uint32_t chunk, uint32_t centroid, uint32_t iter) {
+    uint32_t h = (chunk * 2654435761u) ^ (centroid * 40503u) ^ (iter * 2246822519u);
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    return h;
+}
+
+static void qo_update_indexes(const float *data, uint64_t n, uint64_t dim, const float *centroids,
+                              uint64_t centroids_count, uint32_t *indexes) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float *v = data + i * dim;
+        float min_d = 3.40282347e+38f;
+        uint32_t min_i = 0;
+        for (uint64_t k = 0; k < centroids_count; k++) {
+            const float *c = centroids + k * dim;
+            float d = 0.0f;
+            for (uint64_t j = 0; j < dim; j++) {
+                float t = v[j] - c[j];
+                d += t * t;
+            }
+            if (d < min_d) {
+                min_d = d;
+                min_i = (uint32_t)k;
+            }
+        }
+        indexes[i] = min_i;
+    }
+}
+
+QO_EXPORT int qo_kmeans(const float *data, uint64_t n, uint64_t dim, uint64_t centroids_count,
+                        uint32_t max_iterations, uint32_t max_threads, float accuracy, uint32_t chunk_index,
+                        float *centroids /* [centroids_count][dim] */, uint32_t *iterations, uint32_t *empties,
+                        uint32_t *trace) {
+    const uint64_t nc = centroids_count * dim;
+    if (n < centroids_count || max_threads == 0) return -1;
+    memcpy(centroids, data, nc * sizeof(float)); /* :25 */
+    uint32_t *indexes = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    double *acc = (double *)malloc(nc * sizeof(double));
+    double *part = (double *)malloc(nc * sizeof(double));
+    uint64_t *cnt = (uint64_t *)malloc(centroids_count * sizeof(uint64_t));
+    uint32_t it = 0, em = 0;
+    for (; it < max_iterations; it++) {
+        qo_update_indexes(data, n, dim, centroids, centroids_count, indexes);
+        if (trace) memcpy(trace + (uint64_t)it * n, indexes, n * sizeof(uint32_t));
+        /* update_centroids */
+        for (uint64_t i = 0; i < nc; i++) acc[i] = 0.0;
+        memset(cnt, 0, centroids_count * sizeof(uint64_t));
+        const uint64_t per = n / max_threads; /* :77 */
+        for (uint32_t w = 0; w < max_threads; w++) {
+            const uint64_t lo = per * w, hi = (w + 1 == max_threads) ? n : per * (w + 1);
+            for (uint64_t i = 0; i < nc; i++) part[i] = 0.0;
+            for (uint64_t r = lo; r < hi; r++) {
+                const uint32_t ci = indexes[r];
+                cnt[ci] += 1;
+                for (uint64_t j = 0; j < dim; j++) part[ci * dim + j] += (double)data[r * dim + j];
+            }
+            for (uint64_t i = 0; i < nc; i++) acc[i] += part[i]; /* :101-107 */
+        }
+        for (uint64_t k = 0; k < centroids_count; k++) {
+            if (cnt[k] == 0) {
+                const uint64_t row = qo_reseed_hash(chunk_index, (uint32_t)k, it) % n;
+                for (uint64_t j = 0; j < dim; j++) acc[k * dim + j] = (double)data[row * dim + j];
+                em++;
+            } else {
+                const double c = (double)cnt[k];
+                for (uint64_t j = 0; j < dim; j++) acc[k * dim + j] /= c;
+            }
+        }
+        float diff = 0.0f;
+        for (uint64_t i = 0; i < nc; i++) {
+            const float c_acc = (float)acc[i];
+            diff += fabsf(centroids[i] - c_acc);
+            centroids[i] = c_acc;
+        }
+        if (diff < accuracy) {
+            it++;
+            break;
+        }
+    }
+    /* the reference runs update_indexes once more (:45); its result is dropped */
+    if (iterations) *iterations = it;
+    if (empties) *empties = em;
+    free(indexes);
+    free(acc);
+    free(part);
+    free(cnt);
+    return 0;
+}
+
+/* encoded_vectors_pq.rs:278-342 find_centroids GIVEN the sampled row indices (the reference draws
+ * them from a random Permutor, :300-302, and sorts them, :307).  count <= 256: the vectors
+ * themselves (:290-297).  Otherwise, chunk by chunk: the sample's sub-vectors (:311-323) ->
+ * kmeans(256 centroids, <= 100 iterations, 1e-5) (:325-333) -> written into centroid rows
+ * [256][dim] at the chunk's columns (:336-338). */
+QO_EXPORT int qo_find_centroids(const float *data, uint64_t count, uint64_t dim, uint64_t chunk_size,
+                                const uint64_t *sample_rows, uint64_t sample_size, uint32_t max_threads,
+                                float *centroids /* [256][dim] */, uint32_t *iterations /* [m] or NULL */,
+                                uint32_t *empties /* total, or NULL */) {
+    if (count <= 256) {
+        qo_pq_centroids_small(data, count, dim, centroids);
+        return 0;
+    }
+    const uint64_t m = qo_pq_chunks(dim, chunk_size);
+    float *subset = (float *)malloc(sample_size * chunk_size * sizeof(float));
+    float *cen = (float *)malloc(256 * chunk_size * sizeof(float));
+    uint32_t em_total = 0;
+    int rc = 0;
+    for (uint64_t c = 0; c < m && rc == 0; c++) {
+        const uint64_t lo = c * chunk_size, hi = lo + chunk_size < dim ? lo + chunk_size : dim, len = hi - lo;
+        for (uint64_t s = 0; s < sample_size; s++)
+            memcpy(subset + s * len, data + sample_rows[s] * dim + lo, len * sizeof(float));
+        uint32_t it = 0, em = 0;
+        rc = qo_kmeans(subset, sample_size, len, 256, 100, max_threads, 1e-5f, (uint32_t)c, cen, &it, &em, NULL);
+        for (uint64_t k = 0; k < 256; k++) memcpy(centroids + k * dim + lo, cen + k * len, len * sizeof(float));
+        if (iterations) iterations[c] = it;
+        em_total += em;
+    }
+    if (empties) *empties = em_total;
+    free(subset);
+    free(cen);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* The caller's selection: demos/src/ann_benchmark_data.rs:151-167 keeps `k` (30) entries in a
+ * BinaryHeap<Score> ordered by score only (Score::cmp, :29-33: partial_cmp().unwrap() -> a NaN
+ * would panic): while the heap is full a new score replaces the top (the largest kept) iff
+ * top.score > score (strict: an equal score never displaces), and into_sorted_vec() returns
+ * them ascending.  So the kept multiset is the k smallest scores; among rows tied at the boundary
+ * the EARLIER rows win, up to the heap's internal order.
+ * BinaryHeap itself is Rust std (alloc::collections::binary_heap; the reference pins no toolchain):
+ * push = sift_up with `hole <= parent -> stop`; PeekMut drop = sift_down_range(0, len) choosing
+ * the greater child (right on ties) and stopping at `hole >= child`; into_sorted_vec = repeated
+ * swap(0, end) + sift_down_range(0, end).  Restated below; the order it leaves among EQUAL
+ * scores is an implementation detail no caller may rely on. */
+typedef struct {
+    uint32_t index;
+    float score;
+} qo_score;
+
+static void qo_heap_sift_up(qo_score *d, size_t start, size_t pos) {
+    qo_score hole = d[pos];
+    while (pos > start) {
+        size_t parent = (pos - 1) / 2;
+        if (hole.score <= d[parent].score) break;
+        d[pos] = d[parent];
+        pos = parent;
+    }
+    d[pos] = hole;
+}
+
+static void qo_heap_sift_down_range(qo_score *d, size_t pos, size_t end) {
+    qo_score hole = d[pos];
+    size_t child = 2 * pos + 1;
+    while (child <= (end >= 2 ? end - 2 : 0) && end >= 2) {
+        child += (d[child].score <= d[child + 1].score) ? 1 : 0;
+        if (hole.score >= d[child].score) {
+            d[pos] = hole;
+            return;
+        }
+        d[pos] = d[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    if (end >= 1 && child == end - 1 && hole.score < d[child].score) {
+        d[pos] = d[child];
+        pos = child;
+    }
+    d[pos] = hole;
+}
+
+/* scores[i] = postprocess(score_point(q, i)); returns the number kept (min(k, n)). */
+QO_EXPORT uint64_t qo_topk_heap(const float *scores, uint64_t n, uint64_t k, uint32_t *out_ids,
+                                float *out_scores) {
+    if (k == 0) return 0;
+    qo_score *heap = (qo_score *)malloc(k * sizeof(qo_score));
+    size_t len = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        qo_score s = {(uint32_t)i, scores[i]};
+        if (len == k) {
+            if (heap[0].score > s.score) { /* :157-160 */
+                heap[0] = s;
+                qo_heap_sift_down_range(heap, 0, len);
+            }
+        } else {
+            heap[len] = s; /* :162 */
+            qo_heap_sift_up(heap, 0, len);
+            len++;
+        }
+    }
+    size_t end = len; /* into_sorted_vec (:165) */
+    while (end > 1) {
+        end--;
+        qo_score t = heap[0];
+        heap[0] = heap[end];
+        heap[end] = t;
+        qo_heap_sift_down_range(heap, 0, end);
+    }
+    for (size_t i = 0; i < len; i++) {
+        out_ids[i] = heap[i].index;
+        out_scores[i] = heap[i].score;
+    }
+    free(heap);
+    return len;
 }
 
 /* ------------------------------------------------------------------------ */

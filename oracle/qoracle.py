@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
             "qo_pq_score_all": (None, [vp, u64, vp, u64, u64, i32, vp]),
             "qo_pq_score_internal": (f32, [vp, u64, u64, vp, i32, i32, u64, u64]),
             "qo_metric_f32": (f32, [i32, vp, vp, u64]),
+            "qo_kmeans": (i32, [vp, u64, u64, u64, u32, u32, f32, u32, vp, vp, vp, vp]),
+            "qo_find_centroids": (i32, [vp, u64, u64, u64, vp, u64, u32, vp, vp, vp]),
+            "qo_topk_heap": (u64, [vp, u64, u64, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -296,6 +299,52 @@ def pq_score_internal(rows, dim: int, chunk_size: int, centroids, distance: int,
     centroids = _f32(centroids)
     return np.float32(lib().qo_pq_score_internal(_p(rows), dim, chunk_size, _p(centroids),
                                                  distance, int(invert), i, j))
+
+
+def kmeans(data, max_threads: int = 1, chunk_index: int = 0, max_iterations: int = 100, accuracy: float = 1e-5,
+           trace: bool = False):
+    """kmeans.rs:7-47 on [n, dim] sub-vectors -> (centroids [256, dim], iterations, empty re-seeds[, trace])."""
+    data = _f32(data)
+    n, dim = data.shape
+    cen = np.zeros((256, dim), dtype=np.float32)
+    it, em = C.c_uint32(), C.c_uint32()
+    tr = np.zeros((max_iterations, n), dtype=np.uint32) if trace else None
+    rc = lib().qo_kmeans(_p(data), n, dim, 256, max_iterations, max_threads, accuracy, chunk_index, _p(cen),
+                         C.byref(it), C.byref(em), _p(tr) if trace else None)
+    assert rc == 0
+    return (cen, it.value, em.value, tr[: it.value]) if trace else (cen, it.value, em.value)
+
+
+def pq_sample_rows(count: int, sample_size: int = 10_000) -> np.ndarray:
+    """The product's deterministic stand-in for the reference's random Permutor sample
+    (encoded_vectors_pq.rs:300-307): evenly strided rows floor(k * count / S), ascending."""
+    S = min(sample_size, count)
+    return (np.arange(S, dtype=np.uint64) * np.uint64(count)) // np.uint64(S)
+
+
+def find_centroids(data, chunk_size: int, sample_rows=None, max_threads: int = 1):
+    """encoded_vectors_pq.rs:278-342 given the sampled rows -> (centroids [256, dim],
+    iterations per chunk, empty re-seeds)."""
+    data = _f32(data)
+    count, dim = data.shape
+    rows = np.ascontiguousarray(pq_sample_rows(count) if sample_rows is None else sample_rows, dtype=np.uint64)
+    cen = np.zeros((256, dim), dtype=np.float32)
+    its = np.zeros(pq_chunks(dim, chunk_size), dtype=np.uint32)
+    em = C.c_uint32()
+    rc = lib().qo_find_centroids(_p(data), count, dim, chunk_size, _p(rows), rows.size, max_threads, _p(cen), _p(its),
+                                 C.byref(em))
+    assert rc == 0
+    return cen, its, em.value
+
+
+def topk_heap(scores, k: int = 30):
+    """The caller's k-entry max-heap (demos/src/ann_benchmark_data.rs:151-167): k SMALLEST scores,
+    ascending -> (ids, scores)."""
+    scores = _f32(scores)
+    ids = np.zeros(k, dtype=np.uint32)
+    sc = np.zeros(k, dtype=np.float32)
+    n = lib().qo_topk_heap(_p(scores), scores.size, k, _p(ids), _p(sc))
+    return ids[:n], sc[:n]
 
 
 def metric_f32(distance: int, a, b) -> np.float32:

@@ -1252,7 +1252,7 @@ qamd_status pq_encoder_close_pass1(qamd_pq_encoder *e) {
     qamd_pq *h = e->h.get();
     const uint64_t dim = h->vp.dim, count = h->count;
     if (e->observed != count)
-        return fail(QAMD_ERR_ARGUMENTS, "observe pass saw %llu of %llu vectors before the first push",
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu (observe pass ended early)",
                     (unsigned long long)e->observed, (unsigned long long)count);
     if (count <= (uint64_t)kCentroids) {  // :290-297: the vectors themselves, zero-filled up to 256
         std::vector<float> cen((size_t)kCentroids * dim, 0.0f);

@@ -1496,8 +1496,12 @@ namespace {
 qamd_status encoder_close_pass1(qamd_u8_encoder *e) {
     if (e->has_interval) return QAMD_OK;
     const uint64_t count = e->vp.count, dim = e->vp.dim;
+    if (count == 0) {  // :43-54: nothing was observed, nothing will be quantized
+        e->has_interval = true;
+        return QAMD_OK;
+    }
     if (e->observed != count)
-        return fail(QAMD_ERR_ARGUMENTS, "observe pass saw %llu of %llu vectors before the first push",
+        return fail(QAMD_ERR_ARGUMENTS, "Vector count %llu does not match vector parameters count %llu (observe pass ended early)",
                     (unsigned long long)e->observed, (unsigned long long)count);
     float mn, mx;
     QAMD_TRY(e->acc.result(e->stream, mn, mx));

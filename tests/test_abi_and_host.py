@@ -20,7 +20,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/quantization_amd.h but not exported"
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
-    assert set(declared) <= exported
+    # the product library exports EXACTLY the declared entry points: no developer hooks, no tuning
+    # harness (those live in libquantization_amd_dev.so, `make dev`)
+    assert exported == set(declared), (sorted(exported - set(declared)), sorted(set(declared) - exported))
+    assert not any(s.startswith("qamd_dev_") for s in exported)
     # nothing of the oracle is linked into or referenced by the product
     assert not any(s.startswith("qo_") for s in exported)
     needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
