@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: scored vectors/s of the u8 scalar-quantized dot scan, 10M x 768 per GPU.
+"""Headline benchmark: scored vectors/s of the u8 scalar-quantized dot scan over a 10M x 768 store.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one query against the whole (sharded) store: encode_query -> score_all over the
-rank's shard -> the exchange of per-shard results.  Inputs are resident in HBM before the timed
-region.  Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline, ...).
+One "step" = one query against the whole store: encode_query -> score_all over the rank's shard ->
+the exchange of per-shard results.  Inputs are resident in HBM before the timed region.  Rank 0
+prints ONE JSON line (metric, value, roofline, cpu_baseline, ...).
 
 Workload (BASELINE.json configs[1]): f32 i.i.d. uniform [0,1) vectors (demos/benches/encode.rs:17-22),
-fixed seed, scalar-u8 encoded on the GPU by the library itself; queries from the same
-distribution.  Weak scaling: every rank holds --rows-per-gpu rows (default 10M).
+fixed seed, scalar-u8 encoded on the GPU by the library itself; queries from the same distribution.
+
+Scaling.  N = 1: the whole store (--rows, default 10M) on one GPU.  N > 1 defaults to STRONG
+scaling — the store is FIXED at --rows and row-sharded, rank g holding rows [g*R/N, (g+1)*R/N)
+(1.25M rows = 965 MB per GPU at N = 8) — because that is what "10M x 768 ... >= 6x shard-parallel
+speedup at 8 GPUs" measures.  `--scaling weak` keeps --rows per GPU instead.
 
 roofline.achieved = (actual_dim + 4) algorithmic bytes per row (772 B at dim 768)
 x rows one launch scores / that kernel's mean duration, measured here with HIP events on the
 stream the scan is launched on (torch's current stream, handed to the C ABI).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -26,7 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E vendor peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+LDS_B32_PEAK_GBPS = 75000.0  # ds_read_b32, every CU streaming at ~2.4 GHz (MI355X_MICROARCH.md, LDS section)
+MFMA_INT8_PEAK_TOPS = 5000.0  # dense int8 (the guide's ~5 POP/s; vendor figures with sparsity are not used)
 
 
 def parse_args():
@@ -34,40 +41,60 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--rows", "--rows-per-gpu", dest="rows", type=int, default=10_000_000,
+                    help="rows of the store: the WHOLE store under strong scaling (N>1 default), rows per GPU "
+                         "under --scaling weak; at N=1 the two are the same thing")
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="auto = strong for N>1 (fixed store, row-sharded: the >=6x-at-8-GPUs target), n/a at N=1")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--distance", choices=["dot", "l2"], default="dot")
     ap.add_argument("--quantizer", choices=["u8", "binary", "pq"], default="u8",
                     help="u8 = the headline metric (BASELINE configs[1]); binary / pq run configs[3] / [2] "
-                         "through the same harness (e.g. --quantizer binary --dim 1024 --rows-per-gpu 6250000)")
+                         "through the same harness (e.g. --quantizer binary --dim 1024 --rows 50000000)")
     ap.add_argument("--pq-chunk", type=int, default=8)
     ap.add_argument("--exchange", choices=["scores", "topk", "none"], default="scores",
                     help="per-query result exchange across ranks (N>1): gather of per-shard scores "
-                         "to rank 0 (overlapped with the next scan), per-shard top-k + all-gather, or none")
+                         "(overlapped with the next scan), per-shard top-k + all-gather + device merge, or none")
     ap.add_argument("--gather-root", default="rotate",
                     help="--exchange scores: 'rotate' (step i gathers to rank i %% N: consecutive gathers use "
                          "disjoint inbound xGMI links) or a rank number (every step to that rank)")
     ap.add_argument("--k", type=int, default=30)
-    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=0,
+                    help="rows of the store the CPU baseline scans (0 = all of them, capped at 10M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--queries", type=int, default=16)
     ap.add_argument("--batch-queries", type=int, default=0,
                     help="opt-in second workload (BASELINE config 4 shape): per step, top-k of this many queries "
                          "at once over the shard on the matrix cores (u8 only), then one all-gather of "
-                         "world*Q*k pairs and a merge; the default 0 runs the headline single-query scan")
+                         "world*Q*k pairs and a device-side merge; the default 0 runs the headline single-query scan")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank code path, e.g. several ranks on one GPU)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only: put every rank on this one device (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even at world size 1 (exercises the RCCL code path on one GPU)")
     return ap.parse_args()
 
 
-def cpu_baseline(qa, enc, data_sample, queries, gpu_scores_sample, dist_id):
+def host_cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
     """Times the reference's caller loop (encode_query once, score_point for every row,
-    demos/src/ann_benchmark.rs:247-252) on the host: the oracle's loop driving the REFERENCE's
-    own compiled impl_score_dot_avx (oracle/_ref) when present ("reference"), else the
-    oracle's restatement ("port").  Also checks the GPU scores of those rows bit-for-bit."""
-    import threading
+    demos/src/ann_benchmark.rs:247-252) on the host over the store's OWN encoded rows: the oracle's
+    loop driving the REFERENCE's compiled impl_score_dot_avx (oracle/_ref) when present
+    ("reference"), else the oracle's restatement ("port").  One core is what the reference does (it
+    is single-threaded); the all-cores figure splits the rows over persistent worker threads.  Also
+    checks every GPU score of those rows bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
 
     import numpy as np
 
@@ -75,18 +102,15 @@ def cpu_baseline(qa, enc, data_sample, queries, gpu_scores_sample, dist_id):
 
     md = enc.metadata
     vp = md["vector_parameters"]
-    S = data_sample.shape[0]
-    # Encode the sample with the store's own (alpha, offset): byte-identical to its first S rows.
-    sub = qa.EncodedVectorsU8.encode(data_sample, qa.VectorParameters(vp.dim, S, vp.distance_type, vp.invert),
-                                     alpha_offset=(float(md["alpha"]), float(md["offset"])))
-    rows = sub.storage_bytes()
+    S = sample_rows
+    rows = enc.storage_bytes()[:S]  # reference-format rows, straight from the store being benchmarked
     meta = qo.Meta(md["actual_dim"], float(md["alpha"]), float(md["offset"]), float(md["multiplier"]),
                    vp.dim, S, dist_id, int(vp.invert))
     kind = "reference" if qo.ref() is not None else "port"
     use_ref = kind == "reference"
     codes, qoff = qo.u8_encode_query(meta, queries[0])
     want = qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_AVX2, use_ref=use_ref)
-    parity = bool(np.array_equal(want.view(np.uint32), gpu_scores_sample.view(np.uint32)))
+    parity = bool(np.array_equal(want.view(np.uint32), gpu_scores[:S].view(np.uint32)))
 
     def one_core():
         t0 = time.perf_counter()
@@ -97,46 +121,64 @@ def cpu_baseline(qa, enc, data_sample, queries, gpu_scores_sample, dist_id):
     one_core()  # warm-up (criterion-like: warm-up + >= 10 samples, median)
     samples = []
     t_budget = time.perf_counter()
-    while len(samples) < 10 or (time.perf_counter() - t_budget < 8.0 and len(samples) < 40):
+    while len(samples) < 10 or (time.perf_counter() - t_budget < 6.0 and len(samples) < 30):
         samples.append(one_core())
     t1 = float(np.median(samples))
 
     cores = os.cpu_count() or 1
     nthreads = max(1, min(cores, 64))
+    bounds = [(S * i) // nthreads for i in range(nthreads + 1)]
+    pool = ThreadPoolExecutor(max_workers=nthreads)  # persistent workers: no thread start inside a pass
 
     def all_cores():
         c, o = qo.u8_encode_query(meta, queries[0])
-        bounds = [(S * i) // nthreads for i in range(nthreads + 1)]
-        ts = [threading.Thread(target=qo.u8_score_all, args=(meta, rows, c, o),
-                               kwargs=dict(order=qo.ORDER_AVX2, use_ref=use_ref, begin=bounds[i], end=bounds[i + 1]))
-              for i in range(nthreads)]
         t0 = time.perf_counter()
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        futs = [pool.submit(qo.u8_score_all, meta, rows, c, o, order=qo.ORDER_AVX2, use_ref=use_ref,
+                            begin=bounds[i], end=bounds[i + 1]) for i in range(nthreads)]
+        for f in futs:
+            f.result()
         return time.perf_counter() - t0
 
     all_cores()
+    all_cores()
     tn = float(np.median([all_cores() for _ in range(10)]))
-    cpu_model = "unknown CPU"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    cpu_model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
+    pool.shutdown()
     return {
         "value": S / t1, "unit": "vectors/s", "cores": 1, "kind": kind,
-        "sample": f"first {S} rows of the same store, 1 query, median of {len(samples)} passes of the "
-                  f"reference loop (encode_query + score_point per row, "
+        "sample": f"the first {S} rows of the benchmarked store itself, 1 query, median of {len(samples)} passes of "
+                  f"the reference loop (encode_query + score_point per row, "
                   f"{'compiled reference impl_score_dot_avx' if use_ref else 'oracle restatement'}); "
-                  f"host: {cpu_model}, {cores} logical cores",
-        "all_cores": {"value": S / tn, "cores": nthreads},
+                  f"host: {host_cpu_model()}, {cores} logical cores",
+        "all_cores": {"value": S / tn, "cores": nthreads,
+                      "note": "same rows split over persistent worker threads, median of 10 passes"},
         "gpu_matches_cpu_bits": parity,
     }
+
+
+def pmc_traffic(quantizer, n, bytes_per_row):
+    """HBM bytes per launch from a committed rocprofv3 --pmc profile of THIS workload and kernel
+    source (profiles/r*_pmc_u8_scan.json names the commit it was taken at and a hash of the kernel
+    source file; a profile of other code is not quoted)."""
+    import glob
+    import hashlib
+
+    if quantizer != "u8":
+        return None, None
+    try:
+        src = open(os.path.join(ROOT, "quantization_amd", "csrc", "u8.hip"), "rb").read()
+        src_hash = hashlib.sha256(src).hexdigest()[:16]
+    except OSError:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_u8_scan.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        if (j.get("rows_per_launch") == n and j.get("algorithmic_read_bytes_per_launch") == n * bytes_per_row
+                and j.get("kernel_source_sha256_16") == src_hash):
+            return j.get("traffic_bytes_per_launch"), (f"{os.path.relpath(path, ROOT)} (rocprofv3 --pmc, FETCH_SIZE x2 "
+                                                       f"per the guide; commit {j.get('commit', '?')})")
+    return None, None
 
 
 def main():
@@ -147,7 +189,7 @@ def main():
 
     import quantization_amd as qa
     from quantization_amd import _lib
-    from quantization_amd.sharded import ScoreGather, ShardedTopK
+    from quantization_amd.sharded import ScoreGather, ShardedTopK, max_shard_rows, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,28 +200,38 @@ def main():
         args.gpus = world
     dev_index = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
     torch.cuda.set_device(dev_index)
+    qa.set_device(dev_index)
     L = _lib.lib()
-    if L.qamd_set_device(dev_index) != 0:
-        raise SystemExit(L.qamd_last_error().decode())
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {} if "RANK" in os.environ else {"rank": 0, "world_size": 1}
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, **kw)
 
-    n, dim = args.rows_per_gpu, args.dim
+    scaling = args.scaling if args.scaling != "auto" else "strong"
+    if world == 1:
+        total_rows, row0, n = args.rows, 0, args.rows
+    elif scaling == "strong":
+        total_rows = args.rows
+        row0, row1 = shard_range(total_rows, rank, world)
+        n = row1 - row0
+    else:
+        total_rows, row0, n = args.rows * world, args.rows * rank, args.rows
+    n_max = n if world == 1 else (max_shard_rows(total_rows, world) if scaling == "strong" else args.rows)
+    dim = args.dim
     dtype = qa.DistanceType.Dot if args.distance == "dot" else qa.DistanceType.L2
-    total_rows = n * world
 
     # ---- synthetic store, generated and encoded on the GPU (never timed) -------------------
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
     qgen = torch.Generator(device=dev)
     qgen.manual_seed(43)
-    sample_rows = min(args.cpu_sample_rows, n)
-    data_sample = None
     if args.quantizer == "u8":
         data = torch.rand((n, dim), generator=gen, device=dev, dtype=torch.float32)
         # one global (alpha, offset): data is U[0,1) on every rank, so use the analytic interval
@@ -188,8 +240,6 @@ def main():
         vp = qa.VectorParameters(dim, n, dtype, False)
         enc = qa.EncodedVectorsU8.encode(data, vp, alpha_offset=alpha_offset)
         queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            data_sample = data[:sample_rows].cpu().numpy()
         del data  # stays in torch's caching allocator on purpose: returning the 30.7 GB block to the
         # driver (empty_cache) measured 3.5 % SLOWER scans afterwards on the same box (1.171 vs 1.131 ms,
         # tools/exp_ctx.py), whichever buffers the scores were then written to.
@@ -216,6 +266,28 @@ def main():
         bytes_per_row = m
         kernel_name = "pq_scan_fast_kernel"
     args.no_cpu_baseline = args.no_cpu_baseline or args.quantizer != "u8"
+    scaling_field = "weak" if (world == 1 or scaling == "weak") else "strong"
+    # (at N = 1 there is nothing to scale; the contract's field keeps its default)
+
+    def timed_region(body, steps):
+        """barrier + synchronize, `steps` calls of body(i), synchronize + barrier; max over ranks."""
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            body(i)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     if args.batch_queries > 0:
         if args.quantizer != "u8":
@@ -225,49 +297,37 @@ def main():
         bq = torch.rand((Q, dim), generator=qgen, device=dev, dtype=torch.float32)
         batch = enc.encode_query_batch(bq)
         xchg = ShardedTopKBatch(dist, torch, Q, k, dev, rank, world, total_rows)
+        if scaling_field == "weak" and world > 1:
+            xchg.bases = [args.rows * r for r in range(world)]
         ids, sc = xchg.buffers()
 
-        def bstep():
+        def bstep(_i):
             enc.topk_batch(batch, k, largest=True, out_ids=ids, out_scores=sc)
             return xchg.exchange(largest=True)
 
-        for _ in range(max(1, args.warmup)):
-            bstep()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            bstep()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                         device=dev if args.backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for i in range(max(1, args.warmup)):
+            bstep(i)
+        elapsed = timed_region(bstep, args.steps)
         if rank == 0:
             ad = enc.metadata["actual_dim"]
             ops = 2.0 * Q * n * ad  # per GPU and step
             per_gpu_tops = ops * args.steps / elapsed / 1e12
             print(json.dumps({
-                "metric": f"(query, vector) pairs scored/sec, {Q} queries x {n}x{dim} u8 dot per GPU, top-{k} each",
+                "metric": f"(query, vector) pairs scored/sec, {Q} queries x {total_rows}x{dim} u8 dot, top-{k} each",
                 "value": float(Q) * total_rows * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x u8 -> i32 (MFMA int8)",
-                "data": "synthetic",
-                "config": {"workload": f"{Q} queries x {n} x {dim} scalar-u8 rows per GPU, per step: topk_batch over the "
-                                       f"shard + all-gather of world*Q*k pairs + per-query merge (host)",
+                "higher_is_better": True, "scaling": scaling_field, "vs_baseline": None,
+                "dtype": "u8 x u8 -> i32 (MFMA int8)", "data": "synthetic",
+                "config": {"workload": f"{Q} queries x {total_rows} x {dim} scalar-u8 rows ({n} on rank 0), per step: "
+                                       f"topk_batch over the shard + all-gather of world*Q*k pairs + per-query merge "
+                                       f"on the GPU",
                            "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows},
-                "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": 5000.0, "unit": "TFLOP/s",
-                             "frac": per_gpu_tops / 5000.0, "traffic": None,
+                "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": MFMA_INT8_PEAK_TOPS, "unit": "TFLOP/s",
+                             "frac": per_gpu_tops / MFMA_INT8_PEAK_TOPS, "traffic": None,
                              "note": "int8 op/s per GPU over the whole step (sample pass, filter GEMM, scatter, "
                                      "sort, exchange); algorithmic ops = 2 * actual_dim per (query, row) pair"},
             }), flush=True)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -275,25 +335,39 @@ def main():
     qobj = enc.encode_query(queries[0])
     gather = topk = None
     if args.exchange == "scores":
-        gather = ScoreGather(dist, torch, n, dev, rank, world,
-                             dst=None if args.gather_root == "rotate" else int(args.gather_root))
+        gather = ScoreGather(dist, torch, n_max, dev, rank, world,
+                             dst=None if args.gather_root == "rotate" else int(args.gather_root),
+                             always_collective=args.force_dist)
     elif args.exchange == "topk":
         topk = ShardedTopK(dist, torch, args.k, dev, rank, world, total_rows)
-    scores_plain = torch.empty(n, dtype=torch.float32, device=dev) if gather is None else None
+        if scaling_field == "weak" and world > 1:
+            topk.bases = [args.rows * r for r in range(world)]
+    scores_plain = torch.empty(max(n_max, 1), dtype=torch.float32, device=dev) if gather is None else None
 
+    # The hot step goes to the C ABI directly with pre-bound arguments: at 8 GPUs a shard scan is
+    # ~0.15 ms, so the tens of microseconds the Python mirror spends per call (buffer checks,
+    # torch stream lookup) would show up in the strong-scaling number.
+    pfx = {"u8": "u8", "binary": "bin", "pq": "pq"}[args.quantizer]
+    f_encode = getattr(L, f"qamd_{pfx}_encode_query")
+    f_score = getattr(L, f"qamd_{pfx}_score_all")
+    h_store, h_query = enc._h, C.c_void_p(qobj._h.value)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    q_ptrs = [C.c_void_p(queries[i].data_ptr()) for i in range(args.queries)]
+    qdim = int(dim)
     ev_pairs = []
 
-    def step(i, timed):
-        q = queries[i % args.queries]
-        enc.encode_query(q, reuse=qobj)
+    def step(i, timed=True):
+        st = f_encode(h_store, q_ptrs[i % args.queries], qdim, _lib.MEM_DEVICE, stream, C.byref(h_query))
         out = gather.slot(i) if gather is not None else scores_plain
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        enc.score_all(qobj, out=out)
+        st |= f_score(h_store, h_query, C.c_void_p(out.data_ptr()), _lib.MEM_DEVICE, stream)
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))
+        if st:
+            raise RuntimeError(L.qamd_last_error().decode())
         if gather is not None:
             gather.submit(i)
         elif topk is not None:
@@ -305,25 +379,16 @@ def main():
         step(i, False)
     if gather is not None:
         gather.drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, True)
-    if gather is not None:
-        gather.drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def timed_step(i):
+        step(args.warmup + i, True)
+
+    def body(i):
+        timed_step(i)
+        if i == args.steps - 1 and gather is not None:
+            gather.drain()
+
+    elapsed = timed_region(body, args.steps)
     kern_all = [a.elapsed_time(b) for a, b in ev_pairs]
     kern_ms = float(np.mean(kern_all)) if kern_all else float("nan")
     if os.environ.get("QAMD_BENCH_TRACE") and rank == 0:  # developer: per-step kernel times
@@ -337,18 +402,22 @@ def main():
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                     "kernel": kernel_name, "kernel_ms": kern_ms,
+                    "kernel_ms_min": float(np.min(kern_all)), "kernel_ms_median": float(np.median(kern_all)),
+                    "kernel_ms_mean": kern_ms,
                     "algorithmic_bytes_per_row": bytes_per_row, "rows_per_launch": n}
-        # measured traffic from the committed PMC profile of this exact workload, if present
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_u8_scan.json")
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                if (args.quantizer == "u8" and j.get("rows_per_launch") == n
-                        and j.get("algorithmic_read_bytes_per_launch") == n * bytes_per_row):
-                    roofline["traffic"] = j.get("traffic_bytes_per_launch")
-                    roofline["traffic_source"] = "profiles/r01_pmc_u8_scan.json (rocprofv3 --pmc, FETCH_SIZE x2 per guide)"
-            except Exception:
-                pass
+        if args.quantizer == "pq":
+            # The PQ scan reads only m bytes per row from HBM; its limiter is the LDS gather (one
+            # ds_read_b32 per chunk and row, bank-conflicting by construction: DESIGN 3.3).
+            lds = 4.0 * bytes_per_row * n / (kern_ms * 1e-3) / 1e9
+            roofline.update({"bound": "lds", "achieved": lds, "peak": LDS_B32_PEAK_GBPS, "frac": lds / LDS_B32_PEAK_GBPS,
+                             "hbm_achieved_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBPS,
+                             "note": "achieved = 4 B x m LUT gathers per row (ds_read_b32) against the conflict-free "
+                                     "LDS rate of all CUs; random 8-bit codes give ~3.5-way bank conflicts, i.e. a "
+                                     "practical ceiling near 0.29 of that peak"})
+        traffic, source = pmc_traffic(args.quantizer, n, bytes_per_row)
+        if traffic is not None:
+            roofline["traffic"] = traffic
+            roofline["traffic_source"] = source
         # on-box streaming-read ceiling with the same load shape (16 B/lane, nt)
         try:
             probe = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
@@ -369,17 +438,19 @@ def main():
             roofline["stream_read_ceiling_GBps"] = None
             roofline["stream_read_error"] = str(e)
 
+        headline = (total_rows == 10_000_000 and dim == 768 and args.distance == "dot" and args.quantizer == "u8")
+        shard_txt = (f"{total_rows} x {dim} store" if world == 1 else
+                     f"{total_rows} x {dim} store row-sharded over {world} GPUs ({n} rows on rank 0, {scaling_field} scaling)")
         result = {
-            "metric": "scored vectors/sec, 10Mx768 u8 dot"
-            if (n == 10_000_000 and dim == 768 and args.distance == "dot" and args.quantizer == "u8")
-            else f"scored vectors/sec, {n}x{dim} {args.quantizer} {args.distance}",
+            "metric": "scored vectors/sec, 10Mx768 u8 dot" if headline
+            else f"scored vectors/sec, {total_rows}x{dim} {args.quantizer} {args.distance}",
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling_field, "vs_baseline": None,
             "dtype": {"u8": "u8", "binary": "u1 (xor+popcount, i32)", "pq": "f32 (LUT adds)"}[args.quantizer],
             "data": "synthetic",
-            "config": {"workload": (f"{n} x {dim} f32 U[0,1) per GPU -> scalar u8 ({args.distance}); "
+            "config": {"workload": (f"{shard_txt}: f32 U[0,1) -> scalar u8 ({args.distance}); "
                                     if args.quantizer == "u8" else
-                                    f"{n} x {dim} {args.quantizer} rows per GPU ({bytes_per_row} B/row, {args.distance}); ") +
+                                    f"{shard_txt}: {args.quantizer} rows ({bytes_per_row} B/row, {args.distance}); ") +
                                    f"per step: encode_query + score_all over the shard"
                                    + (f" + {args.exchange} exchange" if world > 1 and args.exchange != "none" else ""),
                        "quantizer": args.quantizer, "rows_per_gpu": n, "dim": dim, "distance": args.distance,
@@ -394,15 +465,15 @@ def main():
                 enc.encode_query(queries[0], reuse=qobj)
                 full = enc.score_all(qobj, out=torch.empty(n, dtype=torch.float32, device=dev))
                 torch.cuda.synchronize()
-                gpu_sample = full[:sample_rows].cpu().numpy()
-                result["cpu_baseline"] = cpu_baseline(qa, enc, data_sample, queries.cpu().numpy(), gpu_sample,
-                                                      0 if args.distance == "dot" else 2)
+                sample_rows = min(n, args.cpu_sample_rows or n, 10_000_000)
+                result["cpu_baseline"] = cpu_baseline(enc, queries.cpu().numpy(), full.cpu().numpy(),
+                                                      0 if args.distance == "dot" else 2, sample_rows)
             except Exception as e:
                 result["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port",
                                           "sample": f"failed: {e}"}
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

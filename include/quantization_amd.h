@@ -449,6 +449,19 @@ QAMD_API qamd_status qamd_topk_scores(const float *scores_dev, uint64_t n, uint3
                                       uint32_t *out_ids, float *out_scores, qamd_mem out_mem,
                                       void *stream);
 
+/* The exchange step of a row-sharded top-k on its own, for callers that shard across PROCESSES
+ * (one rank per GPU, quantization_amd/sharded.py over torch.distributed / RCCL): after the
+ * all-gather of every rank's [n_queries][k] (local id, score) lists into device memory, one kernel
+ * per query block merges them -- global id = row_bases[shard] + local id, best first, ties to the
+ * lower global id: exactly what a single handle over all rows returns.
+ * ids_dev / scores_dev: shard g's lists start at + g * shard_stride elements; n_shards * k <= 8192.
+ * row_bases: host array.  Synchronises `stream`. */
+QAMD_API qamd_status qamd_topk_merge(const uint32_t *ids_dev, const float *scores_dev,
+                                     uint64_t shard_stride, const uint64_t *row_bases,
+                                     uint32_t n_shards, uint32_t n_queries, uint32_t k, int largest,
+                                     uint32_t *out_ids, float *out_scores, qamd_mem out_mem,
+                                     void *stream);
+
 /* ===================================================================================
  * Measurement helpers (bench.py): HIP events on the caller's stream, and a plain
  * streaming-read kernel that measures the box's achievable HBM read ceiling.

@@ -182,6 +182,7 @@ def lib() -> C.CDLL:
         "qamd_pq_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
         "qamd_pq_sharded_free": (None, [vp]),
         "qamd_topk_scores": (i32, [vp, u64, u32, i32, vp, vp, i32, vp]),
+        "qamd_topk_merge": (i32, [vp, vp, u64, vp, u32, u32, u32, i32, vp, vp, i32, vp]),
         # measurement
         "qamd_stream_read": (i32, [vp, u64, vp, vp]),
     }

@@ -156,8 +156,9 @@ struct Pool {
 // One workgroup per query: the G per-shard lists (k pairs each, local ids) become the global best
 // k.  Keys are (order-preserving score bits << 32 | global id), all distinct, so the result is the
 // single-handle one: best first, ties to the lower global row id.
-__global__ __launch_bounds__(1024) void merge_topk_kernel(const uint32_t *__restrict__ ids /*[G][Q][k]*/,
-                                                         const float *__restrict__ scores /*[G][Q][k]*/,
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const uint32_t *__restrict__ ids /*[G] x [Q][k]*/,
+                                                         const float *__restrict__ scores /*[G] x [Q][k]*/,
+                                                         uint64_t shard_stride /* elements between two shards' lists */,
                                                          const uint64_t *__restrict__ bases /*[G]*/, uint32_t G, uint32_t Q,
                                                          uint32_t k, int largest, uint32_t N /* pow2 >= G*k */,
                                                          uint32_t *__restrict__ out_ids /*[Q][k]*/,
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const uint32_t *__rest
         unsigned long long key = ~0ull;
         if (i < total) {
             const uint32_t g = i / k, j = i - g * k;
-            const size_t at = ((size_t)g * Q + q) * k + j;
+            const size_t at = (size_t)g * shard_stride + (size_t)q * k + j;
             const uint32_t id = ids[at];
             if (id != 0xFFFFFFFFu)  // a shard shorter than k pads its list
                 key = ((unsigned long long)topk_ordered_bits(scores[at], largest != 0) << 32) | (uint32_t)(bases[g] + id);
@@ -372,7 +373,7 @@ template <class H, class Qy> struct Sharded {
                         : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
                                                 : reinterpret_cast<float *>(result.as<uint32_t>() + (size_t)Q * k);
         hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(1024), (size_t)N * 8, root_stream, g_ids, g_sc,
-                           bases_dev.as<uint64_t>(), G(), Q, k, largest, N, ids_dev, sc_dev);
+                           (uint64_t)Q * k, bases_dev.as<uint64_t>(), G(), Q, k, largest, N, ids_dev, sc_dev);
         QAMD_HIP(hipGetLastError());
         if (out_mem == QAMD_MEM_HOST && !hs.host) {
             QAMD_HIP(hipMemcpyAsync(out_ids, ids_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, root_stream));
@@ -443,6 +444,39 @@ qamd_status shard_source(const void *src, qamd_mem mem, size_t bytes, int device
     return QAMD_OK;
 }
 
+// The merge on its own (qamd_topk_merge): what a multi-PROCESS caller runs after its all-gather.
+qamd_status merge_lists(const uint32_t *ids, const float *scores, uint64_t shard_stride, const uint64_t *bases_host,
+                        uint32_t G, uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                        qamd_mem out_mem, hipStream_t s) {
+    if (G == 0 || Q == 0 || k == 0) return QAMD_OK;
+    if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
+    const uint32_t N = pow2_at_least(G * k);
+    if ((size_t)N * 8 > 64 * 1024) return fail(QAMD_ERR_ARGUMENTS, "shards x k = %u exceeds 8192 merge slots", G * k);
+    // bases ride in the calling thread's workspace, results (host output) too
+    const size_t off_res = round_up((size_t)G * 8, 256), bytes = off_res + (out_mem == QAMD_MEM_HOST ? (size_t)Q * k * 8 : 0);
+    char *ws = nullptr;
+    QAMD_TRY(thread_ws_acquire(WS_SELECT, bytes, s, reinterpret_cast<void **>(&ws)));
+    qamd_status st = QAMD_OK;
+    if (hipMemcpyAsync(ws, bases_host, (size_t)G * 8, hipMemcpyHostToDevice, s) != hipSuccess)
+        st = fail(QAMD_ERR_DEVICE, "topk merge: upload of the shard bases failed");
+    uint32_t *ids_dev = out_mem == QAMD_MEM_DEVICE ? out_ids : reinterpret_cast<uint32_t *>(ws + off_res);
+    float *sc_dev = out_mem == QAMD_MEM_DEVICE ? out_scores : reinterpret_cast<float *>(ws + off_res) + (size_t)Q * k;
+    if (st == QAMD_OK) {
+        hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(1024), (size_t)N * 8, s, ids, scores, shard_stride,
+                           reinterpret_cast<const uint64_t *>(ws), G, Q, k, largest, N, ids_dev, sc_dev);
+        if (hipGetLastError() != hipSuccess) st = fail(QAMD_ERR_DEVICE, "topk merge: launch failed");
+    }
+    if (st == QAMD_OK && out_mem == QAMD_MEM_HOST) {
+        st = copy_out(out_ids, QAMD_MEM_HOST, ids_dev, (size_t)Q * k * 4, s);
+        if (st == QAMD_OK) st = copy_out(out_scores, QAMD_MEM_HOST, sc_dev, (size_t)Q * k * 4, s);
+    } else if (st == QAMD_OK) {
+        // the pageable `bases_host` must stay valid until the copy above has run
+        if (hipStreamSynchronize(s) != hipSuccess) st = fail(QAMD_ERR_DEVICE, "topk merge: synchronisation failed");
+    }
+    thread_ws_release(WS_SELECT, s);
+    return st;
+}
+
 const Ops<qamd_u8, qamd_u8_query> kU8Ops = {qamd_u8_encode_query, qamd_u8_query_free, qamd_u8_score_all, qamd_u8_topk,
                                             qamd_u8_free};
 const Ops<qamd_bin, qamd_bin_query> kBinOps = {qamd_bin_encode_query, qamd_bin_query_free, qamd_bin_score_all,
@@ -477,6 +511,16 @@ struct qamd_pq_sharded : Sharded<qamd_pq, qamd_pq_query> {
 struct qamd_pq_sharded_query : ShardedQuery<qamd_pq, qamd_pq_query> {};
 
 extern "C" {
+
+qamd_status qamd_topk_merge(const uint32_t *ids_dev, const float *scores_dev, uint64_t shard_stride,
+                            const uint64_t *row_bases, uint32_t n_shards, uint32_t n_queries, uint32_t k, int largest,
+                            uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
+    if (!ids_dev || !scores_dev || !row_bases || !out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    int dev = device_of(ids_dev);
+    QAMD_ON_DEVICE(dev < 0 ? current_device() : dev);
+    return merge_lists(ids_dev, scores_dev, shard_stride, row_bases, n_shards, n_queries, k, largest, out_ids, out_scores,
+                       out_mem, as_stream(stream));
+}
 
 // ===================================================================================== u8
 qamd_status qamd_u8_sharded_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,

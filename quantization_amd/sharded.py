@@ -11,7 +11,12 @@ query, after the local scan:
   * `topk`: per-shard top-k, then an all-gather of G*k (id, score) pairs and a merge — what a
     caller that wants neighbours should use (the score gather moves 4 B/row over ~150 GB/s
     links while the scan reads 128-772 B/row at ~6 TB/s, so for binary rows it costs more than
-    the scan itself).
+    the scan itself).  On the GPU the merge is one kernel of the C ABI (`qamd_topk_merge`, the
+    same one the single-process sharded handles use): the result stays in HBM, nothing is copied
+    to the host per query.  The numpy merge below serves the CPU (gloo) tests only.
+
+The single-PROCESS form of all this — one handle, one worker thread per GPU, peer copies instead
+of collectives — is `sharded_store.py` over `qamd_*_sharded_*`.
 
 The scoring itself is any object with the EncodedVectors API of this package; this module only
 does the index arithmetic and the collectives, so the CPU tests drive it with a stand-in scorer.
@@ -50,13 +55,17 @@ class ScoreGather:
     round-robin, which is also how their post-processing would be balanced.
     """
 
-    def __init__(self, dist, torch, rows_padded: int, device, rank: int, world: int, dst=0, group=None):
+    def __init__(self, dist, torch, rows_padded: int, device, rank: int, world: int, dst=0, group=None,
+                 always_collective: bool = False):
         self.dist, self.torch = dist, torch
         self.rank, self.world, self.dst, self.group = rank, world, dst, group
         self.rows_padded = rows_padded
+        # always_collective: run the collective even at world size 1 (a one-rank gather is legal;
+        # it lets a single-GPU box exercise the RCCL call path)
+        self.single = world == 1 and not always_collective
         self.local = [torch.empty(rows_padded, dtype=torch.float32, device=device) for _ in range(2)]
         self.gathered = None
-        if world > 1 and (dst is None or rank == dst):
+        if not self.single and (dst is None or rank == dst):
             self.gathered = [torch.empty((world, rows_padded), dtype=torch.float32, device=device)
                              for _ in range(2)]
         self.work = [None, None]
@@ -74,7 +83,7 @@ class ScoreGather:
 
     def submit(self, step: int) -> None:
         s = step % 2
-        if self.world == 1:  # single shard: the local scores ARE the global scores
+        if self.single:  # single shard: the local scores ARE the global scores
             return
         dst = self.root(step)
         if _needs_host_staging(self.dist, self.local[s]):
@@ -92,7 +101,7 @@ class ScoreGather:
         if self.work[s] is not None:
             self.work[s].wait()
             self.work[s] = None
-        if self.world == 1:
+        if self.single:
             return self.local[s].unsqueeze(0)
         return self.gathered[s] if self.rank == self.root(step) else None
 
@@ -132,8 +141,27 @@ def merge_topk(ids_per_rank, scores_per_rank, bases, k: int, largest: bool):
     return out_ids, out_sc
 
 
+def _device_merge(torch, all_pairs, n_queries: int, k: int, bases, largest: bool, out):
+    """[world][2][n_queries][k] gathered i32 bit patterns (ids plane, scores plane) in HBM ->
+    out [2][n_queries][k] on the same device, through the C ABI's merge kernel."""
+    import ctypes as C
+
+    from . import _lib
+    from .encoded_vectors import check, stream_ptr
+
+    world = all_pairs.shape[0]
+    per = n_queries * k
+    arr = (C.c_uint64 * world)(*[int(b) for b in bases])
+    base = all_pairs.data_ptr()
+    check(_lib.lib().qamd_topk_merge(C.c_void_p(base), C.c_void_p(base + 4 * per), 2 * per, arr, world, n_queries, k,
+                                     int(bool(largest)), C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 4 * per),
+                                     _lib.MEM_DEVICE, stream_ptr(None)))
+    return out[0], out[1].view(torch.float32)
+
+
 class ShardedTopK:
-    """Per-shard device top-k + all-gather of world*k pairs + host merge."""
+    """Per-shard device top-k + all-gather of world*k pairs + merge (on the GPU: one kernel, the
+    merged (ids, scores) stay in HBM as tensors; on CPU tensors: numpy)."""
 
     def __init__(self, dist, torch, k: int, device, rank: int, world: int, count: int, group=None):
         self.dist, self.torch, self.k = dist, torch, k
@@ -142,6 +170,7 @@ class ShardedTopK:
         # one packed buffer: k ids (as i32 bit patterns) then k scores (as f32 bit patterns)
         self.pack = torch.empty(2 * k, dtype=torch.int32, device=device)
         self.all = torch.empty((world, 2 * k), dtype=torch.int32, device=device)
+        self.merged = torch.empty((2, 1, k), dtype=torch.int32, device=device)
 
     def buffers(self):
         """(ids, scores) device views the local topk writes into."""
@@ -157,7 +186,11 @@ class ShardedTopK:
             self.all.copy_(ha)
         else:
             self.dist.all_gather_into_tensor(self.all.view(-1), self.pack, group=self.group)
-        host = self.all.cpu().numpy()
+        if self.all.is_cuda:  # merged on the device; callers that want host values copy them out
+            ids, sc = _device_merge(self.torch, self.all.view(self.world, 2, 1, self.k), 1, self.k, self.bases, largest,
+                                    self.merged)
+            return ids[0], sc[0]
+        host = self.all.numpy()
         ids = host[:, : self.k].view(np.uint32)
         sc = host[:, self.k:].view(np.float32)
         return merge_topk(ids, sc, self.bases, self.k, largest)
@@ -176,6 +209,7 @@ class ShardedTopKBatch:
         # [2][n_queries][k] int32 bit patterns: plane 0 ids, plane 1 scores
         self.pack = torch.empty((2, n_queries, k), dtype=torch.int32, device=device)
         self.all = torch.empty((world, 2, n_queries, k), dtype=torch.int32, device=device)
+        self.merged = torch.empty((2, n_queries, k), dtype=torch.int32, device=device)
 
     def buffers(self):
         """(ids [n_queries*k], scores [n_queries*k]) device views for the local topk_batch."""
@@ -191,7 +225,9 @@ class ShardedTopKBatch:
             self.all.copy_(ha)
         else:
             self.dist.all_gather_into_tensor(self.all.view(-1), self.pack.view(-1), group=self.group)
-        host = self.all.cpu().numpy()
+        if self.all.is_cuda:
+            return _device_merge(self.torch, self.all, self.nq, self.k, self.bases, largest, self.merged)
+        host = self.all.numpy()
         ids = host[:, 0].view(np.uint32)   # [world, nq, k]
         sc = host[:, 1].view(np.float32)
         # all queries at once: [nq, world*k] candidates per query, one lexsort along the rows

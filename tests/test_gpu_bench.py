@@ -31,23 +31,43 @@ def test_bench_single_gpu_line(extra):
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in j, key
     assert j["n_gpus"] == 1 and j["steps"] == 5 and j["value"] > 0
-    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1.2
+    rf = j["roofline"]
+    assert rf["bound"] == ("lds" if "pq" in extra else "hbm") and 0 < rf["frac"] < 1.2
+    assert rf["kernel_ms_min"] <= rf["kernel_ms_median"] and rf["kernel_ms_mean"] == rf["kernel_ms"]
+    if "pq" in extra:
+        assert 0 < rf["hbm_frac"] < 1.2
     if not extra:
         cb = j["cpu_baseline"]
         assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("reference", "port")
         assert cb["gpu_matches_cpu_bits"] is True
+        assert cb["all_cores"]["value"] > 0
 
 
-@pytest.mark.parametrize("exchange", ["scores", "topk"])
-def test_bench_two_ranks_one_gpu_gloo_rehearsal(exchange):
+def test_bench_rccl_code_path_on_one_gpu():
+    """torch.distributed over nccl (= RCCL) initialised at world size 1: process group, barrier,
+    all_reduce and a one-rank asynchronous score gather all go through RCCL on the single GPU."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--rows", "300000",
+           "--no-cpu-baseline", "--force-dist", "--backend", "nccl"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["n_gpus"] == 1 and j["value"] > 0
+
+
+@pytest.mark.parametrize("exchange,scaling", [("scores", "strong"), ("topk", "strong"), ("scores", "weak")])
+def test_bench_two_ranks_one_gpu_gloo_rehearsal(exchange, scaling):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "1", "--rows-per-gpu", "200000", "--backend", "gloo", "--all-ranks-on-device", "0",
-           "--exchange", exchange]
+           "--warmup", "1", "--rows", "200001", "--backend", "gloo", "--all-ranks-on-device", "0",
+           "--exchange", exchange] + (["--scaling", "weak"] if scaling == "weak" else [])
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     j = _last_json(res.stdout)
-    assert j["n_gpus"] == 2 and j["config"]["total_rows"] == 400000 and j["scaling"] == "weak"
+    # the default for N > 1 is STRONG scaling: the store stays at --rows and is row-sharded
+    assert j["n_gpus"] == 2 and j["scaling"] == scaling
+    assert j["config"]["total_rows"] == (200001 if scaling == "strong" else 400002)
+    assert j["config"]["rows_per_gpu"] == (100000 if scaling == "strong" else 200001)
     assert "cpu_baseline" not in j
 
 
@@ -67,4 +87,4 @@ def test_bench_batched_topk_mode(ranks):
     j = _last_json(res.stdout)
     assert j["n_gpus"] == ranks and j["unit"] == "pairs/s" and j["value"] > 0
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
-    assert j["config"]["total_rows"] == 1200000 * ranks
+    assert j["config"]["total_rows"] == 1200000  # strong scaling: the store is fixed, the ranks split it

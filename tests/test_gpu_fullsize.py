@@ -159,5 +159,111 @@ def test_c4_shard_u8_1536_topk(qo):
     order = torch.sort(s, descending=True, stable=True)
     assert np.array_equal(ts, order.values[:100].cpu().numpy())
     assert np.array_equal(ti.astype(np.int64), order.indices[:100].cpu().numpy())
+    del order, s
+    # configs[4] proper: 1024 queries at once against the shard, top-30 each (the ping-pong MFMA
+    # kernel at 1536 dims, 256-query tile), then the 64-query shape (128-query tile).
+    _check_batched_topk(qo, enc, data, n, dim, g, dev, n_queries=1024)
+    _check_batched_topk(qo, enc, data, n, dim, g, dev, n_queries=64)
     del enc, data
     _free()
+
+
+def _check_batched_topk(qo, enc, data, n, dim, g, dev, n_queries, k=30):
+    """topk_batch at full size: >= 8 sampled queries against the exact single-query topk (ids and
+    score bits), 2 of them also against oracle scores recomputed for the winning rows."""
+    md = enc.metadata
+    queries = torch.rand((n_queries, dim), generator=g, device=dev)
+    batch = enc.encode_query_batch(queries)
+    ids_d = torch.empty(n_queries * k, dtype=torch.int32, device=dev)
+    sc_d = torch.empty(n_queries * k, dtype=torch.float32, device=dev)
+    enc.topk_batch(batch, k, out_ids=ids_d, out_scores=sc_d)
+    torch.cuda.synchronize()
+    ids = ids_d.cpu().numpy().view(np.uint32).reshape(n_queries, k)
+    sc = sc_d.cpu().numpy().reshape(n_queries, k)
+    picks = sorted({0, n_queries - 1, *np.random.default_rng(n_queries).integers(0, n_queries, 8).tolist()})
+    assert len(picks) >= 8 or n_queries < 8
+    qobj = None
+    for j, qi in enumerate(picks):
+        qobj = enc.encode_query(queries[qi], reuse=qobj)
+        wi, ws = enc.topk(qobj, k)
+        assert np.array_equal(ids[qi], wi), f"query {qi}: ids differ from the single-query top-k"
+        assert_bits_equal(sc[qi], ws, f"query {qi}: scores")
+        if j < 2:  # the winners' scores straight from the oracle
+            win = torch.from_numpy(ids[qi].astype(np.int64)).to(dev)
+            rows, meta = qo.u8_encode_with(data[win].cpu().numpy(), qo.DOT, False, float(md["alpha"]), float(md["offset"]))
+            codes, qoff = qo.u8_encode_query(meta, queries[qi].cpu().numpy())
+            order = qo.ORDER_AVX2 if md["actual_dim"] <= 1040 else qo.ORDER_SIMPLE
+            assert_bits_equal(sc[qi], qo.u8_score_all(meta, rows, codes, qoff, order=order), f"query {qi} vs oracle")
+    assert np.all(np.diff(sc.astype(np.float64), axis=1) <= 0), "every list is sorted best-first"
+
+
+def test_c1_batched_topk_10m_x_768(qo):
+    """The batched path at the headline store: 10M x 768, 1024 queries (256-query tile) and 64
+    queries (128-query tile), top-30 each."""
+    n, dim = 10_000_000, 768
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    data = torch.rand((n, dim), generator=g, device=dev)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    _check_batched_topk(qo, enc, data, n, dim, g, dev, n_queries=1024)
+    _check_batched_topk(qo, enc, data, n, dim, g, dev, n_queries=64)
+    del enc, data
+    _free()
+
+
+def test_c4_shard_pq_1536_m192(qo):
+    """configs[4]'s PQ leg on one shard: 12.5M x 1536, chunk 8 -> m = 192: the LUT (192 KiB) does
+    not fit the LDS, the scan runs in two slices carrying lane sums in the reference's order."""
+    n, dim, chunk = 12_500_000, 1536, 8
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+    cen = np.random.default_rng(17).random((256, dim), dtype=np.float32)
+    rows = torch.randint(0, 256, (n, 192), generator=g, device=dev, dtype=torch.uint8)
+    vp = qa.VectorParameters(dim, n, D.Dot, False)
+    enc = qa.EncodedVectorsPQ.from_storage(rows, vp, chunk, cen)
+    query = np.random.default_rng(18).random(dim, dtype=np.float32)
+    q = enc.encode_query(query)
+    lut = qo.pq_encode_query(query, chunk, cen, qo.DOT, False)
+    assert_bits_equal(q.lut, lut, "LUT")
+    s = enc.score_all(q, out=torch.empty(n, device=dev))
+    ids = torch.randint(0, n, (8192,), generator=g, device=dev)
+    ids[:2] = torch.tensor([0, n - 1], device=dev)
+    torch.cuda.synchronize()
+    want = qo.pq_score_all(rows[ids].cpu().numpy(), lut, order=qo.ORDER_SSE)
+    assert_bits_equal(s[ids].cpu().numpy(), want, "sampled rows vs oracle (SSE order), sliced LUT")
+    ti, ts = enc.topk(q, 30)
+    best = torch.sort(s, descending=True, stable=True)
+    assert np.array_equal(ts, best.values[:30].cpu().numpy())
+    assert np.array_equal(ti.astype(np.int64), best.indices[:30].cpu().numpy())
+    del enc, rows, s, best
+    _free()
+
+
+def test_c0_u8_100k_x_128_full_compare(qo):
+    """configs[0]: 100k x 128 f32 -> scalar u8 + dot, every row against the reference CPU SIMD path
+    (the oracle's loop over the reference's own compiled impl_score_dot_avx when oracle/_ref is
+    present) and every encoded byte against the oracle's encode."""
+    n, dim = 100_000, 128
+    rng = np.random.default_rng(0)
+    data = rng.random((n, dim), dtype=np.float32)
+    for dist, dist_id in ((D.Dot, qo.DOT), (D.L2, qo.L2)):
+        enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, False))
+        rows, meta = qo.u8_encode(data, dist_id, False)
+        assert np.array_equal(enc.storage_bytes(), rows), "encoded rows"
+        md = enc.metadata
+        for key in ("alpha", "offset", "multiplier"):
+            assert np.float32(md[key]).view(np.uint32) == np.float32(getattr(meta, key)).view(np.uint32)
+        for seed in (1, 2):
+            query = np.random.default_rng(seed).random(dim, dtype=np.float32)
+            q = enc.encode_query(query)
+            codes, qoff = qo.u8_encode_query(meta, query)
+            assert np.array_equal(q.encoded_query, codes) and np.float32(q.offset).view(np.uint32) == np.float32(qoff).view(np.uint32)
+            want = qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_AVX2, use_ref=qo.ref() is not None)
+            assert_bits_equal(enc.score_all(q), want, "all 100k scores vs the reference CPU path")
+            hi, _ = qo.topk_heap(-want, 30)  # the caller's heap keeps the SMALLEST of what postprocess() feeds it
+            gi, gs = enc.topk(q, 30, largest=True)
+            assert np.array_equal(np.sort(gs), np.sort(want[hi])), "top-30 score multiset == the caller's heap"
+            strict = want[hi] > gs.min()  # rows strictly better than the boundary score: same ids
+            assert set(hi[strict].tolist()) == set(gi[gs > gs.min()].tolist())
