@@ -58,6 +58,16 @@ def parse_args():
     ap.add_argument("--gather-root", default="rotate",
                     help="--exchange scores: 'rotate' (step i gathers to rank i %% N: consecutive gathers use "
                          "disjoint inbound xGMI links) or a rank number (every step to that rank)")
+    ap.add_argument("--gather-group", type=int, default=0,
+                    help="--exchange scores: queries whose per-shard scores travel in ONE collective (0 = auto: 1 at "
+                         "N=1, 4 at N>1, where a shard scan is ~0.15 ms and a collective's launch latency would "
+                         "otherwise be paid per query)")
+    ap.add_argument("--encode-ahead", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1: encode_query of step i+1 runs on a side stream while the scan of step i runs (two query "
+                         "objects); 0 / -1 (default): strictly in line, which measured faster")
+    ap.add_argument("--time-every", type=int, default=0,
+                    help="HIP-event-time the scan kernel every this many steps (0 = auto: every step at N=1, every "
+                         "8th at N>1: an event pair costs ~10 us of launch gap, 7 %% of a 1.25M-row shard scan)")
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the store the CPU baseline scans (0 = all of them, capped at 10M)")
@@ -85,6 +95,19 @@ def host_cpu_model() -> str:
     except OSError:
         pass
     return "unknown CPU"
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU
+    box hands each job a share of a large host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
@@ -126,7 +149,7 @@ def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
     t1 = float(np.median(samples))
 
     cores = os.cpu_count() or 1
-    nthreads = max(1, min(cores, 64))
+    nthreads = max(1, min(usable_cores(), 64))
     bounds = [(S * i) // nthreads for i in range(nthreads + 1)]
     pool = ThreadPoolExecutor(max_workers=nthreads)  # persistent workers: no thread start inside a pass
 
@@ -148,7 +171,7 @@ def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
         "sample": f"the first {S} rows of the benchmarked store itself, 1 query, median of {len(samples)} passes of "
                   f"the reference loop (encode_query + score_point per row, "
                   f"{'compiled reference impl_score_dot_avx' if use_ref else 'oracle restatement'}); "
-                  f"host: {host_cpu_model()}, {cores} logical cores",
+                  f"host: {host_cpu_model()}, {cores} logical cores, {usable_cores()} usable by this job",
         "all_cores": {"value": S / tn, "cores": nthreads,
                       "note": "same rows split over persistent worker threads, median of 10 passes"},
         "gpu_matches_cpu_bits": parity,
@@ -269,6 +292,8 @@ def main():
     scaling_field = "weak" if (world == 1 or scaling == "weak") else "strong"
     # (at N = 1 there is nothing to scale; the contract's field keeps its default)
 
+    host_enqueue = [0.0]
+
     def timed_region(body, steps):
         """barrier + synchronize, `steps` calls of body(i), synchronize + barrier; max over ranks."""
         torch.cuda.synchronize()
@@ -278,6 +303,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             body(i)
+        host_enqueue[0] = (time.perf_counter() - t0) / max(steps, 1) * 1e3  # host time to ENQUEUE a step
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -332,12 +358,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    qobj = enc.encode_query(queries[0])
+    multi = world > 1 or args.force_dist
+    group = args.gather_group or (4 if multi else 1)
+    encode_ahead = args.encode_ahead == 1  # measured at 1.25M rows/GPU: 0.151 ms per step against 0.147 in line
+    # (the side stream's kernel and the two cross-stream waits cost more than the 4 us encode they hide)
+    time_every = args.time_every or (8 if multi else 1)
+    qobjs = [enc.encode_query(queries[0]), enc.encode_query(queries[0])]
     gather = topk = None
     if args.exchange == "scores":
         gather = ScoreGather(dist, torch, n_max, dev, rank, world,
                              dst=None if args.gather_root == "rotate" else int(args.gather_root),
-                             always_collective=args.force_dist)
+                             always_collective=args.force_dist, group_steps=group)
     elif args.exchange == "topk":
         topk = ShardedTopK(dist, torch, args.k, dev, rank, world, total_rows)
         if scaling_field == "weak" and world > 1:
@@ -350,22 +381,43 @@ def main():
     pfx = {"u8": "u8", "binary": "bin", "pq": "pq"}[args.quantizer]
     f_encode = getattr(L, f"qamd_{pfx}_encode_query")
     f_score = getattr(L, f"qamd_{pfx}_score_all")
-    h_store, h_query = enc._h, C.c_void_p(qobj._h.value)
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    h_store = enc._h
+    h_query = [C.c_void_p(q._h.value) for q in qobjs]
+    main_stream = torch.cuda.current_stream()
+    stream = C.c_void_p(main_stream.cuda_stream)
+    side = torch.cuda.Stream() if encode_ahead else None  # non-blocking side stream for the next query's encode
+    side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
+    scan_done = [torch.cuda.Event(), torch.cuda.Event()]  # the scan that last READ query object j
     q_ptrs = [C.c_void_p(queries[i].data_ptr()) for i in range(args.queries)]
     qdim = int(dim)
     ev_pairs = []
 
-    def step(i, timed=True):
-        st = f_encode(h_store, q_ptrs[i % args.queries], qdim, _lib.MEM_DEVICE, stream, C.byref(h_query))
+    def encode(i, on):
+        """encode_query of step i into query object i % 2 (the library orders a consumer on another
+        stream after it: ReadyEvent in csrc/common.hpp)."""
+        return f_encode(h_store, q_ptrs[i % args.queries], qdim, _lib.MEM_DEVICE, on, C.byref(h_query[i % 2]))
+
+    def step(i, timed=True, first=False, last=False):
+        st = 0
+        if encode_ahead:
+            if first:
+                st |= encode(i, side_ptr)
+            if not last:  # step i+1's query: its object was last read by the scan of step i-1
+                side.wait_event(scan_done[(i + 1) % 2])
+                st |= encode(i + 1, side_ptr)
+        else:
+            st |= encode(i, stream)
         out = gather.slot(i) if gather is not None else scores_plain
+        timed = timed and (i % time_every == 0)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        st |= f_score(h_store, h_query, C.c_void_p(out.data_ptr()), _lib.MEM_DEVICE, stream)
+        st |= f_score(h_store, h_query[i % 2], C.c_void_p(out.data_ptr()), _lib.MEM_DEVICE, stream)
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))
+        if encode_ahead:
+            scan_done[i % 2].record(main_stream)
         if st:
             raise RuntimeError(L.qamd_last_error().decode())
         if gather is not None:
@@ -376,15 +428,13 @@ def main():
             topk.exchange(largest=True)
 
     for i in range(args.warmup):
-        step(i, False)
+        step(i, False, first=(i == 0), last=(i == args.warmup - 1))
     if gather is not None:
         gather.drain()
-
-    def timed_step(i):
-        step(args.warmup + i, True)
+    torch.cuda.synchronize()
 
     def body(i):
-        timed_step(i)
+        step(i, True, first=(i == 0), last=(i == args.steps - 1))
         if i == args.steps - 1 and gather is not None:
             gather.drain()
 
@@ -445,7 +495,8 @@ def main():
             "metric": "scored vectors/sec, 10Mx768 u8 dot" if headline
             else f"scored vectors/sec, {total_rows}x{dim} {args.quantizer} {args.distance}",
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling_field, "vs_baseline": None,
+            "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": host_enqueue[0],
+            "higher_is_better": True, "scaling": scaling_field, "vs_baseline": None,
             "dtype": {"u8": "u8", "binary": "u1 (xor+popcount, i32)", "pq": "f32 (LUT adds)"}[args.quantizer],
             "data": "synthetic",
             "config": {"workload": (f"{shard_txt}: f32 U[0,1) -> scalar u8 ({args.distance}); "
@@ -454,7 +505,8 @@ def main():
                                    f"per step: encode_query + score_all over the shard"
                                    + (f" + {args.exchange} exchange" if world > 1 and args.exchange != "none" else ""),
                        "quantizer": args.quantizer, "rows_per_gpu": n, "dim": dim, "distance": args.distance,
-                       "exchange": args.exchange,
+                       "exchange": args.exchange, "gather_group": group if gather is not None else None,
+                       "encode_ahead": encode_ahead, "kernel_timed_every": time_every,
                        "gather_root": args.gather_root if (world > 1 and args.exchange == "scores") else None,
                        "total_rows": total_rows, "queries": args.queries},
             "roofline": roofline,
@@ -462,8 +514,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 torch.cuda.synchronize()
-                enc.encode_query(queries[0], reuse=qobj)
-                full = enc.score_all(qobj, out=torch.empty(n, dtype=torch.float32, device=dev))
+                enc.encode_query(queries[0], reuse=qobjs[0])
+                full = enc.score_all(qobjs[0], out=torch.empty(n, dtype=torch.float32, device=dev))
                 torch.cuda.synchronize()
                 sample_rows = min(n, args.cpu_sample_rows or n, 10_000_000)
                 result["cpu_baseline"] = cpu_baseline(enc, queries.cpu().numpy(), full.cpu().numpy(),

@@ -42,71 +42,97 @@ def _needs_host_staging(dist, tensor) -> bool:
 
 
 class ScoreGather:
-    """Double-buffered asynchronous gather of per-shard score vectors to one rank per step.
+    """Double-buffered asynchronous gather of per-shard score vectors to one rank per group of steps.
 
-    submit(step) starts the gather of slot step%2 (a tensor of `rows_padded` f32 the scan of that
-    step wrote) and returns; the caller may immediately launch the next scan into the other slot.
-    collect(step) waits (stream-ordered) and, on that step's root, returns the [world, rows_padded]
-    tensor holding every shard's scores of that step (None elsewhere).
+    slot(step) is the tensor of `rows_padded` f32 the scan of that step writes; submit(step) starts
+    the gather once the group's last step has been submitted (group_steps queries travel in ONE
+    collective: at 8 GPUs a 1.25M-row shard scan takes ~0.15 ms, the launch latency of a collective is
+    tens of microseconds, so paying it per query would cost ~20 % of the step) and returns; the
+    caller goes straight on to the next scan.  collect(step) waits (stream-ordered) and, on that
+    step's root, returns the [world, rows_padded] tensor holding every shard's scores of that step
+    (None elsewhere).
 
-    dst = an int: every step gathers to that rank (its 7 inbound xGMI links carry everything).
-    dst = None ("rotate"): step i gathers to rank i % world, so consecutive gathers use disjoint
+    dst = an int: every group gathers to that rank (its 7 inbound xGMI links carry everything).
+    dst = None ("rotate"): group j gathers to rank j % world, so consecutive gathers use disjoint
     inbound links and overlap each other as well as the scans; each query's scores land on one GPU,
     round-robin, which is also how their post-processing would be balanced.
     """
 
     def __init__(self, dist, torch, rows_padded: int, device, rank: int, world: int, dst=0, group=None,
-                 always_collective: bool = False):
+                 always_collective: bool = False, group_steps: int = 1):
         self.dist, self.torch = dist, torch
         self.rank, self.world, self.dst, self.group = rank, world, dst, group
         self.rows_padded = rows_padded
+        self.B = max(1, int(group_steps))
         # always_collective: run the collective even at world size 1 (a one-rank gather is legal;
         # it lets a single-GPU box exercise the RCCL call path)
         self.single = world == 1 and not always_collective
-        self.local = [torch.empty(rows_padded, dtype=torch.float32, device=device) for _ in range(2)]
+        self.local = [torch.empty((self.B, rows_padded), dtype=torch.float32, device=device) for _ in range(2)]
         self.gathered = None
         if not self.single and (dst is None or rank == dst):
-            self.gathered = [torch.empty((world, rows_padded), dtype=torch.float32, device=device)
+            self.gathered = [torch.empty((world, self.B, rows_padded), dtype=torch.float32, device=device)
                              for _ in range(2)]
         self.work = [None, None]
+        self.pending = [0, 0]  # steps written into buffer s and not yet sent
+        self.pending_step = [0, 0]
 
     def root(self, step: int) -> int:
-        return step % self.world if self.dst is None else self.dst
+        return (step // self.B) % self.world if self.dst is None else self.dst
+
+    def _buf(self, step: int) -> int:
+        return (step // self.B) % 2
 
     def slot(self, step: int):
         """Buffer the scan of `step` must write into (after the previous use has drained)."""
-        s = step % 2
-        if self.work[s] is not None:
+        s = self._buf(step)
+        if step % self.B == 0 and self.work[s] is not None:
             self.work[s].wait()
             self.work[s] = None
-        return self.local[s]
+        return self.local[s][step % self.B]
 
-    def submit(self, step: int) -> None:
-        s = step % 2
+    def _send(self, s: int, dst: int) -> None:
+        self.pending[s] = 0
         if self.single:  # single shard: the local scores ARE the global scores
             return
-        dst = self.root(step)
-        if _needs_host_staging(self.dist, self.local[s]):
-            host = self.local[s].cpu()
+        local = self.local[s].view(-1)
+        if _needs_host_staging(self.dist, local):
+            host = local.cpu()
             hlist = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == dst else None
             self.dist.gather(host, gather_list=hlist, dst=dst, group=self.group)
             if self.rank == dst:
-                self.gathered[s].copy_(self.torch.stack(hlist))
+                self.gathered[s].copy_(self.torch.stack(hlist).view(self.world, self.B, self.rows_padded))
             return
-        glist = list(self.gathered[s].unbind(0)) if self.rank == dst else None
-        self.work[s] = self.dist.gather(self.local[s], gather_list=glist, dst=dst, group=self.group, async_op=True)
+        glist = list(self.gathered[s].view(self.world, -1).unbind(0)) if self.rank == dst else None
+        self.work[s] = self.dist.gather(local, gather_list=glist, dst=dst, group=self.group, async_op=True)
+
+    def submit(self, step: int) -> None:
+        s = self._buf(step)
+        self.pending[s] += 1
+        self.pending_step[s] = step
+        if step % self.B == self.B - 1:
+            self._send(s, self.root(step))
+
+    def flush(self, step: int) -> None:
+        """Send a partly filled group (the last steps of a run)."""
+        s = self._buf(step)
+        if self.pending[s]:
+            self._send(s, self.root(step))
 
     def collect(self, step: int):
-        s = step % 2
+        s = self._buf(step)
+        if self.pending[s]:
+            self._send(s, self.root(step))
         if self.work[s] is not None:
             self.work[s].wait()
             self.work[s] = None
         if self.single:
-            return self.local[s].unsqueeze(0)
-        return self.gathered[s] if self.rank == self.root(step) else None
+            return self.local[s][step % self.B].unsqueeze(0)
+        return self.gathered[s][:, step % self.B] if self.rank == self.root(step) else None
 
     def drain(self) -> None:
         for s in range(2):
+            if self.pending[s]:  # a partly filled group; every rank holds the same one, so this stays collective
+                self._send(s, self.root(self.pending_step[s]))
             if self.work[s] is not None:
                 self.work[s].wait()
                 self.work[s] = None

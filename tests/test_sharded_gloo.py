@@ -40,6 +40,7 @@ def _worker(rank, world, port, n, dim, tmp):
     pad = max_shard_rows(n, world)
     gather = ScoreGather(dist, torch, pad, "cpu", rank, world, dst=0)
     rotating = ScoreGather(dist, torch, pad, "cpu", rank, world, dst=None)  # root = step % world
+    grouped = ScoreGather(dist, torch, pad, "cpu", rank, world, dst=None, group_steps=2)  # 2 queries per collective
     topk = ShardedTopK(dist, torch, 10, "cpu", rank, world, n)
     g_rows, g_meta = qo.u8_encode_with(data, qo.DOT, False, alpha, offset)
     results = []
@@ -58,6 +59,9 @@ def _worker(rank, world, port, n, dim, tmp):
         rslot = rotating.slot(step)
         rslot[: e - b] = torch.from_numpy(local)
         rotating.submit(step)
+        gslot = grouped.slot(step)
+        gslot[: e - b] = torch.from_numpy(local)
+        grouped.submit(step)  # sends after steps 1 (full group) — step 2's half-filled group goes at drain()
         got = gather.collect(step)
         want = qo.u8_score_all(g_meta, g_rows, codes, qoff)
         if rank == 0:
@@ -71,7 +75,15 @@ def _worker(rank, world, port, n, dim, tmp):
         worder = np.lexsort((np.arange(n), -want))[:10]
         assert np.array_equal(merged_ids, worder.astype(np.uint32)), "merged top-k ids differ"
         assert np.array_equal(merged_sc, want[worder])
-        results.append(True)
+        results.append(want)
+    grouped.drain()
+    for step, want in enumerate(results):  # group 0 = steps 0, 1 -> rank 0; group 1 = step 2 -> rank 1
+        assert grouped.root(step) == (step // 2) % world
+        got_g = grouped.collect(step)
+        assert (got_g is not None) == (rank == grouped.root(step))
+        if got_g is not None:
+            flat = assemble_global_scores(got_g, n, world).numpy()
+            assert np.array_equal(flat.view(np.uint32), want.view(np.uint32)), "grouped gather differs"
     # batched exchange: all three queries at once, k = 7 (some shards hold fewer than k rows when n is tiny)
     kb = 7
     batch = ShardedTopKBatch(dist, torch, len(queries), kb, "cpu", rank, world, n)
