@@ -265,6 +265,22 @@ QAMD_API qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, u
                                    qamd_mem out_mem, void *stream);
 QAMD_API void qamd_bin_free(qamd_bin *h);
 
+/* Many queries at once (the caller's outer loop, demos/src/ann_benchmark.rs:245-260; BASELINE config
+ * 3/4 shape).  score_batch reads every row once for up to 8 queries; topk_batch runs the per-query
+ * fused selections back to back with one status read-back per 32 queries.  Every score and list is
+ * bit-identical to the single-query calls.  topk_batch synchronises the stream. */
+typedef struct qamd_bin_query_batch qamd_bin_query_batch; /* n x EncodedBinVector */
+QAMD_API qamd_status qamd_bin_encode_query_batch(const qamd_bin *h, const float *queries, uint64_t n_queries,
+                                                 uint64_t qdim, qamd_mem queries_mem, void *stream,
+                                                 qamd_bin_query_batch **batch_io);
+QAMD_API void qamd_bin_query_batch_free(qamd_bin_query_batch *b);
+/* out[q * count + i] = score_point(query q, i). */
+QAMD_API qamd_status qamd_bin_score_batch(const qamd_bin *h, const qamd_bin_query_batch *b, float *out,
+                                          qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b, uint32_t k,
+                                         int largest, uint32_t *out_ids, float *out_scores,
+                                         qamd_mem out_mem, void *stream);
+
 /* ===================================================================================
  * Product quantizer — quantization/src/encoded_vectors_pq.rs
  * =================================================================================== */
@@ -338,6 +354,21 @@ QAMD_API qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint
                                   int largest, uint32_t *out_ids, float *out_scores,
                                   qamd_mem out_mem, void *stream);
 QAMD_API void qamd_pq_free(qamd_pq *h);
+
+/* Many queries at once (BASELINE config 4's PQ leg): all LUTs are built by one launch, the per-query
+ * LDS-LUT scans are enqueued back to back (the scan is LDS-gather-bound, one LUT fills the LDS, so
+ * queries cannot share a pass); topk_batch reads statuses back once per 32 queries and synchronises
+ * the stream.  Bit-identical to the single-query calls. */
+typedef struct qamd_pq_query_batch qamd_pq_query_batch; /* n x EncodedQueryPQ */
+QAMD_API qamd_status qamd_pq_encode_query_batch(const qamd_pq *h, const float *queries, uint64_t n_queries,
+                                                uint64_t qdim, qamd_mem queries_mem, void *stream,
+                                                qamd_pq_query_batch **batch_io);
+QAMD_API void qamd_pq_query_batch_free(qamd_pq_query_batch *b);
+QAMD_API qamd_status qamd_pq_score_batch(const qamd_pq *h, const qamd_pq_query_batch *b, float *out,
+                                         qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_batch *b, uint32_t k,
+                                        int largest, uint32_t *out_ids, float *out_scores,
+                                        qamd_mem out_mem, void *stream);
 
 /* ===================================================================================
  * Row-sharded stores: ONE process, several GPUs of a node behind one handle.

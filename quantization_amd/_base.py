@@ -26,9 +26,30 @@ class EncodedQueryBase:
             self._h = None
 
 
+class EncodedQueryBatch:
+    """n encoded queries resident in HBM (n x EncodedQuery*), for the many-queries-at-once calls."""
+
+    _prefix = ""
+
+    def __init__(self, handle: C.c_void_p, n_queries: int, prefix: str | None = None):
+        self._h = handle
+        self.n_queries = n_queries
+        if prefix is not None:
+            self._prefix = prefix
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                getattr(_lib.lib(), f"qamd_{self._prefix}_query_batch_free")(self._h)
+            except Exception:
+                pass
+        self._h = None
+
+
 class EncodedVectorsBase:
     _prefix = ""
     _query_cls = EncodedQueryBase
+    _batch_cls = EncodedQueryBatch
 
     def __init__(self, handle: C.c_void_p, device: int | None = None, owned: bool = True):
         self._h = handle
@@ -100,6 +121,42 @@ class EncodedVectorsBase:
             raise ValueError("out_ids and out_scores must both be host or both be device buffers")
         check(self._fn("topk")(self._h, query._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem,
                                stream_ptr(stream)))
+        return ids, sc
+
+    # ------------------------------------------------------------------ many queries at once
+    def encode_query_batch(self, queries, reuse=None, stream=None):
+        """encode_query for a [n_queries, dim] block of queries (the caller's outer loop,
+        demos/src/ann_benchmark.rs:245-260)."""
+        nq, qdim = int(queries.shape[0]), int(queries.shape[1])
+        check_same_device(self._device, queries)
+        buf = in_buf(queries, np.float32)
+        h = reuse._h if reuse is not None else C.c_void_p()
+        check(self._fn("encode_query_batch")(self._h, buf.ptr, nq, qdim, buf.mem, stream_ptr(stream), C.byref(h)))
+        if reuse is not None:
+            reuse.n_queries = nq
+            return reuse
+        return self._batch_cls(h, nq, self._prefix)
+
+    def score_batch(self, batch, out=None, stream=None):
+        """scores[q, i] = score_point(query q, i) — bit-identical to score_all per query."""
+        n = self.count
+        check_same_device(self._device, out)
+        buf, ret = out_buf(out, batch.n_queries * n, np.float32)
+        check(self._fn("score_batch")(self._h, batch._h, buf.ptr, buf.mem, stream_ptr(stream)))
+        return ret.reshape(batch.n_queries, n) if isinstance(ret, np.ndarray) else ret
+
+    def topk_batch(self, batch, k: int, largest: bool = True, out_ids=None, out_scores=None, stream=None):
+        """Per-query best-k (ann_benchmark_data.rs:151-167), [n_queries, k] ids and scores."""
+        nq = batch.n_queries
+        check_same_device(self._device, out_ids, out_scores)
+        ib, ids = out_buf(out_ids, nq * k, np.uint32)
+        sb, sc = out_buf(out_scores, nq * k, np.float32)
+        if ib.mem != sb.mem:
+            raise ValueError("out_ids and out_scores must both be host or both be device buffers")
+        check(self._fn("topk_batch")(self._h, batch._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem,
+                                     stream_ptr(stream)))
+        if isinstance(ids, np.ndarray):
+            return ids.reshape(nq, k), sc.reshape(nq, k)
         return ids, sc
 
     def __del__(self):

@@ -121,6 +121,10 @@ def lib() -> C.CDLL:
         "qamd_bin_score_ids": (i32, [vp, vp, vp, u64, i32, vp, i32, vp]),
         "qamd_bin_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_bin_free": (None, [vp]),
+        "qamd_bin_encode_query_batch": (i32, [vp, vp, u64, u64, i32, vp, pp]),
+        "qamd_bin_query_batch_free": (None, [vp]),
+        "qamd_bin_score_batch": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_bin_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_bin_encoder_begin": (i32, [VP, i32, STOP_FN, vp, vp, pp]),
         "qamd_bin_encoder_push": (i32, [vp, vp, u64, i32]),
         "qamd_bin_encoder_finish": (i32, [vp, pp]),
@@ -142,6 +146,10 @@ def lib() -> C.CDLL:
         "qamd_pq_score_ids": (i32, [vp, vp, vp, u64, i32, vp, i32, vp]),
         "qamd_pq_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_pq_free": (None, [vp]),
+        "qamd_pq_encode_query_batch": (i32, [vp, vp, u64, u64, i32, vp, pp]),
+        "qamd_pq_query_batch_free": (None, [vp]),
+        "qamd_pq_score_batch": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_pq_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_pq_kmeans_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32)]),
         "qamd_pq_encoder_begin": (i32, [VP, u64, vp, u32, STOP_FN, vp, vp, pp]),
         "qamd_pq_encoder_observe": (i32, [vp, vp, u64, i32]),

@@ -133,6 +133,66 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__res
     }
 }
 
+// NQ queries per row read (qamd_bin_score_batch): the row's 16-byte pieces are loaded once and
+// xor-popcounted against NQ query rows held in registers, so the HBM bytes per (query, row) pair fall
+// from ds + 4 to ds / NQ + 4 and the scan turns from HBM-bound into popcount-bound.
+// Lane (row slot, sub = j) keeps query j's score of the row: one store instruction per row slot
+// writes NQ segments of 64/G consecutive floats.  G >= NQ.
+template <int G, int ITERS, int UNROLL, int NQ, bool EXACT>
+__global__ __launch_bounds__(kScanBlock) void bin_scan_multi_kernel(const uint4 *__restrict__ rows,
+                                                                   const uint4 *__restrict__ qbits /* [NQ][q_stride] */,
+                                                                   uint32_t q_stride, float dim_f, int is_dot, int invert,
+                                                                   uint32_t n_rows, uint32_t row_chunks,
+                                                                   float *__restrict__ out /* [NQ][out_pitch] */,
+                                                                   uint64_t out_pitch) {
+    static_assert(G >= NQ, "one lane of the row group per query");
+    constexpr int RW = 64 / G;
+    constexpr int TILE = RW * UNROLL;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kScanBlock + threadIdx.x) >> 6;
+    const uint64_t base = wave * TILE;
+    if (base >= n_rows) return;
+    uint4 q[NQ][ITERS];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint32_t c = sub + it * G;
+            const bool in = EXACT || c < row_chunks;
+            const uint4 t = qbits[(size_t)j * q_stride + (in ? c : row_chunks - 1)];
+            q[j][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+        }
+    }
+    uint4 v[UNROLL][ITERS];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        const uint64_t row = base + u * RW + rslot;
+        const uint4 *p = rows + row * row_chunks;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint32_t c = sub + it * G;
+            const bool in = EXACT || c < row_chunks;
+            const uint4 t = ld_nt(p + (in ? c : row_chunks - 1));
+            v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        float mine = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) acc = xpop16(v[u][it], q[j][it], acc);
+            acc = group_sum<G>(acc);
+            if (sub == j) mine = metric(acc, dim_f, is_dot, invert);
+        }
+        const uint64_t row = base + (uint64_t)u * RW + rslot;
+        if (sub < NQ && row < n_rows) __builtin_nontemporal_store(mine, out + (uint64_t)sub * out_pitch + row);
+    }
+}
+
 // Any row size, dword granularity: used for tiny rows (ds 4 or 8), very long rows and the
 // random-access entry points.  ids == nullptr scans rows [0, n).
 __global__ __launch_bounds__(kBlock) void bin_words_kernel(const uint32_t *__restrict__ rows,
@@ -302,12 +362,12 @@ qamd_status words_launch(const qamd_bin *h, const uint32_t *qbits, const uint32_
 
 bool fused_capable(const qamd_bin *h) { return h->ds % 16 == 0 && h->ds / 16 <= 64; }
 
-qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev, hipStream_t s,
+qamd_status scan_bits(const qamd_bin *h, const void *qbits_dev, float *out_dev, hipStream_t s,
                       const TopkFilter *filt = nullptr) {
     if (h->count == 0) return QAMD_OK;
     const uint32_t rc = (uint32_t)(h->ds / 16);
-    if (!fused_capable(h)) return words_launch(h, q->buf.as<uint32_t>(), nullptr, h->count, out_dev, s);
-    const uint4 *qb = q->buf.as<uint4>();
+    if (!fused_capable(h)) return words_launch(h, static_cast<const uint32_t *>(qbits_dev), nullptr, h->count, out_dev, s);
+    const uint4 *qb = static_cast<const uint4 *>(qbits_dev);
     if (rc == 1) launch_bin<1, 1, 4>(h, qb, out_dev, filt, s);
     else if (rc == 2) launch_bin<2, 1, 4>(h, qb, out_dev, filt, s);
     else if (rc <= 4) launch_bin<4, 1, 8>(h, qb, out_dev, filt, s);
@@ -318,6 +378,11 @@ qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev
     else launch_bin<16, 4, 2>(h, qb, out_dev, filt, s);
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;
+}
+
+qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev, hipStream_t s,
+                      const TopkFilter *filt = nullptr) {
+    return scan_bits(h, q->buf.ptr, out_dev, s, filt);
 }
 
 qamd_status check_query(const qamd_bin *h, const qamd_bin_query *q) {
@@ -639,6 +704,156 @@ void qamd_bin_free(qamd_bin *h) { delete h; }
 
 }  // extern "C"
 
+
+// ============================================================================= many queries at once
+// The caller's outer loop over queries (demos/src/ann_benchmark.rs:245-260).  score_batch reads every
+// row ONCE for up to 8 queries (bin_scan_multi_kernel); topk_batch enqueues the per-query fused
+// pipelines back to back (fused_topk_batch: one status read-back per 32 queries).
+struct qamd_bin_query_batch {
+    int device = 0;
+    uint64_t nb = 0, ds = 0, n_queries = 0;
+    uint64_t q_stride = 0;  // bytes between two queries' bit rows (multiple of 16)
+    DevBuf bits;            // [n_queries][q_stride]
+};
+
+namespace {
+
+template <int G, int ITERS, int UNROLL, int NQ>
+void launch_bin_multi(const qamd_bin *h, const uint8_t *qbits, uint64_t q_stride, float *out, hipStream_t s) {
+    constexpr int TILE = (64 / G) * UNROLL;
+    const uint32_t rc = (uint32_t)(h->ds / 16);
+    const uint64_t waves = (h->count + TILE - 1) / TILE;
+    const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
+    const bool exact = rc == (uint32_t)(G * ITERS);
+#define QAMD_BIN_MULTI(EX)                                                                                        \
+    hipLaunchKernelGGL((bin_scan_multi_kernel<G, ITERS, UNROLL, NQ, EX>), dim3(grid), dim3(kScanBlock), 0, s,     \
+                       h->rows.as<uint4>(), reinterpret_cast<const uint4 *>(qbits), (uint32_t)(q_stride / 16),    \
+                       (float)h->vp.dim, (int)(h->vp.distance_type == QAMD_DOT), h->vp.invert, (uint32_t)h->count, \
+                       rc, out, (uint64_t)h->count)
+    if (exact) QAMD_BIN_MULTI(true);
+    else QAMD_BIN_MULTI(false);
+#undef QAMD_BIN_MULTI
+}
+
+// Queries [q0, q0 + nq) with nq in {8, 4, 2}: rows of 8 .. 64 pieces (dims 1024 .. 8192 at the u128 granule).
+template <int NQ> bool multi_step(const qamd_bin *h, const uint8_t *qbits, uint64_t q_stride, float *out, hipStream_t s) {
+    const uint32_t rc = (uint32_t)(h->ds / 16);
+    if (rc < 8 || rc > 64 || h->ds % 16) return false;
+    if (rc == 8) launch_bin_multi<8, 1, 8, NQ>(h, qbits, q_stride, out, s);
+    else if (rc <= 16) launch_bin_multi<16, 1, 4, NQ>(h, qbits, q_stride, out, s);
+    else if (rc <= 32) launch_bin_multi<16, 2, 2, NQ>(h, qbits, q_stride, out, s);
+    else if (NQ <= 4) launch_bin_multi<16, 4, 2, NQ>(h, qbits, q_stride, out, s);
+    else return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+qamd_status qamd_bin_encode_query_batch(const qamd_bin *h, const float *queries, uint64_t n_queries, uint64_t qdim,
+                                        qamd_mem queries_mem, void *stream, qamd_bin_query_batch **batch_io) {
+    if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    const uint64_t nb = row_bytes_of(qdim, h->store), ds = device_stride_of(nb);
+    if (n_queries && nb != h->nb)
+        return fail(QAMD_ERR_ARGUMENTS, "queries have %llu bytes, rows have %llu", (unsigned long long)nb,
+                    (unsigned long long)h->nb);
+    qamd_bin_query_batch *b = *batch_io;
+    std::unique_ptr<qamd_bin_query_batch> fresh;
+    if (!b) {
+        fresh.reset(new qamd_bin_query_batch);
+        b = fresh.get();
+        b->device = h->device;
+    }
+    const uint64_t q_stride = round_up(ds, 16);
+    const size_t need = std::max<size_t>(q_stride * n_queries, 16);
+    if (b->bits.bytes < need || b->q_stride != q_stride) QAMD_TRY(b->bits.alloc(need, true));
+    b->nb = nb;
+    b->ds = ds;
+    b->q_stride = q_stride;
+    b->n_queries = n_queries;
+    if (n_queries && qdim) {
+        DevBuf qtmp;
+        const void *qd = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(queries, queries_mem, n_queries * qdim * 4, qtmp, s, &qd, &staged));
+        // the row encoder with one "row" per query and the batch's stride (:288-291 is encode_vector itself)
+        int grid = grid_for(n_queries, kBlock / 64, 8);
+        hipLaunchKernelGGL(bin_encode_kernel, dim3(grid), dim3(kBlock), 0, s, static_cast<const float *>(qd), n_queries,
+                           (uint32_t)qdim, (uint32_t)(q_stride / 4), b->bits.as<uint32_t>(), (uint64_t)0);
+        QAMD_HIP(hipGetLastError());
+        if (staged) QAMD_HIP(hipStreamSynchronize(s));
+    }
+    if (fresh) *batch_io = fresh.release();
+    return QAMD_OK;
+}
+
+void qamd_bin_query_batch_free(qamd_bin_query_batch *b) { delete b; }
+
+static qamd_status bin_check_batch(const qamd_bin *h, const qamd_bin_query_batch *b) {
+    if (!h || !b) return fail(QAMD_ERR_ARGUMENTS, "null handle or query batch");
+    if (b->n_queries && b->nb != h->nb)
+        return fail(QAMD_ERR_ARGUMENTS, "queries have %llu bytes, rows have %llu", (unsigned long long)b->nb,
+                    (unsigned long long)h->nb);
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_score_batch(const qamd_bin *h, const qamd_bin_query_batch *b, float *out, qamd_mem out_mem,
+                                 void *stream) {
+    QAMD_TRY(bin_check_batch(h, b));
+    if (h->count == 0 || b->n_queries == 0) return QAMD_OK;
+    if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    StreamBuf tmp;
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(tmp.alloc(b->n_queries * h->count * 4, s));
+        out_dev = tmp.as<float>();
+    }
+    const uint8_t *bits = b->bits.as<uint8_t>();
+    uint64_t q = 0;
+    while (q < b->n_queries) {
+        const uint64_t left = b->n_queries - q;
+        const uint8_t *qb = bits + q * b->q_stride;
+        float *o = out_dev + q * h->count;
+        if (left >= 8 && multi_step<8>(h, qb, b->q_stride, o, s)) q += 8;
+        else if (left >= 4 && multi_step<4>(h, qb, b->q_stride, o, s)) q += 4;
+        else if (left >= 2 && multi_step<2>(h, qb, b->q_stride, o, s)) q += 2;
+        else {
+            QAMD_TRY(scan_bits(h, qb, o, s));
+            q += 1;
+        }
+    }
+    QAMD_HIP(hipGetLastError());
+    if (out_mem == QAMD_MEM_HOST) return copy_out(out, QAMD_MEM_HOST, out_dev, b->n_queries * h->count * 4, s);
+    return QAMD_OK;
+}
+
+qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b, uint32_t k, int largest,
+                                uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(bin_check_batch(h, b));
+    if (k == 0 || b->n_queries == 0) return QAMD_OK;
+    if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
+    QAMD_ON_DEVICE(h->device);
+    const uint8_t *bits = b->bits.as<uint8_t>();
+    const uint64_t qs = b->q_stride;
+    BatchScan scan;
+    scan.filter_capable = fused_capable(h);
+    scan.scan_scores = [&](uint32_t q, float *scores, hipStream_t st) { return scan_bits(h, bits + q * qs, scores, st); };
+    scan.scan_filter = [&](uint32_t q, const TopkFilter &f, hipStream_t st) {
+        return scan_bits(h, bits + q * qs, nullptr, st, &f);
+    };
+    scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+        return words_launch(h, reinterpret_cast<const uint32_t *>(bits + q * qs), ids, n_ids, out, st);
+    };
+    return fused_topk_batch(h->count, (uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, as_stream(stream),
+                            scan);
+}
+
+}  // extern "C"
 
 // ============================================================================= streaming encode
 // EncodedVectorsBin::encode (:165-191) walks its iterator ONCE, pushing one packed row per vector

@@ -103,6 +103,75 @@ void DevBuf::release() {
     bytes = 0;
 }
 
+namespace {
+struct QueryBufCache {
+    struct Entry { void *ptr; size_t bytes; int dev; hipEvent_t ev; bool pending; };
+    std::mutex m;
+    std::vector<Entry> free_list;
+};
+QueryBufCache &query_cache() {
+    static QueryBufCache *c = new QueryBufCache;  // leaked on purpose: no destructor-order issues at exit
+    return *c;
+}
+constexpr size_t kQueryCacheEntries = 64;
+}  // namespace
+
+qamd_status query_buf_get(size_t bytes, DevBuf &out, ReadyEvent &ev) {
+    out.release();
+    int dev = 0;
+    QAMD_HIP(hipGetDevice(&dev));
+    QueryBufCache::Entry hit{nullptr, 0, 0, nullptr, false};
+    {
+        QueryBufCache &c = query_cache();
+        std::lock_guard<std::mutex> lk(c.m);
+        for (size_t i = 0; i < c.free_list.size(); i++) {
+            if (c.free_list[i].dev == dev && c.free_list[i].bytes == bytes) {
+                hit = c.free_list[i];
+                c.free_list[i] = c.free_list.back();
+                c.free_list.pop_back();
+                break;
+            }
+        }
+    }
+    if (!hit.ptr) return out.alloc(bytes, true);
+    if (hit.pending && hit.ev) (void)hipEventSynchronize(hit.ev);  // the previous owner's last work (normally long done)
+    out.ptr = hit.ptr;
+    out.bytes = bytes;
+    if (hit.ev) {
+        if (ev.ev) (void)hipEventDestroy(ev.ev);
+        ev.ev = hit.ev;
+        ev.set = false;
+    }
+    return QAMD_OK;
+}
+
+void query_buf_put(DevBuf &buf, ReadyEvent &ev) {
+    if (!buf.ptr) return;
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, buf.ptr) == hipSuccess) {
+        bool pending = false;
+        if (ev.set && ev.ev) pending = hipEventRecord(ev.ev, ev.stream) == hipSuccess;
+        if (ev.set && !pending) {  // cannot order the next owner after this one: do not recycle
+            (void)hipGetLastError();
+            buf.release();
+            return;
+        }
+        QueryBufCache &c = query_cache();
+        std::lock_guard<std::mutex> lk(c.m);
+        if (c.free_list.size() < kQueryCacheEntries) {
+            c.free_list.push_back({buf.ptr, buf.bytes, attr.device, ev.ev, pending});
+            buf.ptr = nullptr;
+            buf.bytes = 0;
+            ev.ev = nullptr;
+            ev.set = false;
+            return;
+        }
+    } else {
+        (void)hipGetLastError();
+    }
+    buf.release();
+}
+
 qamd_status StreamBuf::alloc(size_t n, hipStream_t s, bool zero) {
     release();
     static std::once_flag once[64];  // per device: its default pool keeps what it is given
@@ -210,6 +279,8 @@ struct ThreadWs {
 struct ThreadState {
     HostScratch scratch;
     bool scratch_tried = false;
+    hipEvent_t query_read = nullptr;  // the last kernel that read the scratch's query area
+    bool query_pending = false;
     std::vector<ThreadWs> ws;  // [device][slot], grown on demand
 
     ThreadWs &at(int dev, ThreadWsSlot slot) {
@@ -236,6 +307,10 @@ struct ThreadState {
         }
         ws.clear();
         if (moved && have_prev) (void)hipSetDevice(prev);
+        if (query_pending && query_read) (void)hipEventSynchronize(query_read);
+        if (query_read) (void)hipEventDestroy(query_read);
+        query_read = nullptr;
+        query_pending = false;
         if (scratch.host) (void)hipHostFree(scratch.host);
         scratch = HostScratch{};
         scratch_tried = false;
@@ -267,6 +342,28 @@ HostScratch host_scratch() {
         }
     }
     return ts.scratch;
+}
+
+float *host_query_acquire(size_t n_floats, const float **dev_view) {
+    if (n_floats > kHostQueryWords) return nullptr;
+    const HostScratch hs = host_scratch();
+    if (!hs.host) return nullptr;
+    ThreadState &ts = thread_state();
+    if (ts.query_pending) {
+        if (hipEventSynchronize(ts.query_read) != hipSuccess) return nullptr;
+        ts.query_pending = false;
+    }
+    if (!ts.query_read && hipEventCreateWithFlags(&ts.query_read, hipEventDisableTiming) != hipSuccess) {
+        ts.query_read = nullptr;
+        return nullptr;
+    }
+    *dev_view = reinterpret_cast<const float *>(hs.dev + kHostQueryAt);
+    return reinterpret_cast<float *>(hs.host + kHostQueryAt);
+}
+
+void host_query_release(hipStream_t s) {
+    ThreadState &ts = thread_state();
+    if (ts.query_read && hipEventRecord(ts.query_read, s) == hipSuccess) ts.query_pending = true;
 }
 
 qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out, uint64_t **tags) {

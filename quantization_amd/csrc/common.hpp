@@ -90,6 +90,19 @@ struct DevBuf {
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };
 
+// Recycles the small device buffers behind encoded-query objects.  The reference's encode_query
+// returns a fresh EncodedQuery value per call (encoded_vectors.rs:27); a binding that mirrors that
+// creates and drops one query object per search, and a hipMalloc + hipFree pair costs more than a
+// 100k-row scan.  Freed buffers are kept (per device and size, a few dozen at most) and handed out
+// again; contents are NOT cleared -- every encode_query overwrites what its consumers read.
+// A buffer is parked together with its query's event, re-recorded at that moment on the stream of
+// the last encode (so it covers every consumer enqueued there); the next owner waits on it first.
+// (A query used on OTHER streams than its encode stream must not be freed while those calls are
+// in flight -- the usual rule for asynchronous work.)
+struct ReadyEvent;
+qamd_status query_buf_get(size_t bytes, DevBuf &out, ReadyEvent &ev);
+void query_buf_put(DevBuf &buf, ReadyEvent &ev);
+
 inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
 // Per-call scratch, stream-ordered (hipMallocAsync / hipFreeAsync on the call's stream).  The
@@ -134,12 +147,22 @@ qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t by
 // qamd_thread_release() or at thread exit).  The per-pair API calls
 // (score_point, score_internal, small score_ids) put their row ids there and let the kernel
 // write the scores straight back: no allocation, no explicit copy, one launch + one sync.
-constexpr size_t kHostScratchWords = 2048 + 16;  // [0, 1024) ids, [1024, 2048) results, [2048] a status word
+constexpr size_t kHostQueryWords = 12288;  // a host query of up to 12288 f32 rides in the scratch too
+constexpr size_t kHostQueryAt = 2048 + 16;
+constexpr size_t kHostScratchWords = kHostQueryAt + kHostQueryWords;  // [0, 1024) ids, [1024, 2048) results,
+                                                                     // [2048] a status word, [2064, ...) a query
 struct HostScratch {
     uint32_t *host = nullptr;  // what the CPU reads / writes
     uint32_t *dev = nullptr;   // the same memory as the GPU addresses it
 };
 HostScratch host_scratch();
+// The query area of the scratch: encode_query of a HOST query writes the f32 values there and the
+// encode kernel reads them over the mapped pointer -- no H2D copy call, no synchronisation.
+// acquire waits until the previous kernel that read the area has finished (it normally has);
+// release records that on the stream the new reader was launched on.  nullptr when n_floats does
+// not fit or the scratch is unavailable (callers then stage through device memory).
+float *host_query_acquire(size_t n_floats, const float **dev_view);
+void host_query_release(hipStream_t s);
 
 // Grow-only device workspaces per calling thread AND device, handed from call to call in
 // stream order: release() records an event on the call's stream, the next acquire() makes its own
@@ -148,7 +171,7 @@ HostScratch host_scratch();
 // runtime, which is most of a top-k on a small store.  A thread that alternates between stores
 // on several GPUs keeps one workspace per (slot, device).  Freed by qamd_thread_release() or when
 // the thread exits.
-enum ThreadWsSlot { WS_SCORES = 0, WS_SELECT = 1, WS_PARTIAL = 2, WS_FUSED = 3, WS_SLOTS = 4 };
+enum ThreadWsSlot { WS_SCORES = 0, WS_SELECT = 1, WS_PARTIAL = 2, WS_FUSED = 3, WS_SMALL = 4, WS_SLOTS = 5 };
 // `tags` (optional) points at three caller-owned words that live with the buffer and are zeroed
 // whenever it is (re)allocated: what the caller has cached inside it.
 qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out,

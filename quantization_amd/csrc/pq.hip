@@ -373,6 +373,26 @@ __global__ __launch_bounds__(kBlock) void pq_lut_kernel(const float *__restrict_
     lut[i] = invert ? -s : s;
 }
 
+// encode_query for a block of queries: blockIdx.y = query, same arithmetic as pq_lut_kernel.
+__global__ __launch_bounds__(kBlock) void pq_lut_batch_kernel(const float *__restrict__ queries, uint32_t dim,
+                                                             uint32_t chunk_size, uint32_t m,
+                                                             const float *__restrict__ centroids, int distance,
+                                                             int invert, float *__restrict__ luts) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m * kCentroids) return;
+    const uint32_t c = i / kCentroids, kc = i % kCentroids;
+    const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
+    const float *a = queries + (size_t)blockIdx.y * dim + lo, *b = centroids + (size_t)kc * dim + lo;
+    float s = 0.0f;
+    if (distance == QAMD_DOT)
+        for (uint32_t j = 0; j < len; j++) s += a[j] * b[j];
+    else if (distance == QAMD_L1)
+        for (uint32_t j = 0; j < len; j++) s += fabsf(a[j] - b[j]);
+    else
+        for (uint32_t j = 0; j < len; j++) s += (a[j] - b[j]) * (a[j] - b[j]);
+    luts[(size_t)blockIdx.y * m * kCentroids + i] = invert ? -s : s;
+}
+
 // score_internal (:566-593): decode both rows to centroid sub-vectors, sequential f32.
 __global__ void pq_internal_kernel(const uint8_t *__restrict__ rows, uint32_t row_stride, uint32_t dim,
                                    uint32_t chunk_size, uint32_t m, const float *__restrict__ centroids,
@@ -1380,6 +1400,110 @@ void qamd_pq_encoder_abort(qamd_pq_encoder *e) {
     DeviceGuard g(e->device);
     (void)hipStreamSynchronize(e->stream);
     delete e;
+}
+
+}  // extern "C"
+
+// ============================================================================= many queries at once
+// The caller's OUTER loop over queries (demos/src/ann_benchmark.rs:245-260), each with its 30-entry
+// heap (ann_benchmark_data.rs:151-167).  A PQ scan serves one query at a time -- the LDS holds one
+// chunk-major LUT (96 KiB at m = 96) and the gather rate of that LDS, not HBM, bounds it -- so the
+// batch form builds all LUTs with one launch and then ENQUEUES the per-query scans back to back:
+// no per-query allocation, no per-query synchronisation (fused_topk_batch reads the statuses back
+// once per 32 queries).  Every score and every list is bit-identical to the single-query calls.
+struct qamd_pq_query_batch {
+    int device = 0;
+    uint64_t m = 0, n_queries = 0;
+    DevBuf luts;  // [n_queries][m * 256] f32
+};
+
+extern "C" {
+
+qamd_status qamd_pq_encode_query_batch(const qamd_pq *h, const float *queries, uint64_t n_queries, uint64_t qdim,
+                                       qamd_mem queries_mem, void *stream, qamd_pq_query_batch **batch_io) {
+    if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (n_queries && qdim != h->vp.dim)
+        return fail(QAMD_ERR_ARGUMENTS, "queries have %llu dims, store has %llu", (unsigned long long)qdim,
+                    (unsigned long long)h->vp.dim);
+    if (n_queries > 65535) return fail(QAMD_ERR_ARGUMENTS, "at most 65535 queries per batch");
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    qamd_pq_query_batch *b = *batch_io;
+    std::unique_ptr<qamd_pq_query_batch> fresh;
+    if (!b) {
+        fresh.reset(new qamd_pq_query_batch);
+        b = fresh.get();
+        b->device = h->device;
+    }
+    const size_t per = (size_t)h->m * kCentroids, need = std::max<size_t>(per * n_queries, 4) * sizeof(float);
+    if (b->luts.bytes < need) QAMD_TRY(b->luts.alloc(need));
+    b->m = h->m;
+    b->n_queries = n_queries;
+    if (per && n_queries) {
+        DevBuf qtmp;
+        const void *qd = nullptr;
+        bool staged = false;
+        QAMD_TRY(local_view(queries, queries_mem, n_queries * qdim * 4, qtmp, s, &qd, &staged));
+        hipLaunchKernelGGL(pq_lut_batch_kernel, dim3((uint32_t)((per + kBlock - 1) / kBlock), (uint32_t)n_queries),
+                           dim3(kBlock), 0, s, static_cast<const float *>(qd), (uint32_t)h->vp.dim, (uint32_t)h->chunk_size,
+                           (uint32_t)h->m, h->centroids.as<float>(), h->vp.distance_type, h->vp.invert, b->luts.as<float>());
+        QAMD_HIP(hipGetLastError());
+        if (staged) QAMD_HIP(hipStreamSynchronize(s));  // qtmp is freed on return
+    }
+    if (fresh) *batch_io = fresh.release();
+    return QAMD_OK;
+}
+
+void qamd_pq_query_batch_free(qamd_pq_query_batch *b) { delete b; }
+
+static qamd_status pq_check_batch(const qamd_pq *h, const qamd_pq_query_batch *b) {
+    if (!h || !b) return fail(QAMD_ERR_ARGUMENTS, "null handle or query batch");
+    if (b->m != h->m) return fail(QAMD_ERR_ARGUMENTS, "query LUTs have %llu chunks, store has %llu",
+                                  (unsigned long long)b->m, (unsigned long long)h->m);
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_score_batch(const qamd_pq *h, const qamd_pq_query_batch *b, float *out, qamd_mem out_mem,
+                                void *stream) {
+    QAMD_TRY(pq_check_batch(h, b));
+    if (h->count == 0 || b->n_queries == 0) return QAMD_OK;
+    if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    const size_t per = (size_t)h->m * kCentroids;
+    StreamBuf tmp;
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(tmp.alloc(b->n_queries * h->count * 4, s));
+        out_dev = tmp.as<float>();
+    }
+    for (uint64_t q = 0; q < b->n_queries; q++)
+        QAMD_TRY(scan_launch(h, b->luts.as<float>() + q * per, nullptr, h->count, out_dev + q * h->count, s));
+    if (out_mem == QAMD_MEM_HOST) return copy_out(out, QAMD_MEM_HOST, out_dev, b->n_queries * h->count * 4, s);
+    return QAMD_OK;
+}
+
+qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_batch *b, uint32_t k, int largest,
+                               uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
+    QAMD_TRY(pq_check_batch(h, b));
+    if (k == 0 || b->n_queries == 0) return QAMD_OK;
+    if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
+    QAMD_ON_DEVICE(h->device);
+    const size_t per = (size_t)h->m * kCentroids;
+    const float *luts = b->luts.as<float>();
+    BatchScan scan;
+    scan.filter_capable = fast_capable(h, h->count);
+    scan.scan_scores = [&](uint32_t q, float *scores, hipStream_t st) {
+        return scan_launch(h, luts + q * per, nullptr, h->count, scores, st);
+    };
+    scan.scan_filter = [&](uint32_t q, const TopkFilter &f, hipStream_t st) {
+        return scan_launch(h, luts + q * per, nullptr, h->count, nullptr, st, &f);
+    };
+    scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+        return scan_launch(h, luts + q * per, ids, n_ids, out, st);
+    };
+    return fused_topk_batch(h->count, (uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, as_stream(stream),
+                            scan);
 }
 
 }  // extern "C"

@@ -334,6 +334,18 @@ __global__ void sample_ids_kernel(uint32_t *ids, uint32_t S, uint64_t n) {
 
 }  // namespace
 
+// Sample size S and pivot rank r of the fused path; false = take the classic path.
+static bool fused_policy(uint64_t n, uint32_t k, uint32_t &S, uint32_t &r) {
+    const bool small = n < (1u << 20);
+    const double target = std::max<double>(small ? 512.0 : 2048.0, 3.0 * k);
+    S = (uint32_t)std::min<double>(131072.0, std::max<double>(small ? 2048.0 : (double)kTopkSample,
+                                                              round_up((uint64_t)(8.0 * (double)n / target), 1024)));
+    r = (uint32_t)std::ceil((double)S * target / (double)std::max<uint64_t>(n, 1));
+    // Tiny stores: sampling buys nothing (and r must stay << 1024 for the pivot rule) --
+    // classic path (scores + exact radix select).
+    return n >= 32768 && r <= 64;
+}
+
 qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
                        qamd_mem out_mem, hipStream_t stream, const FusedScan &scan) {
     if (k == 0) return QAMD_OK;
@@ -346,14 +358,8 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
     // Small stores (32k .. 1M rows) take the same route with a smaller sample and fewer expected
     // candidates: there the classic path's chain of ~10 tiny kernels (score array + four radix
     // passes + gather + sort) is what a top-k costs, not HBM.
-    const bool small = n < (1u << 20);
-    const double target = std::max<double>(small ? 512.0 : 2048.0, 3.0 * k);
-    const uint32_t S = (uint32_t)std::min<double>(131072.0, std::max<double>(small ? 2048.0 : (double)kTopkSample,
-                                                                             round_up((uint64_t)(8.0 * (double)n / target), 1024)));
-    const uint32_t r = (uint32_t)std::ceil((double)S * target / (double)n);
-    // Tiny stores: sampling buys nothing (and r must stay << 1024 for the pivot rule) --
-    // classic path (scores + exact radix select).
-    const bool use_fused = n >= 32768 && r <= 64;
+    uint32_t S = 0, r = 0;
+    const bool use_fused = fused_policy(n, k, S, r);
     char *ws = nullptr;
     const size_t off_state = 0, off_cand = round_up(sizeof(FusedState), 256), off_sample = off_cand + (size_t)kTopkShards * kTopkShardCap * 8,
                  off_ids = off_sample + (size_t)S * 4, off_out = off_ids + (size_t)S * 4,
@@ -436,6 +442,81 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
     return st2;
 }
 
+qamd_status fused_topk_batch(uint64_t n, uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                             qamd_mem out_mem, hipStream_t stream, const BatchScan &scan) {
+    if (k == 0 || Q == 0) return QAMD_OK;
+    if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
+    StreamBuf res;  // host outputs: results are assembled on the device, one download at the end
+    uint32_t *ids_dev = out_ids;
+    float *sc_dev = out_scores;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(res.alloc((size_t)Q * k * 8, stream));
+        ids_dev = res.as<uint32_t>();
+        sc_dev = reinterpret_cast<float *>(ids_dev + (size_t)Q * k);
+    }
+    uint32_t S = 0, r = 0;
+    const bool use_fused = scan.filter_capable && fused_policy(n, k, S, r);
+    float *scores = nullptr;  // classic path: one score array, reused query after query in stream order
+    void *sel = nullptr;
+    auto classic = [&](uint32_t q) -> qamd_status {
+        if (!scores) {
+            QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(n, 1) * 4, stream, reinterpret_cast<void **>(&scores)));
+            QAMD_TRY(thread_ws_acquire(WS_SELECT, round_up(topk_workspace_bytes(k), 256), stream, &sel));
+        }
+        QAMD_TRY(scan.scan_scores(q, scores, stream));
+        return topk_f32(scores, n, k, largest != 0, ids_dev + (size_t)q * k, sc_dev + (size_t)q * k, sel, stream);
+    };
+    qamd_status st = QAMD_OK;
+    if (!use_fused) {
+        for (uint32_t q = 0; q < Q && st == QAMD_OK; q++) st = classic(q);
+    } else {
+        constexpr uint32_t kChunk = 32;
+        const size_t off_cand = round_up(sizeof(FusedState), 256), off_sample = off_cand + (size_t)kTopkShards * kTopkShardCap * 8,
+                     per = round_up(off_sample + (size_t)S * 4, 256);
+        const uint32_t C = std::min(Q, kChunk);
+        StreamBuf ws;
+        const size_t off_ids = (size_t)C * per, off_status = off_ids + round_up((size_t)S * 4, 256);
+        QAMD_TRY(ws.alloc(off_status + (size_t)C * 4, stream));
+        char *base = ws.as<char>();
+        uint32_t *sample_ids = reinterpret_cast<uint32_t *>(base + off_ids);
+        uint32_t *status_dev = reinterpret_cast<uint32_t *>(base + off_status);
+        hipLaunchKernelGGL(sample_ids_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, sample_ids, S, n);
+        std::vector<uint32_t> status(C);
+        for (uint32_t q0 = 0; q0 < Q && st == QAMD_OK; q0 += C) {
+            const uint32_t nq = std::min(C, Q - q0);
+            for (uint32_t j = 0; j < nq && st == QAMD_OK; j++) {
+                char *slice = base + (size_t)j * per;
+                FusedState *fs = reinterpret_cast<FusedState *>(slice);
+                unsigned long long *cand = reinterpret_cast<unsigned long long *>(slice + off_cand);
+                float *sample = reinterpret_cast<float *>(slice + off_sample);
+                st = scan.score_ids(q0 + j, sample_ids, S, sample, stream);
+                if (st != QAMD_OK) break;
+                hipLaunchKernelGGL(pivot_kernel, dim3(1), dim3(1024), 0, stream, sample, S, r, largest, fs);
+                TopkFilter f{&fs->pivot_key, fs->counters, cand, largest};
+                st = scan.scan_filter(q0 + j, f, stream);
+                if (st != QAMD_OK) break;
+                hipLaunchKernelGGL(fused_emit_kernel, dim3(1), dim3(1024), 0, stream, cand, fs, n, k, largest,
+                                   ids_dev + (size_t)(q0 + j) * k, sc_dev + (size_t)(q0 + j) * k, status_dev + j);
+            }
+            if (st == QAMD_OK && hipGetLastError() != hipSuccess) st = fail(QAMD_ERR_DEVICE, "batched top-k launch failed");
+            if (st == QAMD_OK) st = copy_out(status.data(), QAMD_MEM_HOST, status_dev, (size_t)nq * 4, stream);  // one sync per chunk
+            for (uint32_t j = 0; j < nq && st == QAMD_OK; j++)
+                if (status[j] != 0) st = classic(q0 + j);  // heavy ties or an unlucky pivot: exact path
+        }
+    }
+    if (scores) {
+        thread_ws_release(WS_SCORES, stream);
+        thread_ws_release(WS_SELECT, stream);
+    }
+    if (st == QAMD_OK && out_mem == QAMD_MEM_HOST) {
+        st = copy_out(out_ids, QAMD_MEM_HOST, ids_dev, (size_t)Q * k * 4, stream);
+        if (st == QAMD_OK) st = copy_out(out_scores, QAMD_MEM_HOST, sc_dev, (size_t)Q * k * 4, stream);
+    } else if (st == QAMD_OK) {
+        if (hipStreamSynchronize(stream) != hipSuccess) st = fail(QAMD_ERR_DEVICE, "batched top-k: synchronisation failed");
+    }
+    return st;
+}
+
 // Workspace + result staging in stream order; host outputs make the call synchronous.
 qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int largest,
                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream) {
@@ -464,6 +545,57 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
         }
     }
     thread_ws_release(WS_SELECT, stream);
+    return st;
+}
+
+// ------------------------------------------------------------------------ single-launch top-k
+bool small_topk_plan(uint64_t n, uint32_t k, uint32_t rows_per_tile, SmallTopkPlan &plan) {
+    if (n == 0 || n > (2u << 20) || k == 0 || k > kSmallTopkMaxK) return false;
+    uint32_t wgs = (uint32_t)device_info().cu_count;  // one 16-wave workgroup per CU
+    wgs = (uint32_t)std::min<uint64_t>(wgs, (n + rows_per_tile - 1) / rows_per_tile);  // at least one tile each
+    const uint32_t per = (uint32_t)round_up((n + wgs - 1) / wgs, rows_per_tile);
+    wgs = (uint32_t)((n + per - 1) / per);  // drop workgroups that would own no row
+    plan.workgroups = wgs;
+    plan.rows_per_wg = per;
+    return true;
+}
+
+qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                       qamd_mem out_mem, hipStream_t stream,
+                       const std::function<qamd_status(const SmallTopk &, hipStream_t)> &launch) {
+    // workspace: ticket (own 256-byte line) | per-workgroup bests | staging for host outputs without scratch
+    const size_t off_best = 256, off_out = off_best + round_up((size_t)plan.workgroups * k * 8, 256),
+                 bytes = off_out + (size_t)k * 8;
+    char *ws = nullptr;
+    uint64_t *tags = nullptr;
+    QAMD_TRY(thread_ws_acquire(WS_SMALL, bytes, stream, reinterpret_cast<void **>(&ws), &tags));
+    qamd_status st = QAMD_OK;
+    if (tags[0] != 0x5154u) {  // fresh (re)allocation: the ticket starts at zero, the last arriver keeps it there
+        if (hipMemsetAsync(ws, 0, 256, stream) != hipSuccess) st = fail(QAMD_ERR_DEVICE, "top-k: ticket reset failed");
+        tags[0] = 0x5154u;
+    }
+    const HostScratch hs = out_mem == QAMD_MEM_HOST ? host_scratch() : HostScratch{};
+    SmallTopk p;
+    p.ticket = reinterpret_cast<uint32_t *>(ws);
+    p.wg_best = reinterpret_cast<unsigned long long *>(ws + off_best);
+    p.k = k;
+    p.largest = largest;
+    p.out_ids = out_mem == QAMD_MEM_DEVICE ? out_ids : hs.host ? hs.dev : reinterpret_cast<uint32_t *>(ws + off_out);
+    p.out_scores = out_mem == QAMD_MEM_DEVICE ? out_scores
+                   : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
+                                           : reinterpret_cast<float *>(ws + off_out) + k;
+    if (st == QAMD_OK) st = launch(p, stream);
+    if (st == QAMD_OK && out_mem == QAMD_MEM_HOST) {
+        if (hs.host) {
+            if (hipStreamSynchronize(stream) != hipSuccess) st = fail(QAMD_ERR_DEVICE, "top-k: stream synchronisation failed");
+            memcpy(out_ids, hs.host, (size_t)k * 4);
+            memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
+        } else {
+            st = copy_out(out_ids, QAMD_MEM_HOST, p.out_ids, (size_t)k * 4, stream);
+            if (st == QAMD_OK) st = copy_out(out_scores, QAMD_MEM_HOST, p.out_scores, (size_t)k * 4, stream);
+        }
+    }
+    thread_ws_release(WS_SMALL, stream);
     return st;
 }
 

@@ -42,4 +42,32 @@ struct FusedScan {
 qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
                        qamd_mem out_mem, hipStream_t stream, const FusedScan &scan);
 
+// Batched form of fused_topk for quantizers whose scan serves one query at a time (PQ: the LDS holds
+// one LUT; binary): the Q per-query pipelines (sample -> pivot -> filtering scan -> sort) are all
+// ENQUEUED back to back on per-query workspace slices, statuses are read back once per chunk of 32
+// queries, and only the queries whose candidate list over/underflowed are redone by the exact
+// classic path.  Results [Q][k]; ordering contract as fused_topk.
+struct BatchScan {
+    std::function<qamd_status(uint32_t q, const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t)> score_ids;
+    std::function<qamd_status(uint32_t q, const TopkFilter &, hipStream_t)> scan_filter;
+    std::function<qamd_status(uint32_t q, float *scores_dev, hipStream_t)> scan_scores;
+    bool filter_capable = true;  // false: no FILTER-mode scan for this store -> classic path for every query
+};
+qamd_status fused_topk_batch(uint64_t n, uint32_t n_queries, uint32_t k, int largest, uint32_t *out_ids,
+                             float *out_scores, qamd_mem out_mem, hipStream_t stream, const BatchScan &scan);
+
+// Single-launch top-k for small stores (count <= 2M rows, k <= 64): one kernel scans the rows,
+// every wave keeps its own best 64 in registers (wave-level bitonic merges, topk_device.hpp), the
+// workgroup folds its 16 waves and the last workgroup to finish folds the workgroups' lists and
+// writes the result -- no score array, no sample pass, no status read-back.  With device outputs
+// the call only ENQUEUES.
+struct SmallTopk;
+struct SmallTopkPlan {
+    uint32_t workgroups = 0, rows_per_wg = 0;
+};
+bool small_topk_plan(uint64_t n, uint32_t k, uint32_t rows_per_tile, SmallTopkPlan &plan);
+qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                       qamd_mem out_mem, hipStream_t stream,
+                       const std::function<qamd_status(const SmallTopk &, hipStream_t)> &launch);
+
 }  // namespace qamd

@@ -196,6 +196,75 @@ __global__ __launch_bounds__(kScanBlock) void u8_scan_kernel(
     }
 }
 
+// Single-launch top-k for small stores (topk.hpp small_topk): workgroup b scores rows
+// [b * rows_per_wg, (b + 1) * rows_per_wg) exactly like u8_scan_kernel (same loads, same integer
+// sum, same f32 epilogue => the same score bits), but a score never goes to HBM: it becomes a
+// 64-bit key (order-preserving score bits << 32 | row) in the wave's LDS staging row, and the wave /
+// workgroup / last-arriver merges of topk_device.hpp keep the best k.  100k x 768: one launch
+// replaces the sample / pivot / filtering-scan / sort chain (66 us).
+template <int G, int ITERS, bool IS_L1, bool EXACT>
+__global__ __launch_bounds__(1024) void u8_topk_small_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint4 *__restrict__ qcodes,
+    const float *__restrict__ q_off_p, float multiplier, uint32_t n_rows, uint32_t row_chunks, uint32_t rows_per_wg,
+    SmallTopk p) {
+    __shared__ unsigned long long lds[2 * kSmallTopkWaves][64];  // [0, 16): tournament lists, [16, 32): staging rows
+    unsigned long long(*lists)[64] = lds;
+    constexpr int RW = 64 / G;
+    constexpr int UNROLL = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G, rslot = lane / G;
+    unsigned long long *stage = lds[kSmallTopkWaves + wave];
+    uint4 q[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t c = sub + it * G;
+        const uint4 t = qcodes[(EXACT || c < row_chunks) ? c : row_chunks - 1];
+        const bool in = EXACT || c < row_chunks;
+        q[it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+    }
+    const float q_off = *q_off_p;
+    const uint64_t wg_base = (uint64_t)blockIdx.x * rows_per_wg;
+    SmallTopkWave acc_list;
+    for (uint32_t tile = wave * UNROLL; tile * RW < rows_per_wg; tile += kSmallTopkWaves * UNROLL) {
+        uint4 v[UNROLL][ITERS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            // rows past the workgroup's range or the store still load from a valid address
+            const uint64_t row = wg_base + (uint64_t)(tile + u) * RW + rslot;
+            const uint64_t rc = row < n_rows ? row : (uint64_t)n_rows - 1;
+            const uint4 *src = codes + rc * row_chunks;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t c = sub + it * G;
+                const uint4 t = ld_nt(src + ((EXACT || c < row_chunks) ? c : row_chunks - 1));
+                const bool in = EXACT || c < row_chunks;
+                v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t local = (tile + u) * RW + rslot;
+            const uint64_t row = wg_base + local;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) acc = IS_L1 ? sad16(v[u][it], q[it], acc) : dot16(v[u][it], q[it], acc);
+            acc = group_sum<G>(acc);
+            if (sub == 0) {
+                unsigned long long key = ~0ull;
+                if (local < rows_per_wg && row < n_rows) {
+                    const float sc = epilogue(multiplier, acc, q_off, offsets[row], 0.0f, EPI_POINT);
+                    key = ((unsigned long long)topk_ordered_bits(sc, p.largest != 0) << 32) | (uint32_t)row;
+                }
+                stage[acc_list.fill + rslot] = key;
+            }
+            acc_list.fill += RW;
+            if (acc_list.fill == 64) small_topk_flush(acc_list, stage, lane);
+        }
+    }
+    if (acc_list.fill) small_topk_flush(acc_list, stage, lane);
+    small_topk_finish(acc_list.best, lists, p);
+}
+
 // Generic dims (row_chunks > 16*8): runtime chunk loop, query re-read through L1/L2.
 template <bool IS_L1>
 __global__ __launch_bounds__(kBlock) void u8_scan_generic_kernel(
@@ -779,6 +848,49 @@ void launch_scan_generic(const qamd_u8 *h, const uint4 *qc, const float *qo, flo
                        (uint32_t)h->count, h->row_chunks, out);
 }
 
+template <bool IS_L1> struct SmallLaunch {
+    template <int G, int ITERS>
+    static qamd_status go(const qamd_u8 *h, const uint4 *qc, const float *qo, const SmallTopkPlan &pl, const SmallTopk &p,
+                          hipStream_t s) {
+        const bool exact = h->row_chunks == (uint32_t)(G * ITERS);
+#define QAMD_U8_SMALL(EX)                                                                                       \
+    hipLaunchKernelGGL((u8_topk_small_kernel<G, ITERS, IS_L1, EX>), dim3(pl.workgroups), dim3(1024), 0, s,       \
+                       h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier, (uint32_t)h->count, \
+                       h->row_chunks, pl.rows_per_wg, p)
+        if (exact) QAMD_U8_SMALL(true);
+        else QAMD_U8_SMALL(false);
+#undef QAMD_U8_SMALL
+        QAMD_HIP(hipGetLastError());
+        return QAMD_OK;
+    }
+};
+
+// Row group of the small top-k kernel for this store's row size; 0 = no templated shape.
+int small_group(uint32_t rc) { return rc == 1 ? 1 : rc == 2 ? 2 : rc <= 4 ? 4 : rc <= 8 ? 8 : rc <= 128 ? 16 : 0; }
+
+template <bool IS_L1>
+qamd_status launch_small(const qamd_u8 *h, const uint4 *qc, const float *qo, const SmallTopkPlan &pl, const SmallTopk &p,
+                         hipStream_t s) {
+    using L = SmallLaunch<IS_L1>;
+    const uint32_t rc = h->row_chunks;
+    if (rc == 1) return L::template go<1, 1>(h, qc, qo, pl, p, s);
+    if (rc == 2) return L::template go<2, 1>(h, qc, qo, pl, p, s);
+    if (rc <= 4) return L::template go<4, 1>(h, qc, qo, pl, p, s);
+    if (rc <= 8) return L::template go<8, 1>(h, qc, qo, pl, p, s);
+    switch ((rc + 15) / 16) {
+        case 1: return L::template go<16, 1>(h, qc, qo, pl, p, s);
+        case 2: return L::template go<16, 2>(h, qc, qo, pl, p, s);
+        case 3: return L::template go<16, 3>(h, qc, qo, pl, p, s);
+        case 4: return L::template go<16, 4>(h, qc, qo, pl, p, s);
+        case 5: return L::template go<16, 5>(h, qc, qo, pl, p, s);
+        case 6: return L::template go<16, 6>(h, qc, qo, pl, p, s);
+        case 7: return L::template go<16, 7>(h, qc, qo, pl, p, s);
+        case 8: return L::template go<16, 8>(h, qc, qo, pl, p, s);
+        default: break;
+    }
+    return fail(QAMD_ERR_ARGUMENTS, "no small top-k kernel for %u chunks", rc);
+}
+
 bool fused_capable(const qamd_u8 *h) {
     const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
     return (is_l1 || h->lane_mode == 0) && h->row_chunks <= 128;
@@ -1271,7 +1383,9 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
         q->device = h->device;
     }
     if (q->actual_dim != ad || !q->buf.ptr) {
-        QAMD_TRY(q->buf.alloc(16 + round_up(ad, 16) + ad * 4 + 16, true));  // offset | codes | f32 staging
+        if (q->pooled) query_buf_put(q->buf, q->ready);
+        QAMD_TRY(query_buf_get(16 + round_up(ad, 16) + ad * 4 + 16, q->buf, q->ready));  // offset | codes | f32 staging
+        q->pooled = true;
         q->actual_dim = ad;
     }
     const qamd_vector_parameters &vp = h->meta.vector_parameters;
@@ -1279,14 +1393,26 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
     // product): a host query is uploaded first (qdim * 4 bytes; the buffer keeps room for it
     // behind the codes).
     const float *q_dev = query;
+    bool via_scratch = false;
     if (query_mem == QAMD_MEM_HOST && qdim) {
-        float *stage = reinterpret_cast<float *>(q->buf.as<uint8_t>() + 16 + round_up(ad, 16));
-        QAMD_TRY(copy_in(stage, query, QAMD_MEM_HOST, qdim * 4, s));
-        q_dev = stage;
+        // through the thread's mapped host scratch when it fits: one memcpy on the host, the kernel
+        // reads the values over PCIe itself -- no copy call, no synchronisation (106 -> ~45 us for
+        // encode_query(host) + topk on a 100k-row store)
+        const float *dev_view = nullptr;
+        if (float *hq = host_query_acquire(qdim, &dev_view)) {
+            memcpy(hq, query, qdim * 4);
+            q_dev = dev_view;
+            via_scratch = true;
+        } else {
+            float *stage = reinterpret_cast<float *>(q->buf.as<uint8_t>() + 16 + round_up(ad, 16));
+            QAMD_TRY(copy_in(stage, query, QAMD_MEM_HOST, qdim * 4, s));
+            q_dev = stage;
+        }
     }
     hipLaunchKernelGGL(encode_query_kernel, dim3(1), dim3(64), 0, s, q_dev, (uint32_t)qdim, (uint32_t)ad,
                        h->meta.alpha, h->meta.offset, vp.distance_type, vp.invert, q->buf.as<uint8_t>());
     QAMD_HIP(hipGetLastError());
+    if (via_scratch) host_query_release(s);
     QAMD_TRY(q->ready.record(s));
     if (fresh) *query_io = fresh.release();
     return QAMD_OK;
@@ -1417,6 +1543,18 @@ qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, i
     scan.score_ids = [&](const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
         return score_ids_dev(h, qc, q->buf.as<float>(), 0.0f, EPI_POINT, ids, n_ids, out, st);
     };
+    {   // small stores: one launch, no status read-back (device outputs only enqueue)
+        const int g = small_group(h->row_chunks);
+        SmallTopkPlan plan;
+        if (g && fused_capable(h) && small_topk_plan(h->count, k, 2 * (64 / g), plan)) {
+            const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+            return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s,
+                              [&](const SmallTopk &p, hipStream_t st) {
+                                  return is_l1 ? launch_small<true>(h, qc, q->buf.as<float>(), plan, p, st)
+                                               : launch_small<false>(h, qc, q->buf.as<float>(), plan, p, st);
+                              });
+        }
+    }
     if (!fused_capable(h)) {  // rare layouts: classic path only
         float *scores = nullptr;
         QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));

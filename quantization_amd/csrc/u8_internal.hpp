@@ -19,6 +19,10 @@ struct qamd_u8_query {
     uint64_t actual_dim = 0;
     qamd::DevBuf buf;  // [0..4) offset f32, [16..16+actual_dim) codes
     qamd::ReadyEvent ready;  // the last encode_query (stream order for consumers on other streams)
+    bool pooled = false;     // buf came from / goes back to the query buffer cache
+    ~qamd_u8_query() {
+        if (pooled) qamd::query_buf_put(buf, ready);
+    }
 };
 
 // Pass-1 pieces used by the sharded encoder; defined in u8.hip.

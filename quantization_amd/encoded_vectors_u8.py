@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._base import EncodedQueryBase, EncodedVectorsBase
+from ._base import EncodedQueryBase, EncodedQueryBatch, EncodedVectorsBase
 from .encoded_vectors import (DistanceType, EncodingError, VectorParameters, check, check_same_device,
                               creating_on, flatten_rows, get_device, in_buf, make_stop, out_buf, stream_ptr,
                               validate)
@@ -40,25 +40,16 @@ class EncodedQueryU8(EncodedQueryBase):
         return codes
 
 
-class EncodedQueryBatchU8:
+class EncodedQueryBatchU8(EncodedQueryBatch):
     """n encoded queries (n x EncodedQueryU8) resident in HBM, for the multi-query MFMA path."""
 
-    def __init__(self, handle: C.c_void_p, n_queries: int):
-        self._h = handle
-        self.n_queries = n_queries
-
-    def __del__(self):
-        if getattr(self, "_h", None):
-            try:
-                _lib.lib().qamd_u8_query_batch_free(self._h)
-            except Exception:
-                pass
-            self._h = None
+    _prefix = "u8"
 
 
 class EncodedVectorsU8(EncodedVectorsBase):
     _prefix = "u8"
     _query_cls = EncodedQueryU8
+    _batch_cls = EncodedQueryBatchU8
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -185,41 +176,8 @@ class EncodedVectorsU8(EncodedVectorsBase):
         """0: integer sum rounded once (default); 1: avx2.c 8-lane f32 summation order."""
         check(_lib.lib().qamd_u8_set_lane_mode(self._h, mode))
 
-    # ------------------------------------------------------------------ multi-query (MFMA) path
-    def encode_query_batch(self, queries, reuse: EncodedQueryBatchU8 | None = None, stream=None) -> EncodedQueryBatchU8:
-        """encode_query for a [n_queries, dim] block of queries (ann_benchmark.rs:245-260's outer loop)."""
-        nq, qdim = int(queries.shape[0]), int(queries.shape[1])
-        check_same_device(self._device, queries)
-        buf = in_buf(queries, np.float32)
-        h = reuse._h if reuse is not None else C.c_void_p()
-        check(_lib.lib().qamd_u8_encode_query_batch(self._h, buf.ptr, nq, qdim, buf.mem, stream_ptr(stream), C.byref(h)))
-        if reuse is not None:
-            reuse.n_queries = nq
-            return reuse
-        return EncodedQueryBatchU8(h, nq)
-
-    def score_batch(self, batch: EncodedQueryBatchU8, out=None, stream=None):
-        """scores[q, i] = score_point(query q, i) — bit-identical to score_all per query."""
-        n = self.count
-        check_same_device(self._device, out)
-        buf, ret = out_buf(out, batch.n_queries * n, np.float32)
-        check(_lib.lib().qamd_u8_score_batch(self._h, batch._h, buf.ptr, buf.mem, stream_ptr(stream)))
-        return ret.reshape(batch.n_queries, n) if isinstance(ret, np.ndarray) else ret
-
-    def topk_batch(self, batch: EncodedQueryBatchU8, k: int, largest: bool = True, out_ids=None, out_scores=None,
-                   stream=None):
-        """Per-query best-k (ann_benchmark_data.rs:151-167), [n_queries, k] ids and scores."""
-        nq = batch.n_queries
-        check_same_device(self._device, out_ids, out_scores)
-        ib, ids = out_buf(out_ids, nq * k, np.uint32)
-        sb, sc = out_buf(out_scores, nq * k, np.float32)
-        if ib.mem != sb.mem:
-            raise ValueError("out_ids and out_scores must both be host or both be device buffers")
-        check(_lib.lib().qamd_u8_topk_batch(self._h, batch._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem,
-                                            stream_ptr(stream)))
-        if isinstance(ids, np.ndarray):
-            return ids.reshape(nq, k), sc.reshape(nq, k)
-        return ids, sc
+    # multi-query (MFMA) path: encode_query_batch / score_batch / topk_batch come from EncodedVectorsBase
+    # (on the GPU: a dense u8 x u8 -> i32 contraction on the matrix cores, csrc/u8_batch.hip).
 
     # queries and scores: encode_query / score_point / score_internal / score_all /
     # score_ids / topk come from EncodedVectorsBase.

@@ -1,0 +1,87 @@
+"""Batched (many queries at once) entry points of the PQ and binary quantizers — BASELINE config 4's
+PQ leg and config 3's shape: every score and every top-k list must be bit-identical to looping the
+single-query call (which is itself oracle-checked), and spot-checked against the oracle directly."""
+import numpy as np
+import pytest
+
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+qa = pytest.importorskip("quantization_amd")
+torch = pytest.importorskip("torch")
+D = qa.DistanceType
+
+
+@pytest.mark.parametrize("n,m_dim", [(120_000, (96, 8)), (3000, (70, 4))])
+def test_pq_batch_equals_single_query_loop(n, m_dim, qo):
+    dim, chunk = m_dim[0] * m_dim[1], m_dim[1]
+    rng = np.random.default_rng(n)
+    cen = rng.random((256, dim), dtype=np.float32)
+    m = qa.EncodedVectorsPQ.get_quantized_vector_size(qa.VectorParameters(dim, n, D.Dot, False), chunk)
+    rows = rng.integers(0, 256, (n, m), dtype=np.uint8)
+    enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, D.Dot, False), chunk, cen)
+    Q = 37
+    queries = rng.random((Q, dim), dtype=np.float32)
+    batch = enc.encode_query_batch(queries)
+    sb = enc.score_batch(batch)
+    ids, sc = enc.topk_batch(batch, 30)
+    ids_s, sc_s = enc.topk_batch(batch, 17, largest=False)
+    for qi in range(Q):
+        q = enc.encode_query(queries[qi])
+        assert_bits_equal(sb[qi], enc.score_all(q), f"score_batch query {qi}")
+        wi, ws = enc.topk(q, 30)
+        assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), qi
+        wi, ws = enc.topk(q, 17, largest=False)
+        assert np.array_equal(ids_s[qi], wi) and np.array_equal(sc_s[qi].view(np.uint32), ws.view(np.uint32)), qi
+    lut = qo.pq_encode_query(queries[5], chunk, cen, qo.DOT, False)
+    assert_bits_equal(sb[5][:4000], qo.pq_score_all(rows[:4000], lut, order=qo.ORDER_SSE), "vs oracle")
+    # device in / device out
+    dq = torch.from_numpy(queries).cuda()
+    b2 = enc.encode_query_batch(dq, reuse=batch)
+    d_ids = torch.empty(Q * 30, dtype=torch.int32, device="cuda")
+    d_sc = torch.empty(Q * 30, dtype=torch.float32, device="cuda")
+    enc.topk_batch(b2, 30, out_ids=d_ids, out_scores=d_sc)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ids.cpu().numpy().view(np.uint32).reshape(Q, 30), ids)
+
+
+@pytest.mark.parametrize("dim,n", [(1024, 200_000), (2048, 60_000), (4096, 40_000), (8192, 20_000), (256, 50_000), (65, 5000)])
+def test_binary_batch_equals_single_query_loop(dim, n, qo):
+    rng = np.random.default_rng(dim)
+    data = np.where(rng.random((n, dim)) < 0.5, -1.0, 1.0).astype(np.float32)
+    enc = qa.EncodedVectorsBin.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    Q = 23  # 8 + 8 + 4 + 2 + 1: every multi-query step size
+    queries = np.where(rng.random((Q, dim)) < 0.5, -1.0, 1.0).astype(np.float32)
+    batch = enc.encode_query_batch(queries)
+    sb = enc.score_batch(batch)
+    assert np.array_equal(sb, (queries @ data.T).astype(np.float32)), "binary Dot on +-1 data is the exact f32 dot"
+    ids, sc = enc.topk_batch(batch, 30)
+    for qi in (0, 7, 8, 15, 19, 21, 22):
+        q = enc.encode_query(queries[qi])
+        assert np.array_equal(sb[qi], enc.score_all(q))
+        wi, ws = enc.topk(q, 30)
+        assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi], ws), qi
+    rows = qo.bin_encode(data[:3000])
+    want = qo.bin_score_all(rows, qo.bin_encode(queries[3:4])[0], dim, qo.DOT, False)
+    assert np.array_equal(sb[3][:3000], want)
+    out = torch.empty(Q * n, dtype=torch.float32, device="cuda")
+    enc.score_batch(batch, out=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(Q, n), sb)
+
+
+def test_batch_edge_cases():
+    rng = np.random.default_rng(1)
+    dim = 64
+    data = rng.standard_normal((10, dim)).astype(np.float32)
+    enc = qa.EncodedVectorsBin.encode(data, qa.VectorParameters(dim, 10, D.L2, False))
+    b = enc.encode_query_batch(data[:3])
+    ids, sc = enc.topk_batch(b, 12, largest=False)
+    assert ids.shape == (3, 12) and np.all(ids[:, 10:] == 0xFFFFFFFF) and ids[0, 0] == 0 and ids[2, 0] == 2
+    cen = rng.random((256, dim), dtype=np.float32)
+    penc = qa.EncodedVectorsPQ.encode(data, qa.VectorParameters(dim, 10, D.Dot, False), 8, centroids=cen)
+    pb = penc.encode_query_batch(data[:2])
+    assert penc.score_batch(pb).shape == (2, 10)
+    with pytest.raises(qa.EncodingError):
+        penc.encode_query_batch(rng.random((2, dim + 1), dtype=np.float32))
