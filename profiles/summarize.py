@@ -4,7 +4,8 @@ profiles/.  Kernel names are shortened (torch's are kilobytes long).
 
     python profiles/summarize.py stats <kernel_stats.csv> <out.csv>
     python profiles/summarize.py pmc   <fetch_counter_collection.csv> <write_counter_collection.csv> \
-                                       <kernel-substring> <rows_per_launch> <row_read_bytes> <out.json>
+                                       <kernel-substring> <rows_per_launch> <row_read_bytes> <out.json> [commit]
+(profiles/collect.sh runs both on the GPU box.)
 
 PMC correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so
@@ -20,6 +21,13 @@ def short(name: str, n: int = 110) -> str:
     return name if len(name) <= n else name[:n] + "..."
 
 
+def kernel_source_hash() -> str:
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return hashlib.sha256(open(os.path.join(root, "quantization_amd", "csrc", "u8.hip"), "rb").read()).hexdigest()[:16]
+
+
 def stats(src, dst):
     rows = list(csv.DictReader(open(src)))
     with open(dst, "w", newline="") as f:
@@ -30,7 +38,7 @@ def stats(src, dst):
                         r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 
-def pmc(fetch_csv, write_csv, needle, rows_per_launch, row_read_bytes, dst):
+def pmc(fetch_csv, write_csv, needle, rows_per_launch, row_read_bytes, dst, commit="unknown"):
     def collect(path, counter):
         vals, durs = [], []
         for r in csv.DictReader(open(path)):
@@ -56,6 +64,9 @@ def pmc(fetch_csv, write_csv, needle, rows_per_launch, row_read_bytes, dst):
         "algorithmic_write_bytes_per_launch": rows_per_launch * 4,
         "traffic_over_algorithmic": (read_bytes + write_bytes) / (rows_per_launch * (row_read_bytes + 4)),
         "mean_kernel_ns_in_fetch_pass": sum(fd) / len(fd),
+        # bench.py quotes this file as roofline.traffic only while the kernel source is the one profiled
+        "commit": commit,
+        "kernel_source_sha256_16": kernel_source_hash(),
     }
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
@@ -65,4 +76,5 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7],
+            sys.argv[8] if len(sys.argv) > 8 else "unknown")

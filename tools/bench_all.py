@@ -153,3 +153,57 @@ if "batch" in which:
                   flush=True)
         del enc
         pass  # no empty_cache: returning tens of GB to the driver starts a VRAM scrub that slows (up to 4x) whatever runs next
+
+if "binbatch" in which:
+    # several queries per row read: where does the binary scan stop being HBM-bound?
+    for dim, n in ((1024, 50_000_000), (2048, 20_000_000)):
+        vp = qa.VectorParameters(dim, n, D.Dot, False)
+        nb = qa.EncodedVectorsBin.get_quantized_vector_size_from_params(vp)
+        rows = torch.randint(0, 256, (n, nb), device=dev, dtype=torch.uint8)
+        enc = qa.EncodedVectorsBin.from_storage(rows, vp)
+        del rows
+        for nq in (1, 2, 4, 8, 16):
+            batch = enc.encode_query_batch(torch.randn((nq, dim), device=dev))
+            out = torch.empty(nq * n, dtype=torch.float32, device=dev)
+            med, mn = timeit(lambda: enc.score_batch(batch, out=out), reps=10)
+            print(json.dumps({"kernel": f"bin_score_batch dim{dim}", "rows": n, "queries": nq, "median_ms": round(med, 4),
+                              "min_ms": round(mn, 4), "G_pairs_per_s": round(nq * n / med / 1e6, 2),
+                              "hbm_GBps_algorithmic": round(n * (nb * ((nq + 7) // 8 if nq > 1 else 1) + 4 * nq) / med / 1e6, 1),
+                              "vs_single_query_loop": round(nq * 1.0, 2)}), flush=True)
+            del out
+        batch = enc.encode_query_batch(torch.randn((64, dim), device=dev))
+        ids = torch.empty(64 * 30, dtype=torch.int32, device=dev)
+        sc = torch.empty(64 * 30, dtype=torch.float32, device=dev)
+        med, mn = timeit(lambda: enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc), reps=5, warm=2)
+        q1 = enc.encode_query(torch.randn(dim, device=dev))
+        i1 = torch.empty(30, dtype=torch.int32, device=dev)
+        s1 = torch.empty(30, dtype=torch.float32, device=dev)
+        med1, _ = timeit(lambda: enc.topk(q1, 30, out_ids=i1, out_scores=s1), reps=10)
+        print(json.dumps({"kernel": f"bin_topk_batch k30 dim{dim}", "rows": n, "queries": 64, "median_ms": round(med, 3),
+                          "ms_per_query": round(med / 64, 4), "single_query_topk_ms": round(med1, 4)}), flush=True)
+        del enc
+
+if "pqbatch" in which:
+    for dim, chunk, n in ((768, 8, 10_000_000), (1536, 8, 12_500_000)):
+        vp = qa.VectorParameters(dim, n, D.Dot, False)
+        m = qa.EncodedVectorsPQ.get_quantized_vector_size(vp, chunk)
+        rows = torch.randint(0, 256, (n, m), device=dev, dtype=torch.uint8)
+        cen = np.random.default_rng(0).random((256, dim), dtype=np.float32)
+        enc = qa.EncodedVectorsPQ.from_storage(rows, vp, chunk, cen)
+        del rows
+        q1 = enc.encode_query(torch.rand(dim, device=dev))
+        i1 = torch.empty(30, dtype=torch.int32, device=dev)
+        s1 = torch.empty(30, dtype=torch.float32, device=dev)
+        med1, _ = timeit(lambda: enc.topk(q1, 30, out_ids=i1, out_scores=s1), reps=10)
+        for nq in (16, 64, 256):
+            queries = torch.rand((nq, dim), device=dev)
+            med_e, _ = timeit(lambda: enc.encode_query_batch(queries), reps=5)
+            batch = enc.encode_query_batch(queries)
+            ids = torch.empty(nq * 30, dtype=torch.int32, device=dev)
+            sc = torch.empty(nq * 30, dtype=torch.float32, device=dev)
+            med, mn = timeit(lambda: enc.topk_batch(batch, 30, out_ids=ids, out_scores=sc), reps=5, warm=2)
+            print(json.dumps({"kernel": f"pq_topk_batch k30 dim{dim} m{m}", "rows": n, "queries": nq,
+                              "median_ms": round(med, 3), "ms_per_query": round(med / nq, 4),
+                              "single_query_topk_ms": round(med1, 4), "encode_query_batch_ms": round(med_e, 4),
+                              "G_pairs_per_s": round(nq * n / med / 1e6, 2)}), flush=True)
+        del enc
