@@ -105,7 +105,7 @@ void DevBuf::release() {
 
 namespace {
 struct QueryBufCache {
-    struct Entry { void *ptr; size_t bytes; int dev; hipEvent_t ev; bool pending; };
+    struct Entry { void *ptr; size_t bytes; int dev; };
     std::mutex m;
     std::vector<Entry> free_list;
 };
@@ -116,57 +116,39 @@ QueryBufCache &query_cache() {
 constexpr size_t kQueryCacheEntries = 64;
 }  // namespace
 
-qamd_status query_buf_get(size_t bytes, DevBuf &out, ReadyEvent &ev) {
+qamd_status query_buf_get(size_t bytes, DevBuf &out) {
     out.release();
     int dev = 0;
     QAMD_HIP(hipGetDevice(&dev));
-    QueryBufCache::Entry hit{nullptr, 0, 0, nullptr, false};
     {
         QueryBufCache &c = query_cache();
         std::lock_guard<std::mutex> lk(c.m);
         for (size_t i = 0; i < c.free_list.size(); i++) {
             if (c.free_list[i].dev == dev && c.free_list[i].bytes == bytes) {
-                hit = c.free_list[i];
+                out.ptr = c.free_list[i].ptr;
+                out.bytes = bytes;
                 c.free_list[i] = c.free_list.back();
                 c.free_list.pop_back();
-                break;
+                return QAMD_OK;
             }
         }
     }
-    if (!hit.ptr) return out.alloc(bytes, true);
-    if (hit.pending && hit.ev) (void)hipEventSynchronize(hit.ev);  // the previous owner's last work (normally long done)
-    out.ptr = hit.ptr;
-    out.bytes = bytes;
-    if (hit.ev) {
-        if (ev.ev) (void)hipEventDestroy(ev.ev);
-        ev.ev = hit.ev;
-        ev.set = false;
-    }
-    return QAMD_OK;
+    return out.alloc(bytes, true);
 }
 
-void query_buf_put(DevBuf &buf, ReadyEvent &ev) {
+void query_buf_put(DevBuf &buf, bool idle) {
     if (!buf.ptr) return;
     hipPointerAttribute_t attr{};
-    if (hipPointerGetAttributes(&attr, buf.ptr) == hipSuccess) {
-        bool pending = false;
-        if (ev.set && ev.ev) pending = hipEventRecord(ev.ev, ev.stream) == hipSuccess;
-        if (ev.set && !pending) {  // cannot order the next owner after this one: do not recycle
-            (void)hipGetLastError();
-            buf.release();
-            return;
-        }
+    if (idle && hipPointerGetAttributes(&attr, buf.ptr) == hipSuccess) {
         QueryBufCache &c = query_cache();
         std::lock_guard<std::mutex> lk(c.m);
         if (c.free_list.size() < kQueryCacheEntries) {
-            c.free_list.push_back({buf.ptr, buf.bytes, attr.device, ev.ev, pending});
+            c.free_list.push_back({buf.ptr, buf.bytes, attr.device});
             buf.ptr = nullptr;
             buf.bytes = 0;
-            ev.ev = nullptr;
-            ev.set = false;
             return;
         }
-    } else {
+    } else if (idle) {
         (void)hipGetLastError();
     }
     buf.release();
@@ -209,6 +191,13 @@ qamd_status ReadyEvent::record(hipStream_t s) {
     stream = s;
     set = true;
     return QAMD_OK;
+}
+
+bool ReadyEvent::complete() const {
+    if (!set || !ev) return true;
+    if (hipEventQuery(ev) == hipSuccess) return true;
+    (void)hipGetLastError();  // hipErrorNotReady
+    return false;
 }
 
 qamd_status ReadyEvent::wait(hipStream_t consumer) const {

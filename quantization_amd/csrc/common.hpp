@@ -93,15 +93,13 @@ struct DevBuf {
 // Recycles the small device buffers behind encoded-query objects.  The reference's encode_query
 // returns a fresh EncodedQuery value per call (encoded_vectors.rs:27); a binding that mirrors that
 // creates and drops one query object per search, and a hipMalloc + hipFree pair costs more than a
-// 100k-row scan.  Freed buffers are kept (per device and size, a few dozen at most) and handed out
-// again; contents are NOT cleared -- every encode_query overwrites what its consumers read.
-// A buffer is parked together with its query's event, re-recorded at that moment on the stream of
-// the last encode (so it covers every consumer enqueued there); the next owner waits on it first.
-// (A query used on OTHER streams than its encode stream must not be freed while those calls are
-// in flight -- the usual rule for asynchronous work.)
-struct ReadyEvent;
-qamd_status query_buf_get(size_t bytes, DevBuf &out, ReadyEvent &ev);
-void query_buf_put(DevBuf &buf, ReadyEvent &ev);
+// 100k-row scan.  A freed buffer is kept (per device and size, a few dozen at most) ONLY when it is
+// provably idle -- its last encode has completed and every consumer call was synchronous (host
+// outputs) -- so recycling never touches a stream (which the caller may have destroyed by then);
+// any other buffer is released with hipFree, which waits for the device.  Contents are not cleared:
+// every encode_query overwrites what its consumers read.
+qamd_status query_buf_get(size_t bytes, DevBuf &out);
+void query_buf_put(DevBuf &buf, bool idle);
 
 inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
@@ -137,6 +135,7 @@ struct ReadyEvent {
     ~ReadyEvent();
     qamd_status record(hipStream_t s);
     qamd_status wait(hipStream_t consumer) const;
+    bool complete() const;  // true when nothing was recorded or the recorded work has finished
 };
 
 // Copy helpers: `mem` describes the caller side.

@@ -1383,8 +1383,8 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
         q->device = h->device;
     }
     if (q->actual_dim != ad || !q->buf.ptr) {
-        if (q->pooled) query_buf_put(q->buf, q->ready);
-        QAMD_TRY(query_buf_get(16 + round_up(ad, 16) + ad * 4 + 16, q->buf, q->ready));  // offset | codes | f32 staging
+        if (q->pooled) query_buf_put(q->buf, false);
+        QAMD_TRY(query_buf_get(16 + round_up(ad, 16) + ad * 4 + 16, q->buf));  // offset | codes | f32 staging
         q->pooled = true;
         q->actual_dim = ad;
     }
@@ -1442,7 +1442,10 @@ qamd_status qamd_u8_score_all(const qamd_u8 *h, const qamd_u8_query *q, float *o
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
-    if (out_mem == QAMD_MEM_DEVICE) return scan_into(h, q, out, s);
+    if (out_mem == QAMD_MEM_DEVICE) {
+        q->async_used.store(true, std::memory_order_relaxed);
+        return scan_into(h, q, out, s);
+    }
     float *tmp = nullptr;  // per-thread workspace: no hipMalloc / hipFree per query
     QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * sizeof(float), s, reinterpret_cast<void **>(&tmp)));
     qamd_status st = scan_into(h, q, tmp, s);
@@ -1459,6 +1462,7 @@ qamd_status qamd_u8_score_ids(const qamd_u8 *h, const qamd_u8_query *q, const ui
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
+    if (out_mem == QAMD_MEM_DEVICE) q->async_used.store(true, std::memory_order_relaxed);
     DevBuf ids_tmp, out_tmp;
     const uint32_t *ids_dev = ids;
     // per-pair granularity (score_point and friends): ids and results through the calling
@@ -1536,6 +1540,7 @@ qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, i
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
+    if (out_mem == QAMD_MEM_DEVICE) q->async_used.store(true, std::memory_order_relaxed);
     const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
     FusedScan scan;
     scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_into(h, q, scores, st); };

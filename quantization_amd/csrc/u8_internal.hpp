@@ -20,8 +20,9 @@ struct qamd_u8_query {
     qamd::DevBuf buf;  // [0..4) offset f32, [16..16+actual_dim) codes
     qamd::ReadyEvent ready;  // the last encode_query (stream order for consumers on other streams)
     bool pooled = false;     // buf came from / goes back to the query buffer cache
+    mutable std::atomic<bool> async_used{false};  // a consumer call only ENQUEUED (device outputs)
     ~qamd_u8_query() {
-        if (pooled) qamd::query_buf_put(buf, ready);
+        if (pooled) qamd::query_buf_put(buf, !async_used.load(std::memory_order_relaxed) && ready.complete());
     }
 };
 

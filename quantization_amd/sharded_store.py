@@ -29,8 +29,9 @@ def _devices(devices):
 
 
 class _ShardedQuery:
-    def __init__(self, handle, free):
+    def __init__(self, handle, free, owner=None):
         self._h, self._free = handle, free
+        self._owner = owner  # the per-shard query objects live on the store's devices: free them first
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -84,7 +85,7 @@ class _ShardedBase:
         n = int(np.prod(tuple(query.shape))) if hasattr(query, "shape") else len(query)
         h = reuse._h if reuse is not None else C.c_void_p()
         check(self._fn("encode_query")(self._h, buf.ptr, n, buf.mem, C.byref(h)))
-        return reuse if reuse is not None else _ShardedQuery(h, self._fn("query_free"))
+        return reuse if reuse is not None else _ShardedQuery(h, self._fn("query_free"), self)
 
     def score_all(self, query, out=None):
         """scores[i] = score_point(query, i) over the GLOBAL row ids — each shard writes its slice."""
@@ -162,7 +163,7 @@ class ShardedVectorsU8(_ShardedBase):
         if reuse is not None:
             reuse.n_queries = nq
             return reuse
-        b = _ShardedQuery(h, _lib.lib().qamd_u8_sharded_query_batch_free)
+        b = _ShardedQuery(h, _lib.lib().qamd_u8_sharded_query_batch_free, self)
         b.n_queries = nq
         return b
 
