@@ -193,6 +193,72 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_multi_kernel(const uint4 
     }
 }
 
+// Single-launch top-k for small stores (topk.hpp small_topk; the scalar-u8 twin in u8.hip explains
+// the structure): workgroup b scores rows [b * rows_per_wg, (b + 1) * rows_per_wg) with
+// bin_scan_kernel's arithmetic; scores become 64-bit keys in the wave's LDS staging row and the
+// wave / workgroup / last-arriver merges of topk_device.hpp keep the best k.  Exact under any
+// number of ties (keys are distinct: score bits << 32 | row), which the sampled-pivot path is not
+// good at for binary scores (few distinct values -> candidate lists overflow -> classic fallback).
+template <int G, int ITERS, bool EXACT>
+__global__ __launch_bounds__(1024) void bin_topk_small_kernel(const uint4 *__restrict__ rows,
+                                                              const uint4 *__restrict__ qbits, float dim_f, int is_dot,
+                                                              int invert, uint32_t n_rows, uint32_t row_chunks,
+                                                              uint32_t rows_per_wg, SmallTopk p) {
+    __shared__ unsigned long long lds[2 * kSmallTopkWaves][64];
+    unsigned long long(*lists)[64] = lds;
+    constexpr int RW = 64 / G;
+    constexpr int UNROLL = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G, rslot = lane / G;
+    unsigned long long *stage = lds[kSmallTopkWaves + wave];
+    uint4 q[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t c = sub + it * G;
+        const bool in = EXACT || c < row_chunks;
+        const uint4 t = qbits[in ? c : row_chunks - 1];
+        q[it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+    }
+    const uint64_t wg_base = (uint64_t)blockIdx.x * rows_per_wg;
+    SmallTopkWave acc_list;
+    for (uint32_t tile = wave * UNROLL; tile * RW < rows_per_wg; tile += kSmallTopkWaves * UNROLL) {
+        uint4 v[UNROLL][ITERS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint64_t row = wg_base + (uint64_t)(tile + u) * RW + rslot;
+            const uint64_t rc = row < n_rows ? row : (uint64_t)n_rows - 1;
+            const uint4 *src = rows + rc * row_chunks;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t c = sub + it * G;
+                const bool in = EXACT || c < row_chunks;
+                const uint4 t = ld_nt(src + (in ? c : row_chunks - 1));
+                v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t local = (tile + u) * RW + rslot;
+            const uint64_t row = wg_base + local;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) acc = xpop16(v[u][it], q[it], acc);
+            acc = group_sum<G>(acc);
+            if (sub == 0) {
+                unsigned long long key = ~0ull;
+                if (local < rows_per_wg && row < n_rows)
+                    key = ((unsigned long long)topk_ordered_bits(metric(acc, dim_f, is_dot, invert), p.largest != 0) << 32) |
+                          (uint32_t)row;
+                stage[acc_list.fill + rslot] = key;
+            }
+            acc_list.fill += RW;
+            if (acc_list.fill == 64) small_topk_flush(acc_list, stage, lane);
+        }
+    }
+    if (acc_list.fill) small_topk_flush(acc_list, stage, lane);
+    small_topk_finish(acc_list.best, lists, p);
+}
+
 // Any row size, dword granularity: used for tiny rows (ds 4 or 8), very long rows and the
 // random-access entry points.  ids == nullptr scans rows [0, n).
 __global__ __launch_bounds__(kBlock) void bin_words_kernel(const uint32_t *__restrict__ rows,
@@ -383,6 +449,35 @@ qamd_status scan_bits(const qamd_bin *h, const void *qbits_dev, float *out_dev, 
 qamd_status scan_into(const qamd_bin *h, const qamd_bin_query *q, float *out_dev, hipStream_t s,
                       const TopkFilter *filt = nullptr) {
     return scan_bits(h, q->buf.ptr, out_dev, s, filt);
+}
+
+template <int G, int ITERS>
+qamd_status launch_bin_small(const qamd_bin *h, const uint4 *qb, const SmallTopkPlan &pl, const SmallTopk &p, hipStream_t s) {
+    const uint32_t rc = (uint32_t)(h->ds / 16);
+    const bool exact = rc == (uint32_t)(G * ITERS);
+#define QAMD_BIN_SMALL(EX)                                                                                         \
+    hipLaunchKernelGGL((bin_topk_small_kernel<G, ITERS, EX>), dim3(pl.workgroups), dim3(1024), 0, s, h->rows.as<uint4>(), \
+                       qb, (float)h->vp.dim, (int)(h->vp.distance_type == QAMD_DOT), h->vp.invert, (uint32_t)h->count, rc, \
+                       pl.rows_per_wg, p)
+    if (exact) QAMD_BIN_SMALL(true);
+    else QAMD_BIN_SMALL(false);
+#undef QAMD_BIN_SMALL
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+int bin_small_group(uint32_t rc) { return rc == 1 ? 1 : rc == 2 ? 2 : rc <= 4 ? 4 : rc <= 8 ? 8 : rc <= 64 ? 16 : 0; }
+
+qamd_status launch_small(const qamd_bin *h, const uint4 *qb, const SmallTopkPlan &pl, const SmallTopk &p, hipStream_t s) {
+    const uint32_t rc = (uint32_t)(h->ds / 16);
+    if (rc == 1) return launch_bin_small<1, 1>(h, qb, pl, p, s);
+    if (rc == 2) return launch_bin_small<2, 1>(h, qb, pl, p, s);
+    if (rc <= 4) return launch_bin_small<4, 1>(h, qb, pl, p, s);
+    if (rc <= 8) return launch_bin_small<8, 1>(h, qb, pl, p, s);
+    if (rc <= 16) return launch_bin_small<16, 1>(h, qb, pl, p, s);
+    if (rc <= 32) return launch_bin_small<16, 2>(h, qb, pl, p, s);
+    if (rc <= 48) return launch_bin_small<16, 3>(h, qb, pl, p, s);
+    return launch_bin_small<16, 4>(h, qb, pl, p, s);
 }
 
 qamd_status check_query(const qamd_bin *h, const qamd_bin_query *q) {
@@ -683,6 +778,14 @@ qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
+    {   // small stores: one launch, exact under any number of ties, no status read-back
+        const int g = bin_small_group((uint32_t)(h->ds / 16));
+        SmallTopkPlan plan;
+        if (g && fused_capable(h) && small_topk_plan(h->count, k, 2 * (64 / g), plan))
+            return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t st) {
+                return launch_small(h, q->buf.as<uint4>(), plan, p, st);
+            });
+    }
     if (!fused_capable(h)) {
         float *scores = nullptr;
         QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));

@@ -257,8 +257,8 @@ constexpr int kMaxDevices = 64;
 struct ThreadWs {
     void *ptr = nullptr;
     size_t bytes = 0;
-    hipEvent_t done = nullptr;
-    bool pending = false;
+    hipStream_t last_stream = nullptr;  // stream of the last call that used the buffer
+    bool in_flight = false;             // that call only enqueued (no synchronisation since)
     uint64_t tags[3] = {0, 0, 0};
 };
 
@@ -284,13 +284,11 @@ struct ThreadState {
         bool moved = false;
         for (size_t i = 0; i < ws.size(); i++) {
             ThreadWs &w = ws[i];
-            if (!w.ptr && !w.done) continue;
+            if (!w.ptr) continue;
             const int dev = (int)(i / WS_SLOTS);
             if (hipSetDevice(dev) == hipSuccess) {
                 moved = true;
-                if (w.pending && w.done) (void)hipEventSynchronize(w.done);
-                if (w.ptr) (void)hipFree(w.ptr);
-                if (w.done) (void)hipEventDestroy(w.done);
+                (void)hipFree(w.ptr);  // waits for the device: nothing of ours can still be using it
             }
             w = ThreadWs{};
         }
@@ -355,6 +353,10 @@ void host_query_release(hipStream_t s) {
     if (ts.query_read && hipEventRecord(ts.query_read, s) == hipSuccess) ts.query_pending = true;
 }
 
+// Hand-off between consecutive calls of one thread: work on ONE stream is ordered by the stream
+// itself (the common case: nothing to do, which also keeps these calls capturable into a hipGraph);
+// a thread that moves to another stream while its previous call may still be running waits for
+// the device once.  No events: nothing is ever recorded on a stream the caller might have destroyed.
 qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out, uint64_t **tags) {
     int dev = 0;
     QAMD_HIP(hipGetDevice(&dev));
@@ -363,19 +365,20 @@ qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, vo
     if (bytes == 0) bytes = 16;
     if (w.bytes < bytes) {
         if (w.ptr) {
-            if (w.pending) (void)hipEventSynchronize(w.done);
-            (void)hipFree(w.ptr);
+            (void)hipFree(w.ptr);  // synchronises with whatever still uses it
             w.ptr = nullptr;
         }
         w.bytes = 0;
-        w.pending = false;
+        w.in_flight = false;
         w.tags[0] = w.tags[1] = w.tags[2] = 0;
         const size_t want = bytes + bytes / 4;  // head room: stores grow, k varies
         QAMD_HIP(hipMalloc(&w.ptr, want));
         w.bytes = want;
-        if (!w.done) QAMD_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     }
-    if (w.pending) QAMD_HIP(hipStreamWaitEvent(s, w.done, 0));
+    if (w.in_flight && w.last_stream != s) {
+        QAMD_HIP(hipDeviceSynchronize());
+        w.in_flight = false;
+    }
     *out = w.ptr;
     if (tags) *tags = w.tags;
     return QAMD_OK;
@@ -385,7 +388,8 @@ void thread_ws_release(ThreadWsSlot slot, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return;
     ThreadWs &w = thread_state().at(dev, slot);
-    if (w.ptr && w.done && hipEventRecord(w.done, s) == hipSuccess) w.pending = true;
+    w.last_stream = s;
+    w.in_flight = true;
 }
 
 void thread_release_all() { thread_state().release(); }

@@ -163,9 +163,9 @@ HostScratch host_scratch();
 float *host_query_acquire(size_t n_floats, const float **dev_view);
 void host_query_release(hipStream_t s);
 
-// Grow-only device workspaces per calling thread AND device, handed from call to call in
-// stream order: release() records an event on the call's stream, the next acquire() makes its own
-// stream wait on it.  For the whole-store calls' scratch (score vector of a top-k, radix-select
+// Grow-only device workspaces per calling thread AND device, handed from call to call: calls on
+// one stream are ordered by the stream; acquire() on ANOTHER stream than the last release() waits
+// for the device once (rare).  For the whole-store calls' scratch (score vector of a top-k, radix-select
 // state, PQ partial sums): hipMallocAsync + hipFreeAsync cost ~70 us per buffer and call on this
 // runtime, which is most of a top-k on a small store.  A thread that alternates between stores
 // on several GPUs keeps one workspace per (slot, device).  Freed by qamd_thread_release() or when

@@ -113,6 +113,74 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_kernel(const uint32_t *__r
     }
 }
 
+// Single-launch top-k for small stores (topk.hpp small_topk; structure: u8_topk_small_kernel).  The
+// LUT is staged in dynamic LDS once per workgroup, four adjacent lanes own a row and lane k is the
+// reference's SSE lane k exactly as in pq_scan_kernel (same summation order => same score bits);
+// lane 0 of a row turns the score into a key in the wave's staging row (16 rows per step).
+template <bool VEC16>
+__global__ __launch_bounds__(1024) void pq_topk_small_kernel(const uint32_t *__restrict__ rows32,
+                                                             const float *__restrict__ lut_g, uint32_t n_rows, uint32_t m,
+                                                             uint32_t row_words, uint32_t rows_per_wg, SmallTopk p) {
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];  // m * 256 f32
+    __shared__ unsigned long long lds[2 * kSmallTopkWaves][64];
+    unsigned long long(*lists)[64] = lds;
+    {
+        const uint32_t total4 = m * (kCentroids / 4);
+        const float4 *src = reinterpret_cast<const float4 *>(lut_g);
+        float4 *dst = reinterpret_cast<float4 *>(lut_s);
+        for (uint32_t i = threadIdx.x; i < total4; i += 1024) dst[i] = src[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane & 3, rslot = lane >> 2;
+    unsigned long long *stage = lds[kSmallTopkWaves + wave];
+    const uint32_t groups = m / 4;
+    const float *lut_k = lut_s + k * kCentroids;
+    const uint32_t shift = 8 * k;
+    const uint64_t wg_base = (uint64_t)blockIdx.x * rows_per_wg;
+    SmallTopkWave acc_list;
+    for (uint32_t step = wave; step * 16 < rows_per_wg; step += kSmallTopkWaves) {
+        const uint32_t local = step * 16 + rslot;
+        const uint64_t row = wg_base + local;
+        const bool ok = local < rows_per_wg && row < n_rows;
+        const uint32_t *pr = rows32 + (ok ? row : 0) * row_words;
+        float acc = 0.0f;
+        uint32_t t = 0;
+        if (VEC16) {
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(pr);
+            for (; t + 4 <= groups; t += 4) {
+                const uint4 w = ld_nt(p4 + (t >> 2));
+                const float *l = lut_k + (size_t)t * 4 * kCentroids;
+                acc += l[(w.x >> shift) & 255u];
+                acc += l[4 * kCentroids + ((w.y >> shift) & 255u)];
+                acc += l[8 * kCentroids + ((w.z >> shift) & 255u)];
+                acc += l[12 * kCentroids + ((w.w >> shift) & 255u)];
+            }
+        }
+        for (; t < groups; t++) {
+            const uint32_t w = pr[t];
+            acc += lut_k[(size_t)t * 4 * kCentroids + ((w >> shift) & 255u)];
+        }
+        const float a = acc + __shfl_xor(acc, 2, 64);  // (l0 + l2) + (l1 + l3)  (:430-432)
+        float sc = a + __shfl_xor(a, 1, 64);
+        if (k == 0) {
+            unsigned long long key = ~0ull;
+            if (ok) {
+                for (uint32_t c = groups * 4; c < m; c++) {  // tail (:434-438)
+                    const uint32_t code = (pr[c >> 2] >> (8 * (c & 3))) & 255u;
+                    sc += lut_s[(size_t)c * kCentroids + code];
+                }
+                key = ((unsigned long long)topk_ordered_bits(sc, p.largest != 0) << 32) | (uint32_t)row;
+            }
+            stage[acc_list.fill + rslot] = key;
+        }
+        acc_list.fill += 16;
+        if (acc_list.fill == 64) small_topk_flush(acc_list, stage, lane);
+    }
+    if (acc_list.fill) small_topk_flush(acc_list, stage, lane);
+    small_topk_finish(acc_list.best, lists, p);
+}
+
 // Fast path for the whole-store scan: m % 16 == 0 (rows are NV = m/16 aligned 16-byte pieces,
 // NV <= 8) and the LUT fits in LDS.  Differences to pq_scan_kernel, all measured to matter
 // (the first version was latency-bound at one 16-byte load in flight per lane):
@@ -1218,6 +1286,32 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
     const float *lut = q->lut.as<float>();
+    {   // small stores: one launch (LUT + the merge lists fit the LDS up to m = 128)
+        SmallTopkPlan plan;
+        const size_t lut_bytes = (size_t)h->m * kCentroids * sizeof(float);
+        if (h->m >= 1 && lut_bytes <= 128 * 1024 && small_topk_plan(h->count, k, 16, plan)) {
+            static std::atomic<uint64_t> set_on{0};
+            if (first_use_on_device(set_on)) {
+                QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            }
+            const uint32_t row_words = (uint32_t)(h->ds / 4);
+            return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t st) {
+                if (row_words % 4 == 0)
+                    hipLaunchKernelGGL(pq_topk_small_kernel<true>, dim3(plan.workgroups), dim3(1024), lut_bytes, st,
+                                       h->rows.as<uint32_t>(), lut, (uint32_t)h->count, (uint32_t)h->m, row_words,
+                                       plan.rows_per_wg, p);
+                else
+                    hipLaunchKernelGGL(pq_topk_small_kernel<false>, dim3(plan.workgroups), dim3(1024), lut_bytes, st,
+                                       h->rows.as<uint32_t>(), lut, (uint32_t)h->count, (uint32_t)h->m, row_words,
+                                       plan.rows_per_wg, p);
+                QAMD_HIP(hipGetLastError());
+                return QAMD_OK;
+            });
+        }
+    }
     if (!fast_capable(h, h->count)) {
         float *scores = nullptr;
         QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));

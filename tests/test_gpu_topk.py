@@ -110,3 +110,62 @@ def test_fused_topk_pq_and_sorted_adversarial_order():
         ids, sc = e2.topk(q2, 50, largest=largest)
         wi, ws = _expect(s2, 50, largest)
         assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
+
+@pytest.mark.parametrize("n", [1, 7, 63, 64, 65, 1000, 33_333, 300_001])
+def test_small_store_single_launch_topk_all_quantizers(n, qo):
+    """The single-launch path (count <= 2M, k <= 64): u8 Dot/L1, binary (massive ties) and PQ, every k
+    class, both directions, against a full stable sort of score_all."""
+    rng = np.random.default_rng(n)
+    dim = 96
+    data = rng.random((n, dim), dtype=np.float32)
+    stores = [
+        qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False)),
+        qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L1, True)),
+        qa.EncodedVectorsBin.encode(data - 0.5, qa.VectorParameters(dim, n, D.Dot, False)),
+        qa.EncodedVectorsPQ.encode(data, qa.VectorParameters(dim, n, D.L2, False), 8,
+                                   centroids=rng.random((256, dim), dtype=np.float32)),
+        qa.EncodedVectorsPQ.encode(data[:, :70].copy(), qa.VectorParameters(70, n, D.Dot, False), 4,  # m = 18: tail chunks
+                                   centroids=rng.random((256, 70), dtype=np.float32)),
+    ]
+    for enc in stores:
+        qdim = enc.vector_parameters.dim
+        q = enc.encode_query(rng.random(qdim, dtype=np.float32) - (0.5 if isinstance(enc, qa.EncodedVectorsBin) else 0.0))
+        scores = enc.score_all(q)
+        for k, largest in ((1, True), (30, True), (30, False), (64, True), (5, False)):
+            ids, sc = enc.topk(q, k, largest=largest)
+            wi, ws = _expect(scores, k, largest)
+            m = min(k, n)
+            assert np.array_equal(ids[:m], wi[:m]), (type(enc).__name__, n, k, largest)
+            assert np.array_equal(sc[:m].view(np.uint32), ws[:m].view(np.uint32))
+            assert np.all(ids[m:] == 0xFFFFFFFF)
+
+
+def test_small_store_topk_is_capturable_with_device_outputs():
+    """No status read-back on the single-launch path: with device outputs the call only enqueues, so
+    encode_query + topk replay from a hipGraph."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(4)
+    n, dim = 50_000, 128
+    data = rng.random((n, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    qbuf = torch.from_numpy(rng.random(dim, dtype=np.float32)).cuda()
+    d_ids = torch.empty(30, dtype=torch.int32, device="cuda")
+    d_sc = torch.empty(30, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        qobj = enc.encode_query(qbuf)
+        enc.topk(qobj, 30, out_ids=d_ids, out_scores=d_sc)  # warm-up: workspace allocation happens here
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            enc.encode_query(qbuf, reuse=qobj)
+            enc.topk(qobj, 30, out_ids=d_ids, out_scores=d_sc)
+    for trial in range(3):
+        query = rng.random(dim, dtype=np.float32)
+        qbuf.copy_(torch.from_numpy(query))
+        g.replay()
+        torch.cuda.synchronize()
+        wi, ws = enc.topk(enc.encode_query(query), 30)
+        assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), wi), trial
+        assert np.array_equal(d_sc.cpu().numpy().view(np.uint32), ws.view(np.uint32))
