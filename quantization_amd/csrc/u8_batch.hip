@@ -1142,7 +1142,8 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
             QAMD_TRY(copy_out(&overflow, QAMD_MEM_HOST, overflow_dev, 4, s));
             if (overflow) std::fill(status.begin(), status.end(), 1u);  // a wave list overflowed: redo all exactly
         }
-        if (getenv("QAMD_DEBUG_TOPK")) {
+        static const bool debug_topk = getenv("QAMD_DEBUG_TOPK") != nullptr;
+        if (debug_topk) {
             std::vector<uint32_t> cnt(b->q_pad * kCounterStride);
             (void)hipMemcpy(cnt.data(), counters, cnt.size() * 4, hipMemcpyDeviceToHost);
             uint32_t mx = 0, mn = ~0u, redo = 0;

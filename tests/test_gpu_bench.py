@@ -71,6 +71,20 @@ def test_bench_two_ranks_one_gpu_gloo_rehearsal(exchange, scaling):
     assert "cpu_baseline" not in j
 
 
+def test_bench_four_ranks_strong_scaling_grouped_rotating_gather():
+    """Four ranks on one GPU over gloo: the strong-scaling default (store fixed, 4 ragged shards), gathers in
+    groups of 4 queries with a rotating root, a step count that leaves a partly filled last group."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+           "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "10",
+           "--warmup", "3", "--rows", "400003", "--backend", "gloo", "--all-ranks-on-device", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["n_gpus"] == 4 and j["scaling"] == "strong" and j["config"]["total_rows"] == 400003
+    assert j["config"]["rows_per_gpu"] == 100000 and j["config"]["gather_group"] == 4
+    assert j["value"] > 0 and j["roofline"]["rows_per_launch"] == 100000
+
+
 @pytest.mark.parametrize("ranks", [1, 2])
 def test_bench_batched_topk_mode(ranks):
     """The opt-in config-4 shape: many queries per step on the matrix cores, sharded rows, one
