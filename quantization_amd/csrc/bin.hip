@@ -138,13 +138,15 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_kernel(const uint4 *__res
 // from ds + 4 to ds / NQ + 4 and the scan turns from HBM-bound into popcount-bound.
 // Lane (row slot, sub = j) keeps query j's score of the row: one store instruction per row slot
 // writes NQ segments of 64/G consecutive floats.  G >= NQ.
-template <int G, int ITERS, int UNROLL, int NQ, bool EXACT>
+// FILTER: no score is written; lane (row slot, sub = j) offers its row to query j's candidate lists
+// (fused top-k of NQ queries in one pass: qamd_bin_topk_batch).
+template <int G, int ITERS, int UNROLL, int NQ, bool EXACT, bool FILTER>
 __global__ __launch_bounds__(kScanBlock) void bin_scan_multi_kernel(const uint4 *__restrict__ rows,
                                                                    const uint4 *__restrict__ qbits /* [NQ][q_stride] */,
                                                                    uint32_t q_stride, float dim_f, int is_dot, int invert,
                                                                    uint32_t n_rows, uint32_t row_chunks,
                                                                    float *__restrict__ out /* [NQ][out_pitch] */,
-                                                                   uint64_t out_pitch) {
+                                                                   uint64_t out_pitch, TopkFilterSlices slices) {
     static_assert(G >= NQ, "one lane of the row group per query");
     constexpr int RW = 64 / G;
     constexpr int TILE = RW * UNROLL;
@@ -189,7 +191,14 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_multi_kernel(const uint4 
             if (sub == j) mine = metric(acc, dim_f, is_dot, invert);
         }
         const uint64_t row = base + (uint64_t)u * RW + rslot;
-        if (sub < NQ && row < n_rows) __builtin_nontemporal_store(mine, out + (uint64_t)sub * out_pitch + row);
+        if (sub < NQ && row < n_rows) {
+            if (FILTER) {
+                const TopkFilter f = topk_filter_of(slices, (uint32_t)sub);
+                topk_offer(f, *f.pivot_key, mine, (uint32_t)row);  // the pivot is an L2-resident word, re-read per row slot
+            } else {
+                __builtin_nontemporal_store(mine, out + (uint64_t)sub * out_pitch + row);
+            }
+        }
     }
 }
 
@@ -822,30 +831,37 @@ struct qamd_bin_query_batch {
 namespace {
 
 template <int G, int ITERS, int UNROLL, int NQ>
-void launch_bin_multi(const qamd_bin *h, const uint8_t *qbits, uint64_t q_stride, float *out, hipStream_t s) {
+void launch_bin_multi(const qamd_bin *h, const uint8_t *qbits, uint64_t q_stride, float *out, hipStream_t s,
+                      const TopkFilterSlices *slices = nullptr) {
     constexpr int TILE = (64 / G) * UNROLL;
     const uint32_t rc = (uint32_t)(h->ds / 16);
     const uint64_t waves = (h->count + TILE - 1) / TILE;
     const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
     const bool exact = rc == (uint32_t)(G * ITERS);
-#define QAMD_BIN_MULTI(EX)                                                                                        \
-    hipLaunchKernelGGL((bin_scan_multi_kernel<G, ITERS, UNROLL, NQ, EX>), dim3(grid), dim3(kScanBlock), 0, s,     \
+#define QAMD_BIN_MULTI(EX, FI)                                                                                    \
+    hipLaunchKernelGGL((bin_scan_multi_kernel<G, ITERS, UNROLL, NQ, EX, FI>), dim3(grid), dim3(kScanBlock), 0, s, \
                        h->rows.as<uint4>(), reinterpret_cast<const uint4 *>(qbits), (uint32_t)(q_stride / 16),    \
                        (float)h->vp.dim, (int)(h->vp.distance_type == QAMD_DOT), h->vp.invert, (uint32_t)h->count, \
-                       rc, out, (uint64_t)h->count)
-    if (exact) QAMD_BIN_MULTI(true);
-    else QAMD_BIN_MULTI(false);
+                       rc, out, (uint64_t)h->count, slices ? *slices : TopkFilterSlices{})
+    if (slices) {
+        if (exact) QAMD_BIN_MULTI(true, true);
+        else QAMD_BIN_MULTI(false, true);
+    } else {
+        if (exact) QAMD_BIN_MULTI(true, false);
+        else QAMD_BIN_MULTI(false, false);
+    }
 #undef QAMD_BIN_MULTI
 }
 
 // Queries [q0, q0 + nq) with nq in {8, 4, 2}: rows of 8 .. 64 pieces (dims 1024 .. 8192 at the u128 granule).
-template <int NQ> bool multi_step(const qamd_bin *h, const uint8_t *qbits, uint64_t q_stride, float *out, hipStream_t s) {
+template <int NQ> bool multi_step(const qamd_bin *h, const uint8_t *qbits, uint64_t q_stride, float *out, hipStream_t s,
+                                  const TopkFilterSlices *slices = nullptr) {
     const uint32_t rc = (uint32_t)(h->ds / 16);
     if (rc < 8 || rc > 64 || h->ds % 16) return false;
-    if (rc == 8) launch_bin_multi<8, 1, 8, NQ>(h, qbits, q_stride, out, s);
-    else if (rc <= 16) launch_bin_multi<16, 1, 4, NQ>(h, qbits, q_stride, out, s);
-    else if (rc <= 32) launch_bin_multi<16, 2, 2, NQ>(h, qbits, q_stride, out, s);
-    else if (NQ <= 4) launch_bin_multi<16, 4, 2, NQ>(h, qbits, q_stride, out, s);
+    if (rc == 8) launch_bin_multi<8, 1, 8, NQ>(h, qbits, q_stride, out, s, slices);
+    else if (rc <= 16) launch_bin_multi<16, 1, 4, NQ>(h, qbits, q_stride, out, s, slices);
+    else if (rc <= 32) launch_bin_multi<16, 2, 2, NQ>(h, qbits, q_stride, out, s, slices);
+    else if (NQ <= 4) launch_bin_multi<16, 4, 2, NQ>(h, qbits, q_stride, out, s, slices);
     else return false;
     return true;
 }
@@ -951,6 +967,16 @@ qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b
     };
     scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
         return words_launch(h, reinterpret_cast<const uint32_t *>(bits + q * qs), ids, n_ids, out, st);
+    };
+    // up to 8 queries share one pass over the rows (the filtering form of bin_scan_multi_kernel)
+    scan.scan_filter_multi = [&](uint32_t q, uint32_t left, const TopkFilterSlices &sl, hipStream_t st, qamd_status &status) -> uint32_t {
+        const uint8_t *qb = bits + (uint64_t)q * qs;
+        uint32_t took = 0;
+        if (left >= 8 && multi_step<8>(h, qb, qs, nullptr, st, &sl)) took = 8;
+        else if (left >= 4 && multi_step<4>(h, qb, qs, nullptr, st, &sl)) took = 4;
+        else if (left >= 2 && multi_step<2>(h, qb, qs, nullptr, st, &sl)) took = 2;
+        if (took && hipGetLastError() != hipSuccess) status = fail(QAMD_ERR_DEVICE, "binary multi-query filter launch failed");
+        return took;
     };
     return fused_topk_batch(h->count, (uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, as_stream(stream),
                             scan);

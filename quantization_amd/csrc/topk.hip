@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 
 namespace qamd {
@@ -484,17 +485,38 @@ qamd_status fused_topk_batch(uint64_t n, uint32_t Q, uint32_t k, int largest, ui
         std::vector<uint32_t> status(C);
         for (uint32_t q0 = 0; q0 < Q && st == QAMD_OK; q0 += C) {
             const uint32_t nq = std::min(C, Q - q0);
+            // 1. every query of the chunk: sample scores -> pivot
             for (uint32_t j = 0; j < nq && st == QAMD_OK; j++) {
                 char *slice = base + (size_t)j * per;
                 FusedState *fs = reinterpret_cast<FusedState *>(slice);
-                unsigned long long *cand = reinterpret_cast<unsigned long long *>(slice + off_cand);
                 float *sample = reinterpret_cast<float *>(slice + off_sample);
                 st = scan.score_ids(q0 + j, sample_ids, S, sample, stream);
                 if (st != QAMD_OK) break;
                 hipLaunchKernelGGL(pivot_kernel, dim3(1), dim3(1024), 0, stream, sample, S, r, largest, fs);
-                TopkFilter f{&fs->pivot_key, fs->counters, cand, largest};
-                st = scan.scan_filter(q0 + j, f, stream);
-                if (st != QAMD_OK) break;
+            }
+            // 2. filtering scans: several queries per pass over the rows where the quantizer can
+            for (uint32_t j = 0; j < nq && st == QAMD_OK;) {
+                char *slice = base + (size_t)j * per;
+                uint32_t took = 0;
+                if (scan.scan_filter_multi) {
+                    TopkFilterSlices sl{slice, per, offsetof(FusedState, pivot_key), offsetof(FusedState, counters), off_cand,
+                                        largest};
+                    took = scan.scan_filter_multi(q0 + j, nq - j, sl, stream, st);
+                    if (st != QAMD_OK) break;
+                }
+                if (took == 0) {
+                    FusedState *fs = reinterpret_cast<FusedState *>(slice);
+                    TopkFilter f{&fs->pivot_key, fs->counters, reinterpret_cast<unsigned long long *>(slice + off_cand), largest};
+                    st = scan.scan_filter(q0 + j, f, stream);
+                    took = 1;
+                }
+                j += took;
+            }
+            // 3. per query: sort the candidates, emit, report
+            for (uint32_t j = 0; j < nq && st == QAMD_OK; j++) {
+                char *slice = base + (size_t)j * per;
+                FusedState *fs = reinterpret_cast<FusedState *>(slice);
+                unsigned long long *cand = reinterpret_cast<unsigned long long *>(slice + off_cand);
                 hipLaunchKernelGGL(fused_emit_kernel, dim3(1), dim3(1024), 0, stream, cand, fs, n, k, largest,
                                    ids_dev + (size_t)(q0 + j) * k, sc_dev + (size_t)(q0 + j) * k, status_dev + j);
             }

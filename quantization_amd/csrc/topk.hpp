@@ -34,6 +34,7 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
 // read-back makes this call synchronise `stream`.
 constexpr uint32_t kTopkSample = 16384;
 struct TopkFilter;
+struct TopkFilterSlices;
 struct FusedScan {
     std::function<qamd_status(const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t)> score_ids;
     std::function<qamd_status(const TopkFilter &, hipStream_t)> scan_filter;
@@ -52,6 +53,10 @@ struct BatchScan {
     std::function<qamd_status(uint32_t q, const TopkFilter &, hipStream_t)> scan_filter;
     std::function<qamd_status(uint32_t q, float *scores_dev, hipStream_t)> scan_scores;
     bool filter_capable = true;  // false: no FILTER-mode scan for this store -> classic path for every query
+    // optional: ONE filtering scan for `nq` consecutive queries (their slices start at `slices.base`);
+    // returns how many queries it took (8, 4, 2) or 0 when it has no kernel for this store / count
+    std::function<uint32_t(uint32_t q0, uint32_t nq, const TopkFilterSlices &slices, hipStream_t, qamd_status &st)>
+        scan_filter_multi;
 };
 qamd_status fused_topk_batch(uint64_t n, uint32_t n_queries, uint32_t k, int largest, uint32_t *out_ids,
                              float *out_scores, qamd_mem out_mem, hipStream_t stream, const BatchScan &scan);

@@ -25,6 +25,22 @@ struct TopkFilter {
     int largest;
 };
 
+// FILTER mode for several queries in one scan (binary: bin_scan_multi_kernel): query j's pivot,
+// shard counters and candidate slots sit in slice j of one workspace, `stride` bytes apart.
+struct TopkFilterSlices {
+    char *base;           // slice of the first query
+    size_t stride;        // bytes between two queries' slices
+    size_t off_pivot;     // u32 pivot key inside a slice
+    size_t off_counters;  // kTopkShards counters, kTopkCounterStride apart
+    size_t off_cand;      // kTopkShards * kTopkShardCap candidate slots
+    int largest;
+};
+__device__ __forceinline__ TopkFilter topk_filter_of(const TopkFilterSlices &s, uint32_t j) {
+    char *sl = s.base + (size_t)j * s.stride;
+    return TopkFilter{reinterpret_cast<const uint32_t *>(sl + s.off_pivot), reinterpret_cast<uint32_t *>(sl + s.off_counters),
+                      reinterpret_cast<unsigned long long *>(sl + s.off_cand), s.largest};
+}
+
 // Ascending total order on f32 bit patterns; `largest` flips it so that "best" == smallest key.
 __device__ __forceinline__ uint32_t topk_ordered_bits(float f, bool largest) {
     uint32_t u = __float_as_uint(f);
