@@ -896,11 +896,11 @@ bool fused_capable(const qamd_u8 *h) {
     return (is_l1 || h->lane_mode == 0) && h->row_chunks <= 128;
 }
 
-qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, hipStream_t s,
+// qc: the query's actual_dim codes (16-byte aligned), qo: its f32 offset -- inside a qamd_u8_query
+// or straight out of a query batch ([q][pitch] codes, [q] offsets).
+qamd_status scan_ptrs(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out_dev, hipStream_t s,
                       const TopkFilter *filt = nullptr) {
     if (h->count == 0) return QAMD_OK;
-    const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
-    const float *qo = q->buf.as<float>();
     const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
     if (!is_l1 && h->lane_mode == 1) {
         uint64_t waves = (h->count + 3) / 4;
@@ -915,6 +915,11 @@ qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, 
     }
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;
+}
+
+qamd_status scan_into(const qamd_u8 *h, const qamd_u8_query *q, float *out_dev, hipStream_t s,
+                      const TopkFilter *filt = nullptr) {
+    return scan_ptrs(h, reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16), q->buf.as<float>(), out_dev, s, filt);
 }
 
 qamd_status check_query(const qamd_u8 *h, const qamd_u8_query *q) {
@@ -1541,34 +1546,7 @@ qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, i
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
     if (out_mem == QAMD_MEM_DEVICE) q->async_used.store(true, std::memory_order_relaxed);
-    const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
-    FusedScan scan;
-    scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_into(h, q, scores, st); };
-    scan.scan_filter = [&](const TopkFilter &f, hipStream_t st) { return scan_into(h, q, nullptr, st, &f); };
-    scan.score_ids = [&](const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
-        return score_ids_dev(h, qc, q->buf.as<float>(), 0.0f, EPI_POINT, ids, n_ids, out, st);
-    };
-    {   // small stores: one launch, no status read-back (device outputs only enqueue)
-        const int g = small_group(h->row_chunks);
-        SmallTopkPlan plan;
-        if (g && fused_capable(h) && small_topk_plan(h->count, k, 2 * (64 / g), plan)) {
-            const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
-            return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s,
-                              [&](const SmallTopk &p, hipStream_t st) {
-                                  return is_l1 ? launch_small<true>(h, qc, q->buf.as<float>(), plan, p, st)
-                                               : launch_small<false>(h, qc, q->buf.as<float>(), plan, p, st);
-                              });
-        }
-    }
-    if (!fused_capable(h)) {  // rare layouts: classic path only
-        float *scores = nullptr;
-        QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));
-        qamd_status st = scan_into(h, q, scores, s);
-        if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
-        thread_ws_release(WS_SCORES, s);
-        return st;
-    }
-    return fused_topk(h->count, k, largest, out_ids, out_scores, out_mem, s, scan);
+    return u8_topk_ptrs(h, q->buf.as<uint8_t>() + 16, q->buf.as<float>(), k, largest, out_ids, out_scores, out_mem, s);
 }
 
 void qamd_u8_free(qamd_u8 *h) { delete h; }
@@ -1838,32 +1816,52 @@ qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev,
     return QAMD_OK;
 }
 
-// Exact single-query top-k for one member of a query batch (its per-query fallback).
+// The top-k of one query given as raw device pointers (its codes and its offset): the body of
+// qamd_u8_topk, also the per-query route of the batch API, which hands in rows of a query batch
+// without copying them into a query object.  Runs on the current device.
+qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float *qo, uint32_t k, int largest,
+                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t s) {
+    const uint4 *qc = reinterpret_cast<const uint4 *>(codes_dev);
+    FusedScan scan;
+    scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_ptrs(h, qc, qo, scores, st); };
+    scan.scan_filter = [&](const TopkFilter &f, hipStream_t st) { return scan_ptrs(h, qc, qo, nullptr, st, &f); };
+    scan.score_ids = [&](const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+        return score_ids_dev(h, qc, qo, 0.0f, EPI_POINT, ids, n_ids, out, st);
+    };
+    {   // small stores: one launch, no status read-back (device outputs only enqueue)
+        const int g = small_group(h->row_chunks);
+        SmallTopkPlan plan;
+        if (g && fused_capable(h) && small_topk_plan(h->count, k, 2 * (64 / g), plan)) {
+            const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+            return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s,
+                              [&](const SmallTopk &p, hipStream_t st) {
+                                  return is_l1 ? launch_small<true>(h, qc, qo, plan, p, st)
+                                               : launch_small<false>(h, qc, qo, plan, p, st);
+                              });
+        }
+    }
+    if (!fused_capable(h)) {  // rare layouts: classic path only
+        float *scores = nullptr;
+        QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));
+        qamd_status st = scan_ptrs(h, qc, qo, scores, s);
+        if (st == QAMD_OK) st = topk_finish(scores, h->count, k, largest, out_ids, out_scores, out_mem, s);
+        thread_ws_release(WS_SCORES, s);
+        return st;
+    }
+    return fused_topk(h->count, k, largest, out_ids, out_scores, out_mem, s, scan);
+}
+
+// Exact single-query top-k for one member of a query batch (its per-query fallback): no copy, no
+// allocation; on small stores (single-launch path) with device outputs it only enqueues.
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,
                            int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream) {
-    qamd_u8_query q;
-    q.device = h->device;
-    q.actual_dim = h->meta.actual_dim;
-    QAMD_TRY(q.buf.alloc(16 + q.actual_dim + 16, true));
-    QAMD_HIP(hipMemcpyAsync(q.buf.ptr, offset_dev, 4, hipMemcpyDeviceToDevice, stream));
-    QAMD_HIP(hipMemcpyAsync(q.buf.as<uint8_t>() + 16, codes_dev, q.actual_dim, hipMemcpyDeviceToDevice, stream));
-    qamd_status st = qamd_u8_topk(h, &q, k, largest, out_ids, out_scores, out_mem, stream);
-    QAMD_HIP(hipStreamSynchronize(stream));  // q.buf is freed on return
-    return st;
+    return u8_topk_ptrs(h, codes_dev, offset_dev, k, largest, out_ids, out_scores, out_mem, stream);
 }
 
 // score_all for one member of a query batch (the L1 route of the batch API: L1 has no MFMA form).
 qamd_status u8_score_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, float *out_dev,
                             hipStream_t stream) {
-    qamd_u8_query q;
-    q.device = h->device;
-    q.actual_dim = h->meta.actual_dim;
-    QAMD_TRY(q.buf.alloc(16 + q.actual_dim + 16, true));
-    QAMD_HIP(hipMemcpyAsync(q.buf.ptr, offset_dev, 4, hipMemcpyDeviceToDevice, stream));
-    QAMD_HIP(hipMemcpyAsync(q.buf.as<uint8_t>() + 16, codes_dev, q.actual_dim, hipMemcpyDeviceToDevice, stream));
-    qamd_status st = qamd_u8_score_all(h, &q, out_dev, QAMD_MEM_DEVICE, stream);
-    QAMD_HIP(hipStreamSynchronize(stream));  // q.buf is freed on return
-    return st;
+    return scan_ptrs(h, reinterpret_cast<const uint4 *>(codes_dev), offset_dev, out_dev, stream);
 }
 
 }  // namespace qamd

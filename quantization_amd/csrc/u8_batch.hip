@@ -1047,13 +1047,16 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     // rank >= 8 (P(fewer than k) < 1e-7, P(more than 8192) ~ 0); S = 8 n / that, capped at 524288
     // sampled rows (beyond 33M rows the expected count grows instead of r shrinking).
     const double want = std::max<double>(512.0, 3.0 * k);
-    const double s_mem_cap = std::max<double>(kTopkSample, std::floor((double)(6ull << 30) / (4.0 * (double)Q) / 256.0) * 256.0);  // <= 6 GB of sample scores
+    // small stores (Qdrant segments: 1e5..1e6 rows) take the same route with a smaller sample: the
+    // per-query fallback costs a launch chain per query, the matrix-core pass one for the whole batch
+    const double s_min = n < (1u << 20) ? 2048.0 : (double)kTopkSample;
+    const double s_mem_cap = std::max<double>(s_min, std::floor((double)(6ull << 30) / (4.0 * (double)Q) / 256.0) * 256.0);  // <= 6 GB of sample scores
     const uint32_t S = (uint32_t)std::min<double>(std::min<double>(524288.0, s_mem_cap),
-                                                  std::max<double>(kTopkSample, round_up((uint64_t)(8.0 * (double)n / want), 256)));
+                                                  std::max<double>(s_min, round_up((uint64_t)(8.0 * (double)n / want), 256)));
     const double target = std::max<double>(want, 8.0 * (double)n / (double)S);
     const uint32_t r = n ? (uint32_t)std::ceil((double)S * target / (double)n) : 0;
     // (the sample scores are Q x S f32: 0.6 GB at 1024 queries and 10M rows, 5 GB at 8192 queries)
-    const bool fused = n >= (1u << 20) && r <= 64 && h->meta.vector_parameters.distance_type != QAMD_L1;
+    const bool fused = n >= 32768 && r <= 64 && h->meta.vector_parameters.distance_type != QAMD_L1;
 
     StreamBuf ids_tmp, sc_tmp;
     uint32_t *ids_dev = out_ids;

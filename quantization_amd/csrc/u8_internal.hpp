@@ -40,6 +40,8 @@ qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev,
                                      uint8_t *codes_dev /* [n][code_pitch], actual_dim written */, uint64_t code_pitch,
                                      float *offsets_dev /* [n] */,
                                      hipStream_t stream);
+qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k, int largest,
+                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);
 qamd_status u8_score_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, float *out_dev,
                             hipStream_t stream);
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,

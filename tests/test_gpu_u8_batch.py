@@ -199,3 +199,22 @@ def test_ping_pong_filter_repeated_runs_match_exact_topk():
                 want_ids, want_sc = enc.topk(enc.encode_query(queries[qi]), k, largest=(it % 2 == 0))
                 assert np.array_equal(ids[qi], want_ids), (nq, it, qi)
                 assert np.array_equal(sc[qi].view(np.uint32), want_sc.view(np.uint32)), (nq, it, qi)
+
+
+@pytest.mark.parametrize("n,dim,nq", [(40_000, 768, 33), (100_003, 192, 130), (700_001, 128, 300), (33_000, 1536, 5)])
+@pytest.mark.parametrize("largest", [True, False])
+def test_topk_batch_medium_stores_take_the_matrix_core_path(n, dim, nq, largest):
+    """Stores of 32k .. 1M rows (typical Qdrant segments) with many queries: one matrix-core pass for
+    the whole batch instead of a launch chain per query; every list equals the exact single-query one."""
+    rng = np.random.default_rng(n + nq)
+    data = rng.random((n, dim), dtype=np.float32)
+    dist = D.Dot if largest else D.L2
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, False))
+    queries = rng.random((nq, dim), dtype=np.float32)
+    ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30, largest=largest)
+    qobj = None
+    for qi in range(nq):
+        qobj = enc.encode_query(queries[qi], reuse=qobj)
+        wi, ws = enc.topk(qobj, 30, largest=largest)
+        assert np.array_equal(ids[qi], wi), (qi, n)
+        assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (qi, n)
