@@ -1851,6 +1851,25 @@ qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float
     return fused_topk(h->count, k, largest, out_ids, out_scores, out_mem, s, scan);
 }
 
+// The batch API for the metrics with no matrix form (L1: sum |q - v| is not a contraction): the
+// per-query fused pipelines of all queries enqueued back to back (fused_topk_batch), one status
+// read-back per 32 queries.  codes_dev: [Q][pitch], offsets_dev: [Q].
+qamd_status u8_topk_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
+                                uint32_t n_queries, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                                qamd_mem out_mem, hipStream_t stream) {
+    auto qc = [&](uint32_t q) { return reinterpret_cast<const uint4 *>(codes_dev + (uint64_t)q * pitch); };
+    BatchScan scan;
+    scan.filter_capable = fused_capable(h);
+    scan.scan_scores = [&](uint32_t q, float *scores, hipStream_t st) { return scan_ptrs(h, qc(q), offsets_dev + q, scores, st); };
+    scan.scan_filter = [&](uint32_t q, const TopkFilter &f, hipStream_t st) {
+        return scan_ptrs(h, qc(q), offsets_dev + q, nullptr, st, &f);
+    };
+    scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+        return score_ids_dev(h, qc(q), offsets_dev + q, 0.0f, EPI_POINT, ids, n_ids, out, st);
+    };
+    return fused_topk_batch(h->count, n_queries, k, largest, out_ids, out_scores, out_mem, stream, scan);
+}
+
 // Exact single-query top-k for one member of a query batch (its per-query fallback): no copy, no
 // allocation; on small stores (single-launch path) with device outputs it only enqueues.
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,

@@ -1038,6 +1038,12 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     const uint64_t Q = b->n_queries, n = h->count;
+    if (h->meta.vector_parameters.distance_type == QAMD_L1 && n > (2u << 20))
+        // no matrix form for L1; above the single-launch top-k's range the per-query fused scans run
+        // back to back with one status read-back per 32 queries (below it the loop further down
+        // only enqueues)
+        return u8_topk_batch_scans(h, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), (uint32_t)Q, k, largest,
+                                   out_ids, out_scores, out_mem, s);
     // Pivot rank r of S sampled rows: the number of rows at least as good as the pivot is about
     // n*Beta(r, S-r+1): mean n*r/S, relative spread 1/sqrt(r).  With many queries per call both tails
     // matter (a list that overflows kBatchCap or holds fewer than k rows sends its query to the exact

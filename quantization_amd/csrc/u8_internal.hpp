@@ -42,6 +42,9 @@ qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev,
                                      hipStream_t stream);
 qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k, int largest,
                          uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);
+qamd_status u8_topk_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
+                                uint32_t n_queries, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                                qamd_mem out_mem, hipStream_t stream);
 qamd_status u8_score_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, float *out_dev,
                             hipStream_t stream);
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,

@@ -218,3 +218,19 @@ def test_topk_batch_medium_stores_take_the_matrix_core_path(n, dim, nq, largest)
         wi, ws = enc.topk(qobj, 30, largest=largest)
         assert np.array_equal(ids[qi], wi), (qi, n)
         assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (qi, n)
+
+
+def test_topk_batch_l1_large_store_runs_back_to_back_fused_scans():
+    """L1 has no matrix form; above 2M rows the batch call enqueues the per-query fused scans back to
+    back (one status read-back per 32 queries) — results equal the single-query call."""
+    torch = pytest.importorskip("torch")
+    n, dim, nq = 2_300_000, 64, 35
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    data = torch.rand((n, dim), generator=g, device="cuda")
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L1, False))
+    queries = np.random.default_rng(3).random((nq, dim), dtype=np.float32)
+    ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 20, largest=False)
+    for qi in (0, 1, 17, 31, 32, 34):
+        wi, ws = enc.topk(enc.encode_query(queries[qi]), 20, largest=False)
+        assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), qi
