@@ -489,6 +489,18 @@ qamd_status launch_small(const qamd_bin *h, const uint4 *qb, const SmallTopkPlan
     return launch_bin_small<16, 4>(h, qb, pl, p, s);
 }
 
+// The single-launch top-k when the store qualifies (<= 2M rows, k <= 64, 16-byte row pieces): false = not applicable.
+bool bin_topk_small(const qamd_bin *h, const void *qbits_dev, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                    qamd_mem out_mem, hipStream_t s, qamd_status &st) {
+    const int g = bin_small_group((uint32_t)(h->ds / 16));
+    SmallTopkPlan plan;
+    if (!g || !fused_capable(h) || !small_topk_plan(h->count, k, 2 * (64 / g), plan)) return false;
+    st = small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t stt) {
+        return launch_small(h, static_cast<const uint4 *>(qbits_dev), plan, p, stt);
+    });
+    return true;
+}
+
 qamd_status check_query(const qamd_bin *h, const qamd_bin_query *q) {
     if (!h || !q) return fail(QAMD_ERR_ARGUMENTS, "null handle or query");
     if (q->nb != h->nb) return fail(QAMD_ERR_ARGUMENTS, "query has %llu bytes, rows have %llu",
@@ -788,12 +800,8 @@ qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
     {   // small stores: one launch, exact under any number of ties, no status read-back
-        const int g = bin_small_group((uint32_t)(h->ds / 16));
-        SmallTopkPlan plan;
-        if (g && fused_capable(h) && small_topk_plan(h->count, k, 2 * (64 / g), plan))
-            return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t st) {
-                return launch_small(h, q->buf.as<uint4>(), plan, p, st);
-            });
+        qamd_status st = QAMD_OK;
+        if (bin_topk_small(h, q->buf.ptr, k, largest, out_ids, out_scores, out_mem, s, st)) return st;
     }
     if (!fused_capable(h)) {
         float *scores = nullptr;
@@ -967,6 +975,9 @@ qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b
     };
     scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
         return words_launch(h, reinterpret_cast<const uint32_t *>(bits + q * qs), ids, n_ids, out, st);
+    };
+    scan.topk_small = [&](uint32_t q, uint32_t *ids, float *sc, hipStream_t st, qamd_status &status) {
+        return bin_topk_small(h, bits + (uint64_t)q * qs, k, largest, ids, sc, QAMD_MEM_DEVICE, st, status);
     };
     // up to 8 queries share one pass over the rows (the filtering form of bin_scan_multi_kernel)
     scan.scan_filter_multi = [&](uint32_t q, uint32_t left, const TopkFilterSlices &sl, hipStream_t st, qamd_status &status) -> uint32_t {

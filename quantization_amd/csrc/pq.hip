@@ -762,6 +762,36 @@ qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *
     return QAMD_OK;
 }
 
+// The single-launch top-k when the store qualifies (<= 2M rows, k <= 64, LUT <= 128 KiB): false = not applicable.
+bool pq_topk_small(const qamd_pq *h, const float *lut, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+                   qamd_mem out_mem, hipStream_t s, qamd_status &status) {
+    SmallTopkPlan plan;
+    const size_t lut_bytes = (size_t)h->m * kCentroids * sizeof(float);
+    if (h->m < 1 || lut_bytes > 128 * 1024 || !small_topk_plan(h->count, k, 16, plan)) return false;
+    static std::atomic<uint64_t> set_on{0};
+    if (first_use_on_device(set_on)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+            status = fail(QAMD_ERR_DEVICE, "cannot raise the dynamic LDS limit of pq_topk_small_kernel");
+            return true;
+        }
+    }
+    const uint32_t row_words = (uint32_t)(h->ds / 4);
+    status = small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t st) {
+        if (row_words % 4 == 0)
+            hipLaunchKernelGGL(pq_topk_small_kernel<true>, dim3(plan.workgroups), dim3(1024), lut_bytes, st,
+                               h->rows.as<uint32_t>(), lut, (uint32_t)h->count, (uint32_t)h->m, row_words, plan.rows_per_wg, p);
+        else
+            hipLaunchKernelGGL(pq_topk_small_kernel<false>, dim3(plan.workgroups), dim3(1024), lut_bytes, st,
+                               h->rows.as<uint32_t>(), lut, (uint32_t)h->count, (uint32_t)h->m, row_words, plan.rows_per_wg, p);
+        QAMD_HIP(hipGetLastError());
+        return QAMD_OK;
+    });
+    return true;
+}
+
 qamd_status check_query(const qamd_pq *h, const qamd_pq_query *q) {
     if (!h || !q) return fail(QAMD_ERR_ARGUMENTS, "null handle or query");
     if (q->m != h->m) return fail(QAMD_ERR_ARGUMENTS, "query LUT has %llu chunks, store has %llu",
@@ -1287,30 +1317,8 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
     QAMD_TRY(q->ready.wait(s));
     const float *lut = q->lut.as<float>();
     {   // small stores: one launch (LUT + the merge lists fit the LDS up to m = 128)
-        SmallTopkPlan plan;
-        const size_t lut_bytes = (size_t)h->m * kCentroids * sizeof(float);
-        if (h->m >= 1 && lut_bytes <= 128 * 1024 && small_topk_plan(h->count, k, 16, plan)) {
-            static std::atomic<uint64_t> set_on{0};
-            if (first_use_on_device(set_on)) {
-                QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            }
-            const uint32_t row_words = (uint32_t)(h->ds / 4);
-            return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t st) {
-                if (row_words % 4 == 0)
-                    hipLaunchKernelGGL(pq_topk_small_kernel<true>, dim3(plan.workgroups), dim3(1024), lut_bytes, st,
-                                       h->rows.as<uint32_t>(), lut, (uint32_t)h->count, (uint32_t)h->m, row_words,
-                                       plan.rows_per_wg, p);
-                else
-                    hipLaunchKernelGGL(pq_topk_small_kernel<false>, dim3(plan.workgroups), dim3(1024), lut_bytes, st,
-                                       h->rows.as<uint32_t>(), lut, (uint32_t)h->count, (uint32_t)h->m, row_words,
-                                       plan.rows_per_wg, p);
-                QAMD_HIP(hipGetLastError());
-                return QAMD_OK;
-            });
-        }
+        qamd_status st = QAMD_OK;
+        if (pq_topk_small(h, lut, k, largest, out_ids, out_scores, out_mem, s, st)) return st;
     }
     if (!fast_capable(h, h->count)) {
         float *scores = nullptr;
@@ -1595,6 +1603,9 @@ qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_batch *b, u
     };
     scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
         return scan_launch(h, luts + q * per, ids, n_ids, out, st);
+    };
+    scan.topk_small = [&](uint32_t q, uint32_t *ids, float *sc, hipStream_t st, qamd_status &status) {
+        return pq_topk_small(h, luts + q * per, k, largest, ids, sc, QAMD_MEM_DEVICE, st, status);
     };
     return fused_topk_batch(h->count, (uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, as_stream(stream),
                             scan);

@@ -468,7 +468,17 @@ qamd_status fused_topk_batch(uint64_t n, uint32_t Q, uint32_t k, int largest, ui
         return topk_f32(scores, n, k, largest != 0, ids_dev + (size_t)q * k, sc_dev + (size_t)q * k, sel, stream);
     };
     qamd_status st = QAMD_OK;
-    if (!use_fused) {
+    bool small_done = false;
+    if (scan.topk_small && n <= (2u << 20) && k <= kSmallTopkMaxK) {  // small stores: one launch per query, no sync
+        small_done = true;
+        for (uint32_t q = 0; q < Q && st == QAMD_OK; q++)
+            if (!scan.topk_small(q, ids_dev + (size_t)q * k, sc_dev + (size_t)q * k, stream, st)) {
+                small_done = false;  // (the first query decides: the plan depends on the store only)
+                break;
+            }
+    }
+    if (small_done) {
+    } else if (!use_fused) {
         for (uint32_t q = 0; q < Q && st == QAMD_OK; q++) st = classic(q);
     } else {
         constexpr uint32_t kChunk = 32;

@@ -52,6 +52,9 @@ struct BatchScan {
     std::function<qamd_status(uint32_t q, const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t)> score_ids;
     std::function<qamd_status(uint32_t q, const TopkFilter &, hipStream_t)> scan_filter;
     std::function<qamd_status(uint32_t q, float *scores_dev, hipStream_t)> scan_scores;
+    // optional: the quantizer's single-launch top-k (stores <= 2M rows, k <= 64) with DEVICE outputs --
+    // when set it serves every query (enqueue-only, no status word); returns false when not applicable
+    std::function<bool(uint32_t q, uint32_t *ids_dev, float *scores_dev, hipStream_t, qamd_status &st)> topk_small;
     bool filter_capable = true;  // false: no FILTER-mode scan for this store -> classic path for every query
     // optional: ONE filtering scan for `nq` consecutive queries (their slices start at `slices.base`);
     // returns how many queries it took (8, 4, 2) or 0 when it has no kernel for this store / count
