@@ -147,6 +147,7 @@ qamd_status copy_out(void *dst, qamd_mem dst_mem, const void *dev_src, size_t by
 // (score_point, score_internal, small score_ids) put their row ids there and let the kernel
 // write the scores straight back: no allocation, no explicit copy, one launch + one sync.
 constexpr size_t kHostQueryWords = 12288;  // a host query of up to 12288 f32 rides in the scratch too
+constexpr size_t kHostDoneAt = 2048 + 8;  // "results are in place" flag of the single-launch top-k
 constexpr size_t kHostQueryAt = 2048 + 16;
 constexpr size_t kHostScratchWords = kHostQueryAt + kHostQueryWords;  // [0, 1024) ids, [1024, 2048) results,
                                                                      // [2048] a status word, [2064, ...) a query

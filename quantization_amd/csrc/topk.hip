@@ -10,6 +10,8 @@
 #include "topk_device.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
@@ -583,7 +585,8 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
 // ------------------------------------------------------------------------ single-launch top-k
 bool small_topk_plan(uint64_t n, uint32_t k, uint32_t rows_per_tile, SmallTopkPlan &plan) {
     if (n == 0 || n > (2u << 20) || k == 0 || k > kSmallTopkMaxK) return false;
-    uint32_t wgs = (uint32_t)device_info().cu_count;  // one 16-wave workgroup per CU
+    uint32_t wgs = std::min<uint32_t>((uint32_t)device_info().cu_count, 256u);  // one 16-wave workgroup per CU;
+                                                                                // <= 256: the last workgroup folds 16 lists per wave
     wgs = (uint32_t)std::min<uint64_t>(wgs, (n + rows_per_tile - 1) / rows_per_tile);  // at least one tile each
     const uint32_t per = (uint32_t)round_up((n + wgs - 1) / wgs, rows_per_tile);
     wgs = (uint32_t)((n + per - 1) / per);  // drop workgroups that would own no row
@@ -612,6 +615,15 @@ qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint3
     p.wg_best = reinterpret_cast<unsigned long long *>(ws + off_best);
     p.k = k;
     p.largest = largest;
+    p.done_flag = nullptr;
+    p.done_value = 0;
+    static thread_local uint32_t done_seq = 0;
+    if (hs.host) {  // the kernel raises a flag in the mapped scratch behind its results: poll, do not sleep
+        if (++done_seq == 0) done_seq = 1;
+        hs.host[kHostDoneAt] = 0;
+        p.done_flag = hs.dev + kHostDoneAt;
+        p.done_value = done_seq;
+    }
     p.out_ids = out_mem == QAMD_MEM_DEVICE ? out_ids : hs.host ? hs.dev : reinterpret_cast<uint32_t *>(ws + off_out);
     p.out_scores = out_mem == QAMD_MEM_DEVICE ? out_scores
                    : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
@@ -619,7 +631,21 @@ qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint3
     if (st == QAMD_OK) st = launch(p, stream);
     if (st == QAMD_OK && out_mem == QAMD_MEM_HOST) {
         if (hs.host) {
-            if (hipStreamSynchronize(stream) != hipSuccess) st = fail(QAMD_ERR_DEVICE, "top-k: stream synchronisation failed");
+            // A stream synchronisation costs a 20-30 us wake-up on this runtime -- as much as the whole
+            // kernel on a 100k-row store.  Poll the flag the kernel writes (system-scope release) after its
+            // results for up to ~2 ms, then fall back to the synchronisation (a long queue ahead of us).
+            volatile uint32_t *flag = hs.host + kHostDoneAt;
+            bool seen = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spin = 0; !seen; spin++) {
+                seen = *flag == p.done_value;
+                if (!seen && (spin & 255u) == 255u &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                    break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (!seen && hipStreamSynchronize(stream) != hipSuccess)
+                st = fail(QAMD_ERR_DEVICE, "top-k: stream synchronisation failed");
             memcpy(out_ids, hs.host, (size_t)k * 4);
             memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
         } else {

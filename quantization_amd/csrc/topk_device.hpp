@@ -83,27 +83,68 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
     const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
+// The key of lane ^ J: distances 1 and 2 stay inside a quad (DPP quad_perm, a plain VALU move instead of
+// a ds_bpermute round trip through the LDS crossbar).
+template <int J> __device__ __forceinline__ unsigned long long xor_exchange(unsigned long long v) {
+    if (J == 1 || J == 2) {
+        constexpr int CTRL = J == 1 ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+        return ((unsigned long long)hi << 32) | lo;
+    }
+    return shfl_xor_u64(v, J);
+}
+template <int J> __device__ __forceinline__ unsigned long long cmpx(unsigned long long v, int lane, bool ascending) {
+    const unsigned long long o = xor_exchange<J>(v);
+    const bool keep_min = ((lane & J) == 0) == ascending;
+    return keep_min ? (o < v ? o : v) : (o > v ? o : v);
+}
 // Bitonic sort of 64 keys, one per lane, ascending by lane.
 __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long v, int lane) {
-#pragma unroll
-    for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (int j = size >> 1; j > 0; j >>= 1) {
-            const unsigned long long o = shfl_xor_u64(v, j);
-            const bool keep_min = ((lane & j) == 0) == ((lane & size) == 0);
-            v = keep_min ? (o < v ? o : v) : (o > v ? o : v);
-        }
-    }
+    v = cmpx<1>(v, lane, (lane & 2) == 0);
+    v = cmpx<2>(v, lane, (lane & 4) == 0);
+    v = cmpx<1>(v, lane, (lane & 4) == 0);
+    v = cmpx<4>(v, lane, (lane & 8) == 0);
+    v = cmpx<2>(v, lane, (lane & 8) == 0);
+    v = cmpx<1>(v, lane, (lane & 8) == 0);
+    v = cmpx<8>(v, lane, (lane & 16) == 0);
+    v = cmpx<4>(v, lane, (lane & 16) == 0);
+    v = cmpx<2>(v, lane, (lane & 16) == 0);
+    v = cmpx<1>(v, lane, (lane & 16) == 0);
+    v = cmpx<16>(v, lane, (lane & 32) == 0);
+    v = cmpx<8>(v, lane, (lane & 32) == 0);
+    v = cmpx<4>(v, lane, (lane & 32) == 0);
+    v = cmpx<2>(v, lane, (lane & 32) == 0);
+    v = cmpx<1>(v, lane, (lane & 32) == 0);
+    v = cmpx<32>(v, lane, true);
+    v = cmpx<16>(v, lane, true);
+    v = cmpx<8>(v, lane, true);
+    v = cmpx<4>(v, lane, true);
+    v = cmpx<2>(v, lane, true);
+    v = cmpx<1>(v, lane, true);
     return v;
 }
 // The 64 smallest keys of two ascending lists; b_rev[i] must be b[63 - i].
 __device__ __forceinline__ unsigned long long wave_merge64_rev(unsigned long long a, unsigned long long b_rev, int lane) {
     unsigned long long v = b_rev < a ? b_rev : a;
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        const unsigned long long o = shfl_xor_u64(v, j);
-        v = ((lane & j) == 0) ? (o < v ? o : v) : (o > v ? o : v);
-    }
+    v = cmpx<32>(v, lane, true);
+    v = cmpx<16>(v, lane, true);
+    v = cmpx<8>(v, lane, true);
+    v = cmpx<4>(v, lane, true);
+    v = cmpx<2>(v, lane, true);
+    v = cmpx<1>(v, lane, true);
+    return v;
+}
+// Two independent 32-key lists per wave (lanes 0-31 and 32-63, each ascending within its half): the 32
+// smallest of a half's list and an incoming list given reversed within the half (b_rev[i] = b[31 - i]).
+// Nothing crosses the halves (distances <= 16), so a wave folds two lists per step.
+__device__ __forceinline__ unsigned long long wave_merge32x2_rev(unsigned long long a, unsigned long long b_rev, int lane) {
+    unsigned long long v = b_rev < a ? b_rev : a;
+    v = cmpx<16>(v, lane, true);
+    v = cmpx<8>(v, lane, true);
+    v = cmpx<4>(v, lane, true);
+    v = cmpx<2>(v, lane, true);
+    v = cmpx<1>(v, lane, true);
     return v;
 }
 
@@ -117,6 +158,11 @@ struct SmallTopk {
     float *out_scores;            // [k]
     uint32_t k;
     int largest;
+    // host outputs through the mapped scratch: after the results, the kernel publishes `done_value`
+    // here (system scope) so that the host can poll for it instead of paying a stream
+    // synchronisation's wake-up latency; nullptr = no flag
+    uint32_t *done_flag;
+    uint32_t done_value;
 };
 
 // Per-wave accumulator: feed keys through `stage` (this wave's 64 LDS slots), flush when full.
@@ -149,41 +195,66 @@ __device__ __forceinline__ unsigned long long small_topk_fold_waves(unsigned lon
     return best;
 }
 
-// Tail of a *_topk_small_kernel.  Cross-workgroup visibility follows the release / ticket / acquire
-// recipe of cdna_hip_programming.md (Guideline 16, counter form): the publishing wave drains its
-// stores, lane 0 runs an agent-scope release + drain and a relaxed agent fetch_add; the workgroup
-// that draws the last ticket runs one agent-scope acquire + drain + barrier before its plain loads.
+// Tail of a *_topk_small_kernel.  Cross-workgroup hand-off in the guide's write-through form
+// (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "hand-offs measured with sc1 loads"):
+// the workgroup's list is stored with sc1 (agent-scope relaxed atomic stores: write-through, so no
+// L2 write-back fence is needed), the storing wave drains its stores (s_waitcnt vmcnt(0)), ONE lane
+// makes a relaxed agent fetch_add on the ticket; the workgroup whose add came last reads every list
+// with sc1 loads -- its other waves behind the barrier that the adding wave joins.  (The first
+// version used plain stores + an agent release fence and an acquire fence + plain loads: the two
+// fences cost 4-8 us of a 35 us kernel.)
 __device__ __forceinline__ void small_topk_finish(unsigned long long best, unsigned long long (*lists)[64],
                                                   const SmallTopk &p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t k = p.k, wgs = gridDim.x;
     best = small_topk_fold_waves(best, lists, wave, lane);
     if (wave == 0) {
-        if ((uint32_t)lane < k) p.wg_best[(size_t)blockIdx.x * k + lane] = best;
+        if ((uint32_t)lane < k)
+            __hip_atomic_store(&p.wg_best[(size_t)blockIdx.x * k + lane], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t last = 0;
         if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t drawn = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = drawn == wgs - 1 ? 1u : 0u;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            lists[0][0] = last;  // "I am last" through the one LDS array
+            lists[0][0] = drawn == wgs - 1 ? 1ull : 0ull;  // "I am last" through the one LDS array (the add has returned)
         }
     }
     __syncthreads();
     const bool last = lists[0][0] != 0ull;
     __syncthreads();
     if (!last) return;
-    // every wave folds its share of the workgroups' lists (ascending, k valid keys each), then the tournament
+    // every wave folds its share of the workgroups' lists (ascending, k valid keys each), then the
+    // tournament.  All of a wave's lists are loaded BEFORE the first merge: sixteen dependent
+    // L2 round trips, one per merge, were most of this workgroup's time.
+    constexpr int kListsPerWave = 16;  // workgroups <= 256 (small_topk_plan)
     unsigned long long mine = ~0ull;
-    for (uint32_t g = wave; g < wgs; g += kSmallTopkWaves) {
+    if (k <= 32) {
+        // a list holds at most 32 keys: the two halves of the wave fold two lists per step (half h takes
+        // the wave's lists 2j + h), then the upper half's result is folded into the lower one
+        const uint32_t half = (uint32_t)lane >> 5, r = 31 - ((uint32_t)lane & 31u);  // reversed read inside the half
+        unsigned long long theirs[kListsPerWave / 2];
+#pragma unroll
+        for (int j = 0; j < kListsPerWave / 2; j++) {
+            const uint32_t g = wave + kSmallTopkWaves * (2 * j + half);
+            theirs[j] = (g < wgs && r < k) ? __hip_atomic_load(&p.wg_best[(size_t)g * k + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : ~0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < kListsPerWave / 2; j++)
+            if (wave + kSmallTopkWaves * 2 * j < (int)wgs) mine = wave_merge32x2_rev(mine, theirs[j], lane);  // wave-uniform test
+        const unsigned long long upper_rev = shfl_u64(mine, 63 - lane);  // lane i < 32 receives the upper half's key 31 - i
+        mine = wave_merge32x2_rev(mine, upper_rev, lane);
+        if (lane >= 32) mine = ~0ull;
+    } else {
+        unsigned long long theirs[kListsPerWave];
         const uint32_t r = 63 - lane;  // reversed read
-        const unsigned long long o = r < k ? p.wg_best[(size_t)g * k + r] : ~0ull;
-        mine = wave_merge64_rev(mine, o, lane);
+#pragma unroll
+        for (int i = 0; i < kListsPerWave; i++) {
+            const uint32_t g = wave + kSmallTopkWaves * i;
+            theirs[i] = (g < wgs && r < k) ? __hip_atomic_load(&p.wg_best[(size_t)g * k + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : ~0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < kListsPerWave; i++)
+            if (wave + kSmallTopkWaves * i < (int)wgs) mine = wave_merge64_rev(mine, theirs[i], lane);
     }
     mine = small_topk_fold_waves(mine, lists, wave, lane);
     if (wave == 0) {
@@ -197,6 +268,10 @@ __device__ __forceinline__ void small_topk_finish(unsigned long long best, unsig
             }
         }
         if (lane == 0) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+        if (p.done_flag) {  // wave-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's result stores have been acknowledged
+            if (lane == 0) __hip_atomic_store(p.done_flag, p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
