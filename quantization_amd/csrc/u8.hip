@@ -196,6 +196,85 @@ __global__ __launch_bounds__(kScanBlock) void u8_scan_kernel(
     }
 }
 
+// NQ (2, 4, 8) queries per row read on the vector ALU -- the route of qamd_u8_topk_batch /
+// score_batch for a handful of queries over a large store, where the matrix-core kernel is bound
+// by what its LDS-DMA path moves (4.6 TB/s of row bytes: 1.67 ms per 10M x 768 whatever the batch)
+// while this one streams the rows like the single-query scan: the row's 16-byte pieces are loaded
+// once (nt) and v_dot4'd against NQ query rows held in registers (NQ * ITERS * 4 VGPRs).  Lane
+// (row slot, sub = j) keeps query j's score of the row.  Same integer sum and the same f32
+// epilogue as u8_scan_kernel => the same score bits.  G >= NQ.
+// FILTER: no score is written; the lane offers its row to query j's candidate lists (slices).
+template <int G, int ITERS, int UNROLL, int NQ, bool IS_L1, bool EXACT, bool FILTER>
+__global__ __launch_bounds__(kScanBlock) void u8_scan_multi_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint8_t *__restrict__ qcodes,
+    uint32_t q_pitch, const float *__restrict__ q_offs, uint32_t nq_valid /* <= NQ: queries really there */,
+    float multiplier, uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out /* [NQ][out_pitch] */,
+    uint64_t out_pitch, TopkFilterSlices slices) {
+    static_assert(G >= NQ, "one lane of the row group per query");
+    constexpr int RW = 64 / G;
+    constexpr int TILE = RW * UNROLL;
+    // A wave walks kMultiTiles consecutive tiles: the NQ query rows (NQ * ITERS 16-byte loads per lane)
+    // are fetched once per wave, so they must be amortised over more rows than one tile holds
+    // (with one tile per wave the query loads were as many bytes as the rows themselves).
+    constexpr int TPW = NQ;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kScanBlock + threadIdx.x) >> 6;
+    if (wave * TILE * TPW >= n_rows) return;
+    uint4 q[NQ][ITERS];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {  // an unused slot (3 queries in a 4-wide pass) re-reads the last query
+        const uint4 *qj = reinterpret_cast<const uint4 *>(qcodes + (size_t)((uint32_t)j < nq_valid ? j : nq_valid - 1) * q_pitch);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint32_t c = sub + it * G;
+            const bool in = EXACT || c < row_chunks;
+            const uint4 t = qj[in ? c : row_chunks - 1];
+            q[j][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+        }
+    }
+    const float q_off = q_offs[(uint32_t)sub < nq_valid ? sub : 0];
+    for (int tile = 0; tile < TPW; tile++) {
+        const uint64_t base = (wave * TPW + tile) * TILE;
+        if (base >= n_rows) break;
+        uint4 v[UNROLL][ITERS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint4 *p = codes + (base + u * RW + rslot) * row_chunks;  // rows are padded: no guard
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t c = sub + it * G;
+                const bool in = EXACT || c < row_chunks;
+                const uint4 t = ld_nt(p + (in ? c : row_chunks - 1));
+                v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint64_t row = base + (uint64_t)u * RW + rslot;
+            const float v_off = offsets[row];  // padded like codes[]
+            float mine = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int it = 0; it < ITERS; it++)
+                    acc = IS_L1 ? sad16(v[u][it], q[j][it], acc) : dot16(v[u][it], q[j][it], acc);
+                acc = group_sum<G>(acc);
+                if (sub == j) mine = epilogue(multiplier, acc, q_off, v_off, 0.0f, EPI_POINT);
+            }
+            if ((uint32_t)sub < nq_valid && row < n_rows) {
+                if (FILTER) {
+                    const TopkFilter f = topk_filter_of(slices, (uint32_t)sub);
+                    topk_offer(f, *f.pivot_key, mine, (uint32_t)row);
+                } else {
+                    __builtin_nontemporal_store(mine, out + (uint64_t)sub * out_pitch + row);
+                }
+            }
+        }
+    }
+}
+
 // Single-launch top-k for small stores (topk.hpp small_topk): workgroup b scores rows
 // [b * rows_per_wg, (b + 1) * rows_per_wg) exactly like u8_scan_kernel (same loads, same integer
 // sum, same f32 epilogue => the same score bits), but a score never goes to HBM: it becomes a
@@ -889,6 +968,60 @@ qamd_status launch_small(const qamd_u8 *h, const uint4 *qc, const float *qo, con
         default: break;
     }
     return fail(QAMD_ERR_ARGUMENTS, "no small top-k kernel for %u chunks", rc);
+}
+
+// ---- several queries per pass (u8_scan_multi_kernel) -------------------------------------------
+template <bool IS_L1, int G, int ITERS, int UNROLL, int NQ>
+void launch_multi_shape(const qamd_u8 *h, const uint8_t *qcodes, uint64_t q_pitch, const float *q_offs, uint32_t nq_valid,
+                        float *out, const TopkFilterSlices *slices, hipStream_t s) {
+    constexpr int TILE = (64 / G) * UNROLL * NQ;  // NQ tiles per wave (u8_scan_multi_kernel TPW)
+    const uint64_t waves = (h->count + TILE - 1) / TILE;
+    const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
+    const bool exact = h->row_chunks == (uint32_t)(G * ITERS);
+#define QAMD_U8_MULTI(EX, FI)                                                                                      \
+    hipLaunchKernelGGL((u8_scan_multi_kernel<G, ITERS, UNROLL, NQ, IS_L1, EX, FI>), dim3(grid), dim3(kScanBlock), 0, s, \
+                       h->codes.as<uint4>(), h->offsets.as<float>(), qcodes, (uint32_t)q_pitch, q_offs, nq_valid,   \
+                       h->meta.multiplier, (uint32_t)h->count, h->row_chunks, out, (uint64_t)h->count,             \
+                       slices ? *slices : TopkFilterSlices{})
+    if (slices) {
+        if (exact) QAMD_U8_MULTI(true, true);
+        else QAMD_U8_MULTI(false, true);
+    } else {
+        if (exact) QAMD_U8_MULTI(true, false);
+        else QAMD_U8_MULTI(false, false);
+    }
+#undef QAMD_U8_MULTI
+}
+
+// Widest pass of the multi-query scan for this row size: 4 queries (2 for rows of more than 96
+// pieces), 0 = none.  Measured on 10M x 768 / 12.5M x 1536, top-30 per query, whole call: 2 queries
+// 1.24 / 2.93 ms and 4 queries 1.38 / 3.50 ms against 1.65 / 3.85 ms on the matrix-core path; an
+// 8-wide pass (96 query VGPRs, 3 waves per SIMD) took 1.97 ms at dim 768 -- worse than the matrix
+// cores -- so batches of 5 and more stay there.
+uint32_t multi_width(const qamd_u8 *h) {
+    const uint32_t rc = h->row_chunks, iters = (rc + 15) / 16;
+    if (rc < 9 || iters > 8 || (h->lane_mode != 0 && h->meta.vector_parameters.distance_type != QAMD_L1)) return 0;
+    return iters <= 6 ? 4 : 2;
+}
+
+// One pass for `nq_valid` (2 .. multi_width) queries; false = unsupported.
+template <bool IS_L1>
+bool launch_multi(const qamd_u8 *h, uint32_t nq_valid, const uint8_t *qcodes, uint64_t q_pitch, const float *q_offs,
+                  float *out, const TopkFilterSlices *slices, hipStream_t s) {
+    const uint32_t iters = (h->row_chunks + 15) / 16, width = multi_width(h);
+    if (nq_valid < 2 || nq_valid > width) return false;
+#define QAMD_U8_MULTI_IT(IT, UN)                                                                              \
+    case IT:                                                                                                  \
+        if (nq_valid > 2) launch_multi_shape<IS_L1, 16, IT, UN, (IT <= 6 ? 4 : 2)>(h, qcodes, q_pitch, q_offs, nq_valid, out, slices, s); \
+        else launch_multi_shape<IS_L1, 16, IT, UN, 2>(h, qcodes, q_pitch, q_offs, nq_valid, out, slices, s);  \
+        return true;
+    switch (iters) {
+        QAMD_U8_MULTI_IT(1, 4) QAMD_U8_MULTI_IT(2, 2) QAMD_U8_MULTI_IT(3, 2) QAMD_U8_MULTI_IT(4, 2)
+        QAMD_U8_MULTI_IT(5, 1) QAMD_U8_MULTI_IT(6, 1) QAMD_U8_MULTI_IT(7, 1) QAMD_U8_MULTI_IT(8, 1)
+        default: break;
+    }
+#undef QAMD_U8_MULTI_IT
+    return false;
 }
 
 bool fused_capable(const qamd_u8 *h) {
@@ -1867,7 +2000,47 @@ qamd_status u8_topk_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint
     scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
         return score_ids_dev(h, qc(q), offsets_dev + q, 0.0f, EPI_POINT, ids, n_ids, out, st);
     };
+    const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+    const uint32_t width = multi_width(h);
+    if (width)  // one filtering pass over the rows for up to `width` queries
+        scan.scan_filter_multi = [&, width, is_l1](uint32_t q, uint32_t left, const TopkFilterSlices &sl, hipStream_t st,
+                                                   qamd_status &status) -> uint32_t {
+            const uint32_t nq = std::min(left, width);
+            if (nq < 2) return 0;
+            const uint8_t *qcodes = codes_dev + (uint64_t)q * pitch;
+            const bool ok = is_l1 ? launch_multi<true>(h, nq, qcodes, pitch, offsets_dev + q, nullptr, &sl, st)
+                                  : launch_multi<false>(h, nq, qcodes, pitch, offsets_dev + q, nullptr, &sl, st);
+            if (ok && hipGetLastError() != hipSuccess) status = fail(QAMD_ERR_DEVICE, "u8 multi-query filter launch failed");
+            return ok ? nq : 0;
+        };
     return fused_topk_batch(h->count, n_queries, k, largest, out_ids, out_scores, out_mem, stream, scan);
+}
+
+// How many queries the vector-ALU multi-query scan takes per pass for this store (0: none).
+uint32_t u8_multi_width(const qamd_u8 *h) { return multi_width(h); }
+
+// out[j * count + row] for queries [0, n_queries) of a batch through the multi-query scan (groups of
+// `width`, then smaller groups, then single scans).
+qamd_status u8_score_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
+                                 uint32_t n_queries, float *out_dev, hipStream_t stream) {
+    const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+    const uint32_t width = multi_width(h);
+    uint32_t q = 0;
+    while (q < n_queries) {
+        const uint32_t nq = std::min(width, n_queries - q);
+        const uint8_t *qcodes = codes_dev + (uint64_t)q * pitch;
+        float *o = out_dev + (uint64_t)q * h->count;
+        const bool ok = nq >= 2 && (is_l1 ? launch_multi<true>(h, nq, qcodes, pitch, offsets_dev + q, o, nullptr, stream)
+                                          : launch_multi<false>(h, nq, qcodes, pitch, offsets_dev + q, o, nullptr, stream));
+        if (ok) {
+            q += nq;
+        } else {
+            QAMD_TRY(scan_ptrs(h, reinterpret_cast<const uint4 *>(qcodes), offsets_dev + q, o, stream));
+            q += 1;
+        }
+    }
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
 }
 
 // Exact single-query top-k for one member of a query batch (its per-query fallback): no copy, no

@@ -1016,11 +1016,12 @@ qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, 
         QAMD_TRY(tmp.alloc(total * 4));
         out_dev = tmp.as<float>();
     }
-    if (h->meta.vector_parameters.distance_type == QAMD_L1) {
-        // sum |q - v| is not a contraction: no MFMA form; the batch API loops the single-query scan
-        for (uint64_t q = 0; q < b->n_queries; q++)
-            QAMD_TRY(u8_score_single(h, b->codes.as<uint8_t>() + q * b->pitch, b->offsets.as<float>() + q,
-                                     out_dev + q * h->count, s));
+    const uint32_t width = u8_multi_width(h);
+    if (h->meta.vector_parameters.distance_type == QAMD_L1 || (width && b->n_queries >= 2 && b->n_queries <= width)) {
+        // sum |q - v| is not a contraction (no MFMA form), and for a handful of queries the vector-ALU
+        // multi-query scan streams the rows faster than the matrix-core kernel's LDS-DMA path
+        QAMD_TRY(u8_score_batch_scans(h, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), (uint32_t)b->n_queries,
+                                      out_dev, s));
     } else {
         QAMD_TRY(launch_gemm<0>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), h->count, out_dev, h->count,
                                 BatchFilter{}, s));
@@ -1038,10 +1039,12 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     const uint64_t Q = b->n_queries, n = h->count;
-    if (h->meta.vector_parameters.distance_type == QAMD_L1 && n > (2u << 20))
-        // no matrix form for L1; above the single-launch top-k's range the per-query fused scans run
-        // back to back with one status read-back per 32 queries (below it the loop further down
-        // only enqueues)
+    const bool l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+    if (n > (2u << 20) && (l1 || (Q <= u8_multi_width(h) && Q >= 2)))
+        // L1 has no matrix form; and a handful of queries (one pass of the vector-ALU multi-query scan)
+        // stream the rows at the single-query scan's rate, which the matrix-core kernel's LDS-DMA
+        // path does not reach.  Per-query sample + pivot, ONE filtering pass per group of queries, one
+        // status read-back per 32 queries.
         return u8_topk_batch_scans(h, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), (uint32_t)Q, k, largest,
                                    out_ids, out_scores, out_mem, s);
     // Pivot rank r of S sampled rows: the number of rows at least as good as the pivot is about

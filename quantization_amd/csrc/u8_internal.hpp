@@ -45,6 +45,9 @@ qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float
 qamd_status u8_topk_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
                                 uint32_t n_queries, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
                                 qamd_mem out_mem, hipStream_t stream);
+uint32_t u8_multi_width(const qamd_u8 *h);
+qamd_status u8_score_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
+                                 uint32_t n_queries, float *out_dev, hipStream_t stream);
 qamd_status u8_score_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, float *out_dev,
                             hipStream_t stream);
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,

@@ -234,3 +234,39 @@ def test_topk_batch_l1_large_store_runs_back_to_back_fused_scans():
     for qi in (0, 1, 17, 31, 32, 34):
         wi, ws = enc.topk(enc.encode_query(queries[qi]), 20, largest=False)
         assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), qi
+
+
+@pytest.mark.parametrize("dim,nq,dist", [(192, 4, D.Dot), (768, 3, D.Dot), (768, 2, D.L2), (1024, 4, D.Dot), (1024, 3, D.L1),
+                                         (2000, 2, D.Dot), (768, 7, D.L1), (768, 8, D.Dot)])
+def test_handful_of_queries_take_the_vector_alu_multi_query_scan(dim, nq, dist, qo):
+    """2 .. 4 queries (any number for L1) over a store above 2M rows: passes of u8_scan_multi_kernel
+    (queries in registers, rows streamed once per pass; 3 queries ride in a 4-wide pass) for score_batch
+    and for the filtering scan of topk_batch — bit-identical to the single-query calls and to the oracle
+    on sampled rows.  (8 Dot queries take the matrix-core path: same check.)"""
+    torch = pytest.importorskip("torch")
+    n = 2_200_003
+    g = torch.Generator(device="cuda")
+    g.manual_seed(dim + nq)
+    data = torch.rand((n, dim), generator=g, device="cuda")
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, False))
+    md = enc.metadata
+    queries = np.random.default_rng(dim).random((nq, dim), dtype=np.float32)
+    batch = enc.encode_query_batch(queries)
+    out = torch.empty(nq * n, dtype=torch.float32, device="cuda")
+    enc.score_batch(batch, out=out)
+    largest = dist == D.Dot
+    ids, sc = enc.topk_batch(batch, 30, largest=largest)
+    torch.cuda.synchronize()
+    sb = out.view(nq, n)
+    rows_idx = torch.randint(0, n, (2000,), generator=g, device="cuda")
+    o_rows, o_meta = qo.u8_encode_with(data[rows_idx].cpu().numpy(), int(dist), False, float(md["alpha"]), float(md["offset"]))
+    for qi in range(nq):
+        q = enc.encode_query(queries[qi])
+        single = enc.score_all(q, out=torch.empty(n, dtype=torch.float32, device="cuda"))
+        assert torch.equal(sb[qi], single), f"score_batch query {qi}"
+        wi, ws = enc.topk(q, 30, largest=largest)
+        assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), qi
+        codes, qoff = qo.u8_encode_query(o_meta, queries[qi])
+        order = qo.ORDER_AVX2 if md["actual_dim"] <= 1040 else qo.ORDER_SIMPLE
+        assert_bits_equal(sb[qi][rows_idx].cpu().numpy(), qo.u8_score_all(o_meta, o_rows, codes, qoff, order=order),
+                          f"query {qi} vs oracle")
