@@ -204,3 +204,39 @@ def test_u8_sharded_on_two_real_devices():
     sh.score_all(qs, out=out)
     assert_bits_equal(out.cpu().numpy(), one.score_all(q1), "two devices, device out (peer copies)")
     _same_topk(sh.topk(qs, 30), one.topk(q1, 30))
+
+
+def test_sharded_handle_serialises_concurrent_callers():
+    """A sharded handle fans one call out at a time; callers on several threads must still each get
+    their own exact answer (the per-call exchange buffers are guarded)."""
+    import threading
+
+    rng = np.random.default_rng(12)
+    n, dim = 120_000, 64
+    data = rng.random((n, dim), dtype=np.float32)
+    vp = qa.VectorParameters(dim, n, D.Dot, False)
+    one = qa.EncodedVectorsU8.encode(data, vp)
+    sh = qa.ShardedVectorsU8.encode(data, vp, [0] * 4)
+    queries = rng.random((6, dim), dtype=np.float32)
+    want = [one.topk(one.encode_query(q), 20) for q in queries]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(15):
+                qs = sh.encode_query(queries[i])
+                ids, sc = sh.topk(qs, 20)
+                if not (np.array_equal(ids, want[i][0]) and np.array_equal(sc.view(np.uint32), want[i][1].view(np.uint32))):
+                    errors.append(i)
+                s_all = sh.score_all(qs)
+                if not np.array_equal(s_all.view(np.uint32), one.score_all(one.encode_query(queries[i])).view(np.uint32)):
+                    errors.append(100 + i)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

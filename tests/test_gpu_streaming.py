@@ -140,3 +140,32 @@ def test_pq_stream_equals_one_shot_and_oracle(qo):
     assert np.array_equal(st3.storage_bytes(), qo.pq_encode(small, chunk, st3.centroids))
     z = qa.EncodedVectorsPQ.encode_stream(lambda: iter(()), qa.VectorParameters(dim, 0, D.Dot, False), chunk)
     assert z.count == 0
+
+
+def test_aborted_and_failed_encoders_give_their_memory_back():
+    """An encoder that is aborted (stop_condition, an exception in the caller's iterator, a count
+    mismatch at finish) frees the store it was building."""
+    rng = np.random.default_rng(9)
+    n, dim = 400_000, 256  # ~100 MB of codes per store
+    data = rng.random((20_000, dim), dtype=np.float32)
+    vp = qa.VectorParameters(dim, n, D.Dot, False)
+
+    def free_now():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    def bad_iter():
+        yield data
+        raise RuntimeError("the caller's iterator failed")
+
+    base = free_now()
+    for _ in range(5):
+        with pytest.raises(RuntimeError, match="iterator failed"):
+            qa.EncodedVectorsU8.encode_stream(bad_iter, vp, alpha_offset=(0.01, 0.0))
+        with pytest.raises(qa.EncodingError):  # 20 000 of 400 000 rows pushed
+            qa.EncodedVectorsU8.encode_stream(lambda: iter([data]), vp, alpha_offset=(0.01, 0.0))
+        with pytest.raises(qa.EncodingError):
+            qa.EncodedVectorsBin.encode_stream(lambda: iter([data]), vp)
+        with pytest.raises(qa.EncodingError):
+            qa.EncodedVectorsPQ.encode_stream(lambda: iter([data]), vp, 8, centroids=rng.random((256, dim), dtype=np.float32))
+    assert abs(free_now() - base) < (32 << 20), "aborted encoders leaked device memory"
