@@ -427,6 +427,15 @@ def main():
             qa.topk_scores(out, n, args.k, largest=True, out_ids=ids, out_scores=sc)
             topk.exchange(largest=True)
 
+    # set-up, like the encode above: a few untimed passes so that the W warm-up steps and the K timed
+    # steps start from a ramped clock and warm allocator pools (the first ~10 launches of a new shape
+    # measured 5-20 % slower); they use the plain score buffer and take part in no exchange
+    prewarm = torch.empty(max(n_max, 1), dtype=torch.float32, device=dev)
+    for i in range(20):
+        encode(i, stream)
+        f_score(h_store, h_query[i % 2], C.c_void_p(prewarm.data_ptr()), _lib.MEM_DEVICE, stream)
+    torch.cuda.synchronize()
+    del prewarm
     for i in range(args.warmup):
         step(i, False, first=(i == 0), last=(i == args.warmup - 1))
     if gather is not None:
