@@ -517,14 +517,24 @@ __global__ __launch_bounds__(kCentroids) void km_group_kernel(const uint8_t *__r
                                                              uint32_t m, const int *__restrict__ done,
                                                              uint32_t *__restrict__ order /*[m][S]*/,
                                                              uint32_t *__restrict__ start /*[m][257]*/) {
-    extern __shared__ uint8_t col[];  // S bytes
+    extern __shared__ __attribute__((aligned(16))) uint8_t col[];  // S bytes (+ padding to a whole dword)
     __shared__ uint32_t cum[kCentroids];
     const uint32_t c = blockIdx.x, kc = threadIdx.x;
     if (done[c]) return;  // uniform per workgroup
-    for (uint32_t s0 = kc; s0 < S; s0 += kCentroids) col[s0] = assign[(size_t)s0 * m + c];
+    const uint32_t S4 = (S + 3) / 4;
+    for (uint32_t s0 = kc; s0 < S4 * 4; s0 += kCentroids) col[s0] = s0 < S ? assign[(size_t)s0 * m + c] : 0;
     __syncthreads();
+    // every thread scans the whole column (an LDS broadcast read per dword, four rows each); rows past S
+    // sit in the padding of the last dword and are masked out
+    const uint32_t *col32 = reinterpret_cast<const uint32_t *>(col);
+    auto hits = [&](uint32_t w, uint32_t x) -> uint32_t {  // bit b set: row 4w + b is assigned to kc
+        uint32_t h = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) h |= (((x >> (8 * b)) & 255u) == kc && 4 * w + b < S) ? (1u << b) : 0u;
+        return h;
+    };
     uint32_t n = 0;
-    for (uint32_t s0 = 0; s0 < S; s0++) n += col[s0] == kc ? 1u : 0u;
+    for (uint32_t w = 0; w < S4; w++) n += __builtin_popcount(hits(w, col32[w]));
     cum[kc] = n;
     __syncthreads();
     for (int off = 1; off < kCentroids; off <<= 1) {  // inclusive scan
@@ -537,8 +547,12 @@ __global__ __launch_bounds__(kCentroids) void km_group_kernel(const uint8_t *__r
     start[(size_t)c * (kCentroids + 1) + kc] = pos;
     if (kc == kCentroids - 1) start[(size_t)c * (kCentroids + 1) + kCentroids] = cum[kc];
     uint32_t *dst = order + (size_t)c * S;
-    for (uint32_t s0 = 0; s0 < S; s0++)
-        if (col[s0] == kc) dst[pos++] = s0;
+    for (uint32_t w = 0; w < S4; w++) {
+        const uint32_t h = hits(w, col32[w]);
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++)
+            if (h & (1u << b)) dst[pos++] = 4 * w + b;
+    }
 }
 
 // Step 2: one thread per centroid value: f64 sums with the reference's partial boundaries, mean,
@@ -908,7 +922,7 @@ qamd_status train_from_sample(qamd_pq *h, const float *sample, uint32_t S, qamd_
         if (cs) QAMD_TRY(build_pair_table(cen.as<float>(), dim, h->chunk_size, m, pair_table, s));
         QAMD_TRY(launch_assign(sample, S, dim, h->chunk_size, m, cen.as<float>(), &pair_table, assign.as<uint8_t>(), m,
                                0, s));
-        hipLaunchKernelGGL(km_group_kernel, dim3(m), dim3(kCentroids), S, s, assign.as<uint8_t>(), S, m, done.as<int>(),
+        hipLaunchKernelGGL(km_group_kernel, dim3(m), dim3(kCentroids), round_up(S, 4), s, assign.as<uint8_t>(), S, m, done.as<int>(),
                            order.as<uint32_t>(), start.as<uint32_t>());
         hipLaunchKernelGGL(km_update_kernel, dim3((uint32_t)((ncen + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, sample, S,
                            (uint32_t)dim, (uint32_t)h->chunk_size, m, workers, cen.as<float>(), done.as<int>(),
