@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "multi_reduce.hpp"
 #include "topk.hpp"
 #include "topk_device.hpp"
 
@@ -179,24 +180,26 @@ __global__ __launch_bounds__(kScanBlock) void bin_scan_multi_kernel(const uint4 
             v[u][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
         }
     }
+    // lane (row slot, sub) ends up with the total of query multi_query_of<NQ>(sub) (multi_reduce.hpp):
+    // the lanes whose sub is below NQ own one query each
+    const int my_q = multi_query_of<NQ>(sub);
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
-        float mine = 0.0f;
+        uint32_t acc[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; j++) {
-            uint32_t acc = 0;
+            acc[j] = 0;
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) acc = xpop16(v[u][it], q[j][it], acc);
-            acc = group_sum<G>(acc);
-            if (sub == j) mine = metric(acc, dim_f, is_dot, invert);
+            for (int it = 0; it < ITERS; it++) acc[j] = xpop16(v[u][it], q[j][it], acc[j]);
         }
+        const float mine = metric(multi_reduce<G, NQ>(acc, sub), dim_f, is_dot, invert);
         const uint64_t row = base + (uint64_t)u * RW + rslot;
         if (sub < NQ && row < n_rows) {
             if (FILTER) {
-                const TopkFilter f = topk_filter_of(slices, (uint32_t)sub);
+                const TopkFilter f = topk_filter_of(slices, (uint32_t)my_q);
                 topk_offer(f, *f.pivot_key, mine, (uint32_t)row);  // the pivot is an L2-resident word, re-read per row slot
             } else {
-                __builtin_nontemporal_store(mine, out + (uint64_t)sub * out_pitch + row);
+                __builtin_nontemporal_store(mine, out + (uint64_t)my_q * out_pitch + row);
             }
         }
     }

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "multi_reduce.hpp"
 #include "topk.hpp"
 #include "topk_device.hpp"
 #include "u8_internal.hpp"
@@ -233,7 +234,10 @@ __global__ __launch_bounds__(kScanBlock) void u8_scan_multi_kernel(
             q[j][it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
         }
     }
-    const float q_off = q_offs[(uint32_t)sub < nq_valid ? sub : 0];
+    // lane (row slot, sub) ends up with the total of query multi_query_of<NQ>(sub) (multi_reduce.hpp)
+    const int my_q = multi_query_of<NQ>(sub);
+    const bool owner = sub < NQ && (uint32_t)my_q < nq_valid;
+    const float q_off = q_offs[owner ? my_q : 0];
     for (int tile = 0; tile < TPW; tile++) {
         const uint64_t base = (wave * TPW + tile) * TILE;
         if (base >= n_rows) break;
@@ -253,22 +257,21 @@ __global__ __launch_bounds__(kScanBlock) void u8_scan_multi_kernel(
         for (int u = 0; u < UNROLL; u++) {
             const uint64_t row = base + (uint64_t)u * RW + rslot;
             const float v_off = offsets[row];  // padded like codes[]
-            float mine = 0.0f;
+            uint32_t acc[NQ];
 #pragma unroll
             for (int j = 0; j < NQ; j++) {
-                uint32_t acc = 0;
+                acc[j] = 0;
 #pragma unroll
                 for (int it = 0; it < ITERS; it++)
-                    acc = IS_L1 ? sad16(v[u][it], q[j][it], acc) : dot16(v[u][it], q[j][it], acc);
-                acc = group_sum<G>(acc);
-                if (sub == j) mine = epilogue(multiplier, acc, q_off, v_off, 0.0f, EPI_POINT);
+                    acc[j] = IS_L1 ? sad16(v[u][it], q[j][it], acc[j]) : dot16(v[u][it], q[j][it], acc[j]);
             }
-            if ((uint32_t)sub < nq_valid && row < n_rows) {
+            const float mine = epilogue(multiplier, multi_reduce<G, NQ>(acc, sub), q_off, v_off, 0.0f, EPI_POINT);
+            if (owner && row < n_rows) {
                 if (FILTER) {
-                    const TopkFilter f = topk_filter_of(slices, (uint32_t)sub);
+                    const TopkFilter f = topk_filter_of(slices, (uint32_t)my_q);
                     topk_offer(f, *f.pivot_key, mine, (uint32_t)row);
                 } else {
-                    __builtin_nontemporal_store(mine, out + (uint64_t)sub * out_pitch + row);
+                    __builtin_nontemporal_store(mine, out + (uint64_t)my_q * out_pitch + row);
                 }
             }
         }
