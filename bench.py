@@ -181,17 +181,19 @@ def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
 def pmc_traffic(quantizer, n, bytes_per_row):
     """HBM bytes per launch from a committed rocprofv3 --pmc profile of THIS workload and kernel
     source (profiles/r*_pmc_u8_scan.json names the commit it was taken at and a hash of the kernel
-    source file; a profile of other code is not quoted)."""
+    source: the part of csrc/u8.hip that defines u8_scan_kernel; a profile of other code is not quoted)."""
     import glob
-    import hashlib
 
     if quantizer != "u8":
         return None, None
     try:
-        src = open(os.path.join(ROOT, "quantization_amd", "csrc", "u8.hip"), "rb").read()
-        src_hash = hashlib.sha256(src).hexdigest()[:16]
-    except OSError:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from summarize import kernel_source_hash  # the one definition of "the source that was profiled"
+        src_hash = kernel_source_hash(ROOT)
+    except Exception:
         return None, None
+    finally:
+        sys.path.pop(0)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_u8_scan.json")), reverse=True):
         try:
             j = json.load(open(path))

@@ -21,11 +21,18 @@ def short(name: str, n: int = 110) -> str:
     return name if len(name) <= n else name[:n] + "..."
 
 
-def kernel_source_hash() -> str:
+def kernel_source_hash(root=None):
+    import os as _os
+    root = root or _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    """Hash of the part of csrc/u8.hip that defines u8_scan_kernel (device helpers + the kernel):
+    edits elsewhere in the file do not void a PMC profile of that kernel."""
     import hashlib
     import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return hashlib.sha256(open(os.path.join(root, "quantization_amd", "csrc", "u8.hip"), "rb").read()).hexdigest()[:16]
+    src = open(os.path.join(root, "quantization_amd", "csrc", "u8.hip"), "rb").read()
+    a = src.find(b"// ------------------------------------------------------------------------------ device helpers")
+    b = src.find(b"// NQ (2, 4, 8) queries per row read on the vector ALU")
+    region = src[a:b] if 0 <= a < b else src
+    return hashlib.sha256(region).hexdigest()[:16]
 
 
 def stats(src, dst):
