@@ -72,6 +72,11 @@ def test_no_cpu_fallback_fails_loudly():
         lambda: qa.EncodedVectorsU8.encode(data, qa.VectorParameters(16, 4, qa.DistanceType.Dot, False)),
         lambda: qa.EncodedVectorsBin.encode(data, qa.VectorParameters(16, 4, qa.DistanceType.Dot, False)),
         lambda: qa.EncodedVectorsPQ.encode(data, qa.VectorParameters(16, 4, qa.DistanceType.Dot, False), 4),
+        # round 2 entry points: streaming encoders and row-sharded handles
+        lambda: qa.EncodedVectorsU8.encode_stream(lambda: iter([data]), qa.VectorParameters(16, 4, qa.DistanceType.Dot, False)),
+        lambda: qa.EncodedVectorsBin.encode_stream(lambda: iter([data]), qa.VectorParameters(16, 4, qa.DistanceType.Dot, False)),
+        lambda: qa.ShardedVectorsU8.encode(data, qa.VectorParameters(16, 4, qa.DistanceType.Dot, False), [0, 0]),
+        lambda: qa.ShardedVectorsBin.encode(data, qa.VectorParameters(16, 4, qa.DistanceType.Dot, False), [0]),
     ):
         with pytest.raises(qa.EncodingError) as e:
             make()
