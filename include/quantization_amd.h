@@ -444,6 +444,15 @@ QAMD_API qamd_status qamd_bin_sharded_score_all(qamd_bin_sharded *h, const qamd_
 QAMD_API qamd_status qamd_bin_sharded_topk(qamd_bin_sharded *h, const qamd_bin_sharded_query *q, uint32_t k,
                                            int largest, uint32_t *out_ids, float *out_scores,
                                            qamd_mem out_mem);
+typedef struct qamd_bin_sharded_query_batch qamd_bin_sharded_query_batch;
+QAMD_API qamd_status qamd_bin_sharded_encode_query_batch(qamd_bin_sharded *h, const float *queries,
+                                                         uint64_t n_queries, uint64_t qdim,
+                                                         qamd_mem queries_mem,
+                                                         qamd_bin_sharded_query_batch **batch_io);
+QAMD_API void qamd_bin_sharded_query_batch_free(qamd_bin_sharded_query_batch *b);
+QAMD_API qamd_status qamd_bin_sharded_topk_batch(qamd_bin_sharded *h, const qamd_bin_sharded_query_batch *b,
+                                                 uint32_t k, int largest, uint32_t *out_ids,
+                                                 float *out_scores, qamd_mem out_mem);
 QAMD_API void qamd_bin_sharded_free(qamd_bin_sharded *h);
 
 typedef struct qamd_pq_sharded qamd_pq_sharded;
@@ -470,6 +479,15 @@ QAMD_API qamd_status qamd_pq_sharded_score_all(qamd_pq_sharded *h, const qamd_pq
 QAMD_API qamd_status qamd_pq_sharded_topk(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, uint32_t k,
                                           int largest, uint32_t *out_ids, float *out_scores,
                                           qamd_mem out_mem);
+typedef struct qamd_pq_sharded_query_batch qamd_pq_sharded_query_batch;
+QAMD_API qamd_status qamd_pq_sharded_encode_query_batch(qamd_pq_sharded *h, const float *queries,
+                                                        uint64_t n_queries, uint64_t qdim,
+                                                        qamd_mem queries_mem,
+                                                        qamd_pq_sharded_query_batch **batch_io);
+QAMD_API void qamd_pq_sharded_query_batch_free(qamd_pq_sharded_query_batch *b);
+QAMD_API qamd_status qamd_pq_sharded_topk_batch(qamd_pq_sharded *h, const qamd_pq_sharded_query_batch *b,
+                                                uint32_t k, int largest, uint32_t *out_ids,
+                                                float *out_scores, qamd_mem out_mem);
 QAMD_API void qamd_pq_sharded_free(qamd_pq_sharded *h);
 
 /* ===================================================================================

@@ -178,6 +178,9 @@ def lib() -> C.CDLL:
         "qamd_bin_sharded_query_free": (None, [vp]),
         "qamd_bin_sharded_score_all": (i32, [vp, vp, vp, i32]),
         "qamd_bin_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_bin_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, pp]),
+        "qamd_bin_sharded_query_batch_free": (None, [vp]),
+        "qamd_bin_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32]),
         "qamd_bin_sharded_free": (None, [vp]),
         "qamd_pq_sharded_encode": (i32, [vp, i32, VP, u64, vp, u32, STOP_FN, vp, C.POINTER(i32), u32, pp]),
         "qamd_pq_sharded_from_rows": (i32, [vp, i32, VP, u64, vp, C.POINTER(i32), u32, pp]),
@@ -188,6 +191,9 @@ def lib() -> C.CDLL:
         "qamd_pq_sharded_query_free": (None, [vp]),
         "qamd_pq_sharded_score_all": (i32, [vp, vp, vp, i32]),
         "qamd_pq_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_pq_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, pp]),
+        "qamd_pq_sharded_query_batch_free": (None, [vp]),
+        "qamd_pq_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32]),
         "qamd_pq_sharded_free": (None, [vp]),
         "qamd_topk_scores": (i32, [vp, u64, u32, i32, vp, vp, i32, vp]),
         "qamd_topk_merge": (i32, [vp, vp, u64, vp, u32, u32, u32, i32, vp, vp, i32, vp]),

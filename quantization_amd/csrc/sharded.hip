@@ -504,6 +504,40 @@ qamd_status merge_lists(const uint32_t *ids, const float *scores, uint64_t shard
     return st;
 }
 
+// Query batches behind a sharded handle: one per-shard batch object each (the queries are replicated),
+// encoded by the shards' workers; identical shapes for the three quantizers.
+template <class B> struct ShardedBatch {
+    std::vector<B *> per_shard;
+    uint64_t n_queries = 0;
+    void (*free_fn)(B *) = nullptr;
+    ~ShardedBatch() {
+        for (B *b : per_shard)
+            if (b && free_fn) free_fn(b);
+    }
+};
+
+template <class S, class B, class EncodeFn>
+qamd_status sharded_encode_query_batch(S *h, const float *queries, uint64_t n_queries, uint64_t qdim, qamd_mem queries_mem,
+                                       ShardedBatch<B> *b, EncodeFn encode) {
+    if (b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "batch belongs to another sharded store");
+    const int src_dev = queries_mem == QAMD_MEM_DEVICE ? device_of(queries) : -1;
+    const size_t bytes = (size_t)n_queries * qdim * 4;
+    std::lock_guard<std::mutex> lk(h->pool.call);
+    QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
+        const float *src = queries;
+        if (queries_mem == QAMD_MEM_DEVICE && src_dev != w.device && bytes) {  // device queries live on ONE GPU
+            if (h->query_stage[g].bytes < bytes) QAMD_TRY(h->query_stage[g].alloc(bytes));
+            QAMD_HIP(hipMemcpyAsync(h->query_stage[g].ptr, queries, bytes, hipMemcpyDefault, w.stream));
+            src = h->query_stage[g].template as<float>();
+        }
+        QAMD_TRY(encode(h->shards[g], src, n_queries, qdim, queries_mem, w.stream, &b->per_shard[g]));
+        QAMD_HIP(hipStreamSynchronize(w.stream));
+        return QAMD_OK;
+    }));
+    b->n_queries = n_queries;
+    return QAMD_OK;
+}
+
 const Ops<qamd_u8, qamd_u8_query> kU8Ops = {qamd_u8_encode_query, qamd_u8_query_free, qamd_u8_score_all, qamd_u8_topk,
                                             qamd_u8_free};
 const Ops<qamd_bin, qamd_bin_query> kBinOps = {qamd_bin_encode_query, qamd_bin_query_free, qamd_bin_score_all,
@@ -517,14 +551,9 @@ struct qamd_u8_sharded : Sharded<qamd_u8, qamd_u8_query> {
     qamd_u8_metadata meta{};
 };
 struct qamd_u8_sharded_query : ShardedQuery<qamd_u8, qamd_u8_query> {};
-struct qamd_u8_sharded_query_batch {
-    std::vector<qamd_u8_query_batch *> per_shard;
-    uint64_t n_queries = 0;
-    ~qamd_u8_sharded_query_batch() {
-        for (auto *b : per_shard)
-            if (b) qamd_u8_query_batch_free(b);
-    }
-};
+struct qamd_u8_sharded_query_batch : ShardedBatch<qamd_u8_query_batch> {};
+struct qamd_bin_sharded_query_batch : ShardedBatch<qamd_bin_query_batch> {};
+struct qamd_pq_sharded_query_batch : ShardedBatch<qamd_pq_query_batch> {};
 struct qamd_bin_sharded : Sharded<qamd_bin, qamd_bin_query> {
     qamd_vector_parameters vp{};
     int store = 0;
@@ -700,26 +729,9 @@ qamd_status qamd_u8_sharded_encode_query_batch(qamd_u8_sharded *h, const float *
         fresh.reset(new qamd_u8_sharded_query_batch);
         b = fresh.get();
         b->per_shard.assign(h->G(), nullptr);
+        b->free_fn = qamd_u8_query_batch_free;
     }
-    if (b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "batch belongs to another sharded store");
-    const int src_dev = queries_mem == QAMD_MEM_DEVICE ? device_of(queries) : -1;
-    const size_t bytes = (size_t)n_queries * qdim * 4;
-    {
-        std::lock_guard<std::mutex> lk(h->pool.call);
-        QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
-            const float *src = queries;
-            if (queries_mem == QAMD_MEM_DEVICE && src_dev != w.device && bytes) {
-                if (h->query_stage[g].bytes < bytes) QAMD_TRY(h->query_stage[g].alloc(bytes));
-                QAMD_HIP(hipMemcpyAsync(h->query_stage[g].ptr, queries, bytes, hipMemcpyDefault, w.stream));
-                src = h->query_stage[g].as<float>();
-            }
-            QAMD_TRY(qamd_set_device(w.device));
-            QAMD_TRY(qamd_u8_encode_query_batch(h->shards[g], src, n_queries, qdim, queries_mem, w.stream, &b->per_shard[g]));
-            QAMD_HIP(hipStreamSynchronize(w.stream));
-            return QAMD_OK;
-        }));
-    }
-    b->n_queries = n_queries;
+    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, b, qamd_u8_encode_query_batch));
     if (fresh) *batch_io = fresh.release();
     return QAMD_OK;
 }
@@ -833,6 +845,35 @@ qamd_status qamd_bin_sharded_topk(qamd_bin_sharded *h, const qamd_bin_sharded_qu
                                   uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
     return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+}
+
+qamd_status qamd_bin_sharded_encode_query_batch(qamd_bin_sharded *h, const float *queries, uint64_t n_queries,
+                                                uint64_t qdim, qamd_mem queries_mem,
+                                                qamd_bin_sharded_query_batch **batch_io) {
+    if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_bin_sharded_query_batch> fresh;
+    qamd_bin_sharded_query_batch *b = *batch_io;
+    if (!b) {
+        fresh.reset(new qamd_bin_sharded_query_batch);
+        b = fresh.get();
+        b->per_shard.assign(h->G(), nullptr);
+        b->free_fn = qamd_bin_query_batch_free;
+    }
+    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, b, qamd_bin_encode_query_batch));
+    if (fresh) *batch_io = fresh.release();
+    return QAMD_OK;
+}
+
+void qamd_bin_sharded_query_batch_free(qamd_bin_sharded_query_batch *b) { delete b; }
+
+qamd_status qamd_bin_sharded_topk_batch(qamd_bin_sharded *h, const qamd_bin_sharded_query_batch *b, uint32_t k, int largest,
+                                        uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+    if (!h || !b || b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "null or foreign argument");
+    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem,
+                          [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
+                              return qamd_bin_topk_batch(h->shards[g], b->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE,
+                                                         w.stream);
+                          });
 }
 
 void qamd_bin_sharded_free(qamd_bin_sharded *h) { delete h; }
@@ -951,6 +992,34 @@ qamd_status qamd_pq_sharded_topk(qamd_pq_sharded *h, const qamd_pq_sharded_query
                                  uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
     return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+}
+
+qamd_status qamd_pq_sharded_encode_query_batch(qamd_pq_sharded *h, const float *queries, uint64_t n_queries, uint64_t qdim,
+                                               qamd_mem queries_mem, qamd_pq_sharded_query_batch **batch_io) {
+    if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    std::unique_ptr<qamd_pq_sharded_query_batch> fresh;
+    qamd_pq_sharded_query_batch *b = *batch_io;
+    if (!b) {
+        fresh.reset(new qamd_pq_sharded_query_batch);
+        b = fresh.get();
+        b->per_shard.assign(h->G(), nullptr);
+        b->free_fn = qamd_pq_query_batch_free;
+    }
+    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, b, qamd_pq_encode_query_batch));
+    if (fresh) *batch_io = fresh.release();
+    return QAMD_OK;
+}
+
+void qamd_pq_sharded_query_batch_free(qamd_pq_sharded_query_batch *b) { delete b; }
+
+qamd_status qamd_pq_sharded_topk_batch(qamd_pq_sharded *h, const qamd_pq_sharded_query_batch *b, uint32_t k, int largest,
+                                       uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+    if (!h || !b || b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "null or foreign argument");
+    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem,
+                          [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
+                              return qamd_pq_topk_batch(h->shards[g], b->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE,
+                                                        w.stream);
+                          });
 }
 
 void qamd_pq_sharded_free(qamd_pq_sharded *h) { delete h; }

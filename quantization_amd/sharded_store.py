@@ -103,6 +103,30 @@ class _ShardedBase:
         check(self._fn("topk")(self._h, query._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem))
         return ids, sc
 
+    def encode_query_batch(self, queries, reuse=None):
+        nq, qdim = int(queries.shape[0]), int(queries.shape[1])
+        buf = in_buf(queries, np.float32)
+        h = reuse._h if reuse is not None else C.c_void_p()
+        check(self._fn("encode_query_batch")(self._h, buf.ptr, nq, qdim, buf.mem, C.byref(h)))
+        if reuse is not None:
+            reuse.n_queries = nq
+            return reuse
+        b = _ShardedQuery(h, self._fn("query_batch_free"), self)
+        b.n_queries = nq
+        return b
+
+    def topk_batch(self, batch, k: int, largest: bool = True, out_ids=None, out_scores=None):
+        nq = batch.n_queries
+        self._check_root(out_ids, out_scores)
+        ib, ids = out_buf(out_ids, nq * k, np.uint32)
+        sb, sc = out_buf(out_scores, nq * k, np.float32)
+        if ib.mem != sb.mem:
+            raise ValueError("out_ids and out_scores must both be host or both be device buffers")
+        check(self._fn("topk_batch")(self._h, batch._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem))
+        if isinstance(ids, np.ndarray):
+            return ids.reshape(nq, k), sc.reshape(nq, k)
+        return ids, sc
+
     def __del__(self):
         if getattr(self, "_h", None):
             try:
@@ -155,29 +179,6 @@ class ShardedVectorsU8(_ShardedBase):
         h, base, dev = self._shard_raw(g)
         return EncodedVectorsU8(h, dev, owned=False), base
 
-    def encode_query_batch(self, queries, reuse=None):
-        nq, qdim = int(queries.shape[0]), int(queries.shape[1])
-        buf = in_buf(queries, np.float32)
-        h = reuse._h if reuse is not None else C.c_void_p()
-        check(_lib.lib().qamd_u8_sharded_encode_query_batch(self._h, buf.ptr, nq, qdim, buf.mem, C.byref(h)))
-        if reuse is not None:
-            reuse.n_queries = nq
-            return reuse
-        b = _ShardedQuery(h, _lib.lib().qamd_u8_sharded_query_batch_free, self)
-        b.n_queries = nq
-        return b
-
-    def topk_batch(self, batch, k: int, largest: bool = True, out_ids=None, out_scores=None):
-        nq = batch.n_queries
-        self._check_root(out_ids, out_scores)
-        ib, ids = out_buf(out_ids, nq * k, np.uint32)
-        sb, sc = out_buf(out_scores, nq * k, np.float32)
-        if ib.mem != sb.mem:
-            raise ValueError("out_ids and out_scores must both be host or both be device buffers")
-        check(_lib.lib().qamd_u8_sharded_topk_batch(self._h, batch._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem))
-        if isinstance(ids, np.ndarray):
-            return ids.reshape(nq, k), sc.reshape(nq, k)
-        return ids, sc
 
 
 class ShardedVectorsBin(_ShardedBase):

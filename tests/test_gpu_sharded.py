@@ -162,6 +162,40 @@ def test_u8_sharded_topk_batch_equals_single_handle():
         _same_topk(sh.topk(qs, k), (ids1[3], sc1[3]))
 
 
+@pytest.mark.parametrize("kind", ["bin", "pq"])
+def test_bin_pq_sharded_topk_batch_equals_single_handle(kind):
+    rng = np.random.default_rng(19)
+    Q, k = 12, 30
+    if kind == "bin":
+        n, dim = 300_001, 512
+        data = np.where(rng.random((n, dim)) < 0.5, -1.0, 1.0).astype(np.float32)
+        vp = qa.VectorParameters(dim, n, D.Dot, False)
+        one = qa.EncodedVectorsBin.encode(data, vp)
+        make = lambda G: qa.ShardedVectorsBin.encode(data, vp, [0] * G)
+        queries = data[rng.integers(0, n, Q)]
+    else:
+        n, dim, chunk = 250_000, 64, 2
+        data = rng.random((n, dim), dtype=np.float32)
+        cen = rng.random((256, dim), dtype=np.float32)
+        vp = qa.VectorParameters(dim, n, D.L2, False)
+        one = qa.EncodedVectorsPQ.encode(data, vp, chunk, centroids=cen)
+        make = lambda G: qa.ShardedVectorsPQ.encode(data, vp, chunk, [0] * G, centroids=cen)
+        queries = rng.random((Q, dim), dtype=np.float32)
+    for largest in (True, False):
+        ids1, sc1 = one.topk_batch(one.encode_query_batch(queries), k, largest=largest)
+        for G in (2, 7):
+            sh = make(G)
+            batch = sh.encode_query_batch(queries)
+            ids, sc = sh.topk_batch(batch, k, largest=largest)
+            assert np.array_equal(ids, ids1), (kind, G, largest)
+            assert_bits_equal(sc, sc1, f"{kind} topk_batch G={G}")
+            # a batch object is reusable for a second set of queries of the same shape
+            batch = sh.encode_query_batch(queries[::-1].copy(), reuse=batch)
+            ids_r, sc_r = sh.topk_batch(batch, k, largest=largest)
+            assert np.array_equal(ids_r, ids1[::-1])
+            _same_topk(sh.topk(sh.encode_query(queries[5]), k, largest=largest), (ids1[5], sc1[5]))
+
+
 def test_sharded_edge_cases_and_errors():
     rng = np.random.default_rng(10)
     dim = 16
