@@ -181,6 +181,124 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_u8_sweep(
     return QAMD_OK;
 }
 
+// ---------------------------------------------------------------- row streaming access patterns
+// Pure-load kernels for the design of u8_gemm_rs_kernel: a wave streams 64-row chunks of the u8 store
+// K-block (128 B per row) after K-block, the way the MFMA B operand wants them, and only XORs the
+// bytes.  PATTERN 0: lane (r, h) takes the 64 contiguous bytes [64h, +64) of rows r and r + 32 (four
+// dwordx4 each: the direct-to-register operand layout).  PATTERN 1: fully coalesced (8 lanes per
+// 128-byte line, 8 rows per instruction).  AHEAD = K-blocks requested before the one being consumed.
+namespace {
+typedef int sv4 __attribute__((ext_vector_type(4)));
+template <int PATTERN, bool NT, int AHEAD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tune_stream(const uint8_t *__restrict__ codes, uint32_t n_rows, uint32_t ad,
+                                                          uint32_t *__restrict__ sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nkb = (ad + 127) / 128;
+    const uint32_t n_chunks = (n_rows + 63) / 64;
+    const uint32_t stride = gridDim.x * WAVES;
+    uint32_t chunk = blockIdx.x * WAVES + wave;
+    auto ld = [&](const uint8_t *p) {
+        return NT ? __builtin_nontemporal_load(reinterpret_cast<const sv4 *>(p)) : *reinterpret_cast<const sv4 *>(p);
+    };
+    sv4 acc = {0, 0, 0, 0};
+    sv4 buf[AHEAD + 1][8];
+    uint32_t pf_chunk = chunk, pf_kb = 0;
+    auto issue = [&](sv4(&b)[8]) {
+        const uint32_t c = pf_chunk < n_chunks ? pf_chunk : n_chunks - 1;
+        if (PATTERN == 0) {
+            const uint8_t *p = codes + ((uint64_t)c * 64 + (lane & 31)) * ad + pf_kb * 128 + 64 * (lane >> 5);
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) b[jj * 4 + x] = ld(p + (uint64_t)jj * 32 * ad + 16 * x);
+        } else {
+            const uint8_t *p = codes + ((uint64_t)c * 64 + (lane >> 3)) * ad + pf_kb * 128 + 16 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 8; i++) b[i] = ld(p + (uint64_t)i * 8 * ad);
+        }
+        if (++pf_kb == nkb) {
+            pf_kb = 0;
+            pf_chunk += stride;
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < AHEAD; a++) issue(buf[a]);
+    for (; chunk < n_chunks; chunk += stride) {
+        for (uint32_t kb = 0; kb < nkb; kb += AHEAD + 1) {
+#pragma unroll
+            for (int a = 0; a <= AHEAD; a++) {
+                if (kb + a < nkb) {  // nkb is a multiple of AHEAD + 1 in the sweep (768 = 6 x 128)
+                    issue(buf[(a + AHEAD) % (AHEAD + 1)]);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) acc ^= buf[a][i];
+                }
+            }
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) sink[0] = 1;  // keeps the loads alive
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_stream_sweep(const void *codes, uint32_t n_rows,
+                                                                                  uint32_t ad, uint32_t *sink,
+                                                                                  int rounds, char *report, size_t cap) {
+    QAMD_ON_DEVICE(current_device());
+    const uint8_t *c = static_cast<const uint8_t *>(codes);
+    const int cu = device_info().cu_count;
+    std::vector<Variant> vs;
+#define ADDV(P, NT, AH, W, BPC)                                                                                          \
+    do {                                                                                                                 \
+        char nm[128];                                                                                                    \
+        snprintf(nm, sizeof nm, "pattern%d nt%d ahead%d waves%d blocks/cu%d", P, NT, AH, W, BPC);                        \
+        vs.push_back({nm, [=](hipStream_t s) {                                                                           \
+                          hipLaunchKernelGGL((tune_stream<P, NT, AH, W>), dim3(cu * BPC), dim3(64 * W), 0, s, c, n_rows, \
+                                             ad, sink);                                                                  \
+                      }, {}});                                                                                           \
+    } while (0)
+    ADDV(0, false, 1, 8, 1);
+    ADDV(0, true, 1, 8, 1);
+    ADDV(0, false, 2, 8, 1);
+    ADDV(0, true, 2, 8, 1);
+    ADDV(0, true, 1, 16, 1);
+    ADDV(0, true, 2, 16, 1);
+    ADDV(0, true, 1, 8, 2);
+    ADDV(1, false, 1, 8, 1);
+    ADDV(1, true, 1, 8, 1);
+    ADDV(1, true, 2, 8, 1);
+    ADDV(1, true, 1, 16, 1);
+    ADDV(1, true, 2, 16, 1);
+    ADDV(1, true, 1, 8, 2);
+#undef ADDV
+    hipEvent_t e0, e1;
+    QAMD_HIP(hipEventCreate(&e0));
+    QAMD_HIP(hipEventCreate(&e1));
+    for (int r = 0; r < rounds; r++) {
+        for (auto &v : vs) {
+            v.launch(nullptr);
+            QAMD_HIP(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < 5; i++) v.launch(nullptr);
+            QAMD_HIP(hipEventRecord(e1, nullptr));
+            QAMD_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            QAMD_HIP(hipEventElapsedTime(&ms, e0, e1));
+            v.ms.push_back(ms / 5);
+        }
+    }
+    std::string rep;
+    for (auto &v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const float med = v.ms[v.ms.size() / 2], mn = v.ms.front();
+        char line[256];
+        snprintf(line, sizeof line, "%-44s median %.4f ms  min %.4f ms  %.0f GB/s\n", v.name.c_str(), med, mn,
+                 (double)n_rows * ad / (med * 1e-3) / 1e9);
+        rep += line;
+    }
+    snprintf(report, cap, "%s", rep.c_str());
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return QAMD_OK;
+}
+
 // ---------------------------------------------------------------- binary scan sweep (dim 1024)
 namespace {
 template <int UNROLL, int BLOCK, int STORE_MODE>

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
 constexpr int PP_KT = 64;  // K-tile bytes per row
+constexpr uint64_t kRsMaxTiles = 1;  // query tiles up to which the row-streaming kernel is preferred
 // Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
 //   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
 //   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
@@ -684,14 +685,298 @@ __global__ __launch_bounds__(512) void u8_gemm_pp_kernel(const uint8_t *__restri
     if (MODE != 0 && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
-// Gather `n` sampled rows (codes + offsets) into a dense sub-store for the pivot pass.
+// ------------------------------------------------------------------------------------------
+// Row-streaming kernel (batches whose query tile fits in LDS: every batch of up to 128 queries at
+// <= 1152 code bytes per row, 64 at <= 2304, 32 at <= 4608).  With so few queries the GEMM is
+// HBM-bound: each store row is needed by ONE wave only, so the rows do not go through LDS at all.
+//   * the workgroup's whole query tile (32*MI queries x the padded row length) is staged into LDS
+//     ONCE (pitch + 16 B: conflict-free ds_read_b128); no ring, no barrier after that — the 8 waves
+//     run independently and hide each other's HBM latency;
+//   * a wave owns 64 store rows at a time and streams them straight from HBM into its MFMA B
+//     operand registers: the K index of an MFMA is only a summation index, so lane (r, h) takes
+//     the 64 contiguous bytes [128 kb + 64 h, +64) of row r as the B fragments of the four MFMA
+//     k-steps of K-block kb (and reads the same bytes of query r from LDS for A) — whole 128-byte
+//     lines per row and K-block, one K-block ahead in a second register set (8 KiB per wave in
+//     flight), continuous across row chunks so the epilogue of one chunk runs under the loads of
+//     the next;
+//   * bytes past the end of a row (last K-block when the row length is not a multiple of 128)
+//     belong to the next row or to the store's zero padding: the query's LDS image is zero there,
+//     so they add nothing (integer arithmetic);
+//   * accumulators start at -(B_q + B_row) and the epilogue is the ping-pong kernel's (integer sign
+//     pre-filter, exact f32 epilogue for the few that may pass, wave-private candidate lists).
+// Workgroups b, b+8, ... of one XCD that share a row lane walk the same rows with different query
+// tiles (q_tiles > 1: the row bytes come from HBM once and from that XCD's L2 afterwards).
+template <int MI> struct RsShape {
+    static constexpr int MJ = 2;              // 32-row fragments per wave
+    static constexpr int TQ = 32 * MI;        // queries per workgroup
+    static constexpr int CHUNK = 32 * MJ;     // rows per wave and chunk
+    static constexpr int TR = 8 * CHUNK;      // rows per workgroup and step
+    static constexpr int KB = 128;            // K-block bytes per row
+    static constexpr size_t CONSTS = 3 * 128 * sizeof(float) + 64;
+    static constexpr size_t SLOTS = 8 * 4096;  // one wave-private transposition slot per wave
+    static size_t lds_bytes(uint32_t ad) { return (size_t)TQ * (round_up((uint64_t)ad, KB) + 16) + CONSTS + SLOTS; }
+};
+
+template <int MODE, bool LOW, int MI, bool NT>
+__global__ __launch_bounds__(512) void u8_gemm_rs_kernel(const uint8_t *__restrict__ codes,
+                                                        const float *__restrict__ v_offsets,
+                                                        const uint8_t *__restrict__ qcodes, uint32_t q_pitch,
+                                                        const float *__restrict__ q_offsets, float multiplier,
+                                                        uint32_t n_rows, uint32_t n_queries, uint32_t ad,
+                                                        uint32_t q_tiles, uint32_t row_lanes,
+                                                        float *__restrict__ out, uint64_t out_pitch,
+                                                        BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    using Shape = RsShape<MI>;
+    constexpr int MJ = Shape::MJ, TQ = Shape::TQ, CHUNK = Shape::CHUNK, TR = Shape::TR, KB = Shape::KB;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+    if (j >= row_lanes * q_tiles) return;
+    const uint32_t q_tile = j % q_tiles, row_lane = j / q_tiles;
+    const uint32_t q0 = q_tile * TQ;
+    const uint32_t nkb = __builtin_amdgcn_readfirstlane((ad + KB - 1) / KB);
+    const uint32_t PA = nkb * KB + 16;  // LDS pitch of a query
+    const uint32_t n_rtiles = (n_rows + TR - 1) / TR;
+    const uint32_t first = xcd + 8 * row_lane, step = 8 * row_lanes;
+    const uint32_t my_tiles =
+        __builtin_amdgcn_readfirstlane(first < n_rtiles ? (n_rtiles - first + step - 1) / step : 0u);
+
+    float *q_off_s = reinterpret_cast<float *>(lds_raw + (size_t)TQ * PA);  // [128]
+    float *pivot_s = q_off_s + 128;                                         // [128]
+    int *bq_s = reinterpret_cast<int *>(pivot_s + 128);                     // [128] integer query bounds
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(bq_s + 128) + wave;   // this wave's append counter
+    constexpr bool LARGEST = MODE == 1;
+    if (MODE != 0 && lane == 0) *wcount_s = 0;
+    if (t < TQ) {
+        const float qo = q_offsets[q0 + t];
+        q_off_s[t] = qo;
+        if (MODE != 0) {
+            const float pv = filt.pivot_scores[q0 + t];
+            pivot_s[t] = pv;
+            int bq = pp_bound<LOW>(pv - qo, fabsf(pv) + fabsf(qo), multiplier, 1);
+            if (__builtin_isinf(pv)) bq = ((pv > 0.0f) == LARGEST) == LOW ? -(int)kPpLim : (int)kPpLim;
+            bq_s[t] = bq;
+        }
+    }
+    {  // the query tile, zero beyond the batch's pitch
+        const uint32_t per_row = nkb * (KB / 16);
+        for (uint32_t idx = t; idx < (uint32_t)TQ * per_row; idx += 512) {
+            const uint32_t row = idx / per_row, k = (idx % per_row) * 16;
+            v4i v = {0, 0, 0, 0};
+            if (k < q_pitch) v = *reinterpret_cast<const v4i *>(qcodes + (uint64_t)(q0 + row) * q_pitch + k);
+            *reinterpret_cast<v4i *>(lds_raw + row * PA + k) = v;
+        }
+    }
+    __syncthreads();
+    if (my_tiles == 0) {
+        if (MODE != 0 && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = 0;
+        return;
+    }
+
+    // B stream.  HBM -> registers: fully coalesced, one touch per 128-byte line (lane l takes bytes
+    // [16 (l % 8), +16) of chunk rows l / 8 + 8 i, i = 0..7), which is what lets the nt policy work
+    // (measured on pure-load kernels, tools/tune_stream.py: 6.96 TB/s this way; 6.25 TB/s with the
+    // operand layout fetched directly — each line touched by four instructions — and 3.5 TB/s if
+    // THAT is marked nt).  Registers -> operand layout through a wave-private 4 KiB LDS slot (32
+    // rows x 128 B, 16-byte chunk index XOR (row & 7): conflict-free both ways), one half chunk
+    // at a time; LDS operations of one wave execute in order, so the slot needs no barrier.
+    const uint64_t row_bytes = ad;
+    const uint32_t l8 = (uint32_t)lane & 7u, lrow = (uint32_t)lane >> 3;
+    const uint8_t *pf0 = codes + ((uint64_t)first * TR + wave * CHUNK + lrow) * row_bytes + 16 * l8;
+    const uint64_t i_stride = (uint64_t)8 * row_bytes;
+    const uint64_t wrap_advance = (uint64_t)step * TR * row_bytes - (uint64_t)nkb * KB;
+    uint32_t pf_kb = 0, pf_left = my_tiles * nkb - 1;  // K-blocks after the one pf0 points at
+    // NT: rows read exactly once (one query tile); with several query tiles the XCD's L2 serves the others
+    v4i L[8];
+    // Always issues its eight loads (past the end of the stream it re-reads the last K-block): a
+    // conditional load would make the compiler drain vmcnt(0) where the two paths join.
+    auto prefetch = [&]() {
+        if (NT) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) L[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(pf0 + i * i_stride));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) L[i] = *reinterpret_cast<const v4i *>(pf0 + i * i_stride);
+        }
+        uint64_t adv = KB;
+        if (++pf_kb == nkb) {
+            pf_kb = 0;
+            adv += wrap_advance;
+        }
+        if (pf_left == 0) {
+            adv = 0;
+            pf_kb = 0;
+        } else {
+            pf_left--;
+        }
+        pf0 += adv;
+    };
+    uint8_t *slot = lds_raw + (size_t)TQ * PA + Shape::CONSTS + (size_t)wave * 4096;
+    uint8_t *wr = slot + lrow * 128 + ((l8 ^ (lrow & 7u)) * 16);  // + 1024 i
+    const uint32_t rbase = (uint32_t)r * 128u + (((4u * (uint32_t)h) ^ ((uint32_t)r & 4u)) * 16u);
+    const uint8_t *rd = slot + rbase;  // + 16 (x ^ (r & 3))
+    const uint32_t r3 = (uint32_t)r & 3u;
+    v4i F[MJ][4];
+    auto transpose = [&]() {
+#pragma unroll
+        for (int jj = 0; jj < MJ; jj++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<v4i *>(wr + 1024 * i) = L[4 * jj + i];
+#pragma unroll
+            for (int x = 0; x < 4; x++) F[jj][x] = *reinterpret_cast<const v4i *>(rd + 16u * ((uint32_t)x ^ r3));
+        }
+    };
+    const uint8_t *a_base = lds_raw + r * PA + 64 * h;
+
+    prefetch();
+    float vo_next[MJ];
+    if (MODE != 0) {
+#pragma unroll
+        for (int jj = 0; jj < MJ; jj++) vo_next[jj] = v_offsets[(uint64_t)first * TR + wave * CHUNK + jj * 32 + r];
+    }
+    const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
+    uint32_t tile = first;
+    for (uint32_t ti = 0; ti < my_tiles; ti++, tile += step) {
+        v16i acc[MI][MJ];
+        float vo_cur[MJ];
+        int br[MJ];
+        const uint64_t row_a = (uint64_t)tile * TR + wave * CHUNK + r;
+#pragma unroll
+        for (int jj = 0; jj < MJ; jj++) {
+            vo_cur[jj] = 0.0f;
+            br[jj] = 0;
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int jj = 0; jj < MJ; jj++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[i][jj][e] = 0;
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < MJ; jj++) vo_cur[jj] = vo_next[jj];
+            {
+                const uint32_t nt = ti + 1 < my_tiles ? tile + step : tile;  // unconditional load (see prefetch)
+#pragma unroll
+                for (int jj = 0; jj < MJ; jj++) vo_next[jj] = v_offsets[(uint64_t)nt * TR + wave * CHUNK + jj * 32 + r];
+            }
+#pragma unroll
+            for (int jj = 0; jj < MJ; jj++)
+                br[jj] = row_a + 32 * jj < n_rows ? pp_bound<LOW>(-vo_cur[jj], fabsf(vo_cur[jj]), multiplier, 0)
+                                                  : (LOW ? -(int)kPpLim : (int)kPpLim);
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + i * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+#pragma unroll
+                        for (int jj = 0; jj < MJ; jj++) acc[i][jj][4 * gq + e] = -(bq4[e] + br[jj]);
+                }
+        }
+        for (uint32_t kb = 0; kb < nkb; kb++) {
+            transpose();  // waits for L, leaves it free
+            prefetch();   // next K-block (of this chunk or the next) under this one's MFMAs
+            const uint8_t *pa = a_base + kb * KB;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                v4i a[MI];
+#pragma unroll
+                for (int i = 0; i < MI; i++) a[i] = *reinterpret_cast<const v4i *>(pa + (uint32_t)i * 32u * PA + 16 * x);
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int jj = 0; jj < MJ; jj++)
+                        acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], F[jj][x], acc[i][jj], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue of this wave's 64 rows (see u8_gemm_pp_kernel)
+        const uint64_t row0 = (uint64_t)tile * TR + wave * CHUNK;
+        uint32_t q0_e = q0, wave_e = (uint32_t)wave, lane_e = (uint32_t)lane;
+        asm volatile("" : "+s"(q0_e), "+s"(wave_e), "+v"(lane_e));
+        uint4 *wave_list = MODE != 0 ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
+        const uint32_t r_e = lane_e & 31u, h_e = lane_e >> 5;
+#pragma unroll
+        for (int jj = 0; jj < MJ; jj++) {
+            const uint64_t row = row0 + jj * 32 + r_e;
+            const bool row_ok = row < n_rows;
+            float v_off;
+            if (MODE == 0) v_off = v_offsets[row];  // padded like codes[]
+            else v_off = row_ok ? vo_cur[jj] : never;
+            const int brj = br[jj];
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 0) {
+                    int all = acc[i][jj][0];
+#pragma unroll
+                    for (int e = 1; e < 16; e++) all = LOW ? (all | acc[i][jj][e]) : (all & acc[i][jj][e]);
+                    if (!__builtin_amdgcn_readfirstlane(__ballot(LOW ? all < 0 : all >= 0) != 0)) continue;
+                }
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const uint32_t ql = i * 32 + 8 * gq + 4 * h_e;
+                    if (MODE == 0) {
+                        const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
+                        const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float sc = (multiplier * (float)acc[i][jj][4 * gq + e] + qo[e]) + v_off;
+                            const uint32_t q = q0_e + ql + e;
+                            if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc;
+                        }
+                    } else {
+                        const int a0 = acc[i][jj][4 * gq], a1 = acc[i][jj][4 * gq + 1], a2 = acc[i][jj][4 * gq + 2],
+                                  a3 = acc[i][jj][4 * gq + 3];
+                        const bool may_pass = LOW ? ((a0 | a1 | a2 | a3) < 0) : ((a0 & a1 & a2 & a3) >= 0);
+                        if (may_pass) {
+                            const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + ql);
+                            const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
+                            const float4 pv4 = *reinterpret_cast<const float4 *>(pivot_s + ql);
+                            const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                            const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                            const int av[4] = {a0, a1, a2, a3};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int s_int = av[e] + bq4[e] + brj;  // the plain integer dot product
+                                const float sc = (multiplier * (float)s_int + qo[e]) + v_off;
+                                const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
+                                if (d >= 0.0f) {
+                                    const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                    if (pos < filt.wave_cap)
+                                        wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row,
+                                                                    filt.query_base + q0_e + ql + e, 0u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (MODE != 0 && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+}
+
+// Gather `n` sampled rows (codes + offsets) into a dense sub-store for the pivot pass, followed by
+// `pad` zero rows (the GEMM kernels read whole row tiles).
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *__restrict__ codes,
                                                          const float *__restrict__ offsets, uint32_t row_chunks,
-                                                         uint64_t n_rows, uint32_t n, uint4 *__restrict__ out_codes,
+                                                         uint64_t n_rows, uint32_t n, uint32_t pad,
+                                                         uint4 *__restrict__ out_codes,
                                                          float *__restrict__ out_offsets) {
-    const uint64_t total = (uint64_t)n * row_chunks;
+    const uint64_t total = (uint64_t)(n + pad) * row_chunks;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
         const uint32_t j = (uint32_t)(i / row_chunks), c = (uint32_t)(i % row_chunks);
+        if (j >= n) {
+            out_codes[i] = make_uint4(0, 0, 0, 0);
+            if (c == 0) out_offsets[j] = 0.0f;
+            continue;
+        }
         const unsigned long long hsh = (unsigned long long)j * 0x9E3779B97F4A7C15ull;
         const uint64_t src = ((hsh >> 32) * n_rows) >> 32;  // same golden-ratio scatter as topk.hip
         out_codes[i] = codes[src * row_chunks + c];
@@ -911,6 +1196,76 @@ qamd_status launch_gemm_pp(const qamd_u8 *h, const qamd_u8_query_batch *b, const
                : launch_gemm_pp_cfg<M, false, 4, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
 }
 
+// Row-streaming kernel launch: one persistent workgroup per CU, query tile resident in LDS.
+// rs_frags() = query fragments per workgroup (0: the tile does not fit, use another kernel).
+inline int rs_frags(uint64_t n_queries, uint64_t ad) {
+    const size_t lds_max = 160 * 1024;
+    for (int mi : {1, 2, 4})  // the smallest tile that holds the whole batch, else the largest that fits
+        if (n_queries <= (uint64_t)32 * mi && (size_t)32 * mi * (round_up(ad, 128) + 16) + 2048 + 32768 <= lds_max) return mi;
+    for (int mi : {4, 2, 1})
+        if ((size_t)32 * mi * (round_up(ad, 128) + 16) + 2048 + 32768 <= lds_max) return mi;
+    return 0;
+}
+
+template <int MODE, bool LOW, int MI, bool NT>
+qamd_status launch_gemm_rs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                               const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                               const BatchFilter &filt, hipStream_t s) {
+    static std::atomic<uint64_t> set_on{0};
+    if (first_use_on_device(set_on))
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_rs_kernel<MODE, LOW, MI, NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    constexpr uint64_t TQW = 32 * MI;
+    const size_t lds_bytes = RsShape<MI>::lds_bytes((uint32_t)h->meta.actual_dim);
+    const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
+    const uint64_t all_q_tiles = (b->n_queries + TQW - 1) / TQW;
+    for (uint64_t qt0 = 0; qt0 < all_q_tiles; qt0 += cus_per_xcd) {
+        const uint32_t q_tiles = (uint32_t)std::min<uint64_t>(cus_per_xcd, all_q_tiles - qt0);
+        const uint32_t row_lanes = cus_per_xcd / q_tiles;
+        const uint64_t q_base = qt0 * TQW;
+        BatchFilter f = filt;
+        if (MODE != 0) {
+            f.pivot_scores += q_base;
+            f.query_base = (uint32_t)q_base;
+            f.wave_base = (uint32_t)(qt0 / cus_per_xcd) * pp_waves_per_launch();
+        }
+        hipLaunchKernelGGL((u8_gemm_rs_kernel<MODE, LOW, MI, NT>), dim3(8 * row_lanes * q_tiles), dim3(512), lds_bytes, s,
+                           codes, v_offsets, b->codes.as<uint8_t>() + q_base * b->pitch, (uint32_t)b->pitch,
+                           b->offsets.as<float>() + q_base, h->meta.multiplier, (uint32_t)n_rows,
+                           (uint32_t)(b->n_queries - q_base), (uint32_t)h->meta.actual_dim, q_tiles, row_lanes,
+                           MODE == 0 ? out + q_base * out_pitch : out, out_pitch, f);
+        QAMD_HIP(hipGetLastError());
+    }
+    return QAMD_OK;
+}
+
+template <int MODE>
+qamd_status launch_gemm_rs(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                           const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                           const BatchFilter &filt, hipStream_t s) {
+    const int mi = rs_frags(b->n_queries, h->meta.actual_dim);
+    constexpr int M = MODE == 0 ? 1 : MODE;
+    const bool low = MODE != 0 && (h->meta.multiplier < 0.0f) != (MODE == 2);
+    const bool nt = b->n_queries <= (uint64_t)32 * mi;  // one query tile: every row byte is read exactly once
+#define QAMD_RS2(MI_, NT_)                                                                                        \
+    (MODE == 0 ? launch_gemm_rs_cfg<0, false, MI_, NT_>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)  \
+     : low     ? launch_gemm_rs_cfg<M, true, MI_, NT_>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s)   \
+               : launch_gemm_rs_cfg<M, false, MI_, NT_>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s))
+#define QAMD_RS(MI_) (nt ? QAMD_RS2(MI_, true) : QAMD_RS2(MI_, false))
+    if (mi == 4) return QAMD_RS(4);
+    if (mi == 2) return QAMD_RS(2);
+    return QAMD_RS(1);
+#undef QAMD_RS2
+#undef QAMD_RS
+}
+
+// Queries per launch slice of the kernel that serves this batch (wave-list bookkeeping).
+inline uint32_t gemm_launches(const qamd_u8 *h, const qamd_u8_query_batch *b, bool rs) {
+    if (!rs) return pp_launches(b->n_queries);
+    const uint64_t per = (uint64_t)std::max(1, device_info().cu_count / 8) * 32 * rs_frags(b->n_queries, h->meta.actual_dim);
+    return (uint32_t)((b->n_queries + per - 1) / per);
+}
+
 // Which kernel serves a batch: the ping-pong kernel (rows of at least three 64-byte K-tiles, a
 // usable multiplier for its integer pre-filter), else u8_gemm_kernel.
 bool pp_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
@@ -920,12 +1275,26 @@ bool pp_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
     return h->meta.actual_dim > 128 && h->meta.actual_dim <= 32768 && (!filter_mode || (std::isfinite(m) && m != 0.0f));
 }
 
+// The row-streaming kernel: where the ping-pong kernel could run (same pre-filter conditions), the
+// query tile fits in LDS, and the batch is small enough to be HBM-bound (QAMD_GEMM_CFG=r / p force).
+bool rs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
+    static const char *cfg = getenv("QAMD_GEMM_CFG");
+    if (cfg && cfg[0] != 'r') return false;
+    const float m = h->meta.multiplier;
+    if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
+    const int mi = rs_frags(b->n_queries, h->meta.actual_dim);
+    if (mi == 0 || h->meta.actual_dim > 32768) return false;
+    if (cfg) return true;
+    return b->n_queries <= (uint64_t)32 * mi * kRsMaxTiles;
+}
+
 template <int MODE>
 qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                         const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                         const BatchFilter &filt, hipStream_t s) {
     if (n_rows == 0 || b->n_queries == 0) return QAMD_OK;
     // q_pad is a multiple of 256 and the row padding of every store covers a 256-row tile.
+    if (rs_selected(h, b, MODE != 0)) return launch_gemm_rs<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (pp_selected(h, b, MODE != 0)) return launch_gemm_pp<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (b->n_queries > 128) {
         static const char *cfg = getenv("QAMD_GEMM_CFG");
@@ -938,6 +1307,30 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
         return launch_gemm_cfg<MODE, 256, 256, 2, 4, 128>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     }
     return launch_gemm_cfg<MODE, 128, 128, 2, 2, 128>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
+}
+
+// The pivot sample of a store, gathered once per handle: sample row j is store row hash(j) whatever
+// the sample size, so one sample of the largest size any call can ask for (8 n / 512 rows, at most
+// 524288) serves every call as a prefix.  Rows past the prefix inside the last row tile are real
+// sample rows instead of zeros: the kernels compute them and store nothing (row >= n_rows).
+qamd_status sample_store(const qamd_u8 *h, uint32_t rows_all, hipStream_t s, const uint8_t **codes, const float **offs) {
+    std::lock_guard<std::mutex> lk(h->sample_mu);
+    if (h->sample_rows < rows_all) {
+        const uint64_t ad = h->meta.actual_dim;
+        qamd::DevBuf c, o;
+        QAMD_TRY(c.alloc((uint64_t)(rows_all + 512) * ad));
+        QAMD_TRY(o.alloc((uint64_t)(rows_all + 512) * 4));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->codes.as<uint4>(),
+                           h->offsets.as<float>(), h->row_chunks, h->count, rows_all, 512u, c.as<uint4>(), o.as<float>());
+        QAMD_HIP(hipGetLastError());
+        QAMD_HIP(hipStreamSynchronize(s));  // once per handle: every later call, on any stream, just reads it
+        h->sample_codes = std::move(c);
+        h->sample_offsets = std::move(o);
+        h->sample_rows = rows_all;
+    }
+    *codes = h->sample_codes.as<uint8_t>();
+    *offs = h->sample_offsets.as<float>();
+    return QAMD_OK;
 }
 
 }  // namespace
@@ -1055,7 +1448,9 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     // measured +7..10 % on the whole call).  So: about max(512, 3k) rows expected to pass at pivot
     // rank >= 8 (P(fewer than k) < 1e-7, P(more than 8192) ~ 0); S = 8 n / that, capped at 524288
     // sampled rows (beyond 33M rows the expected count grows instead of r shrinking).
-    const double want = std::max<double>(512.0, 3.0 * k);
+    // Few queries: a smaller sample (cheaper pivot pass) and more candidates per query instead; the
+    // extra exact epilogues and list appends are then a few thousand per query in a whole-store pass.
+    const double want = std::max<double>(Q <= 32 ? 2048.0 : Q <= 128 ? 1024.0 : 512.0, 3.0 * k);
     // small stores (Qdrant segments: 1e5..1e6 rows) take the same route with a smaller sample: the
     // per-query fallback costs a launch chain per query, the matrix-core pass one for the whole batch
     const double s_min = n < (1u << 20) ? 2048.0 : (double)kTopkSample;
@@ -1081,11 +1476,12 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         const uint64_t ad = h->meta.actual_dim;
         // ONE stream-ordered allocation for all scratch of the call, carved up below: hipFreeAsync
         // costs ~65 us per buffer on this runtime, and ten buffers were a third of a small batch's time.
-        const bool pp = pp_selected(h, b, true);
+        const bool rs = rs_selected(h, b, true);
+        const bool pp = rs || pp_selected(h, b, true);  // both append to wave-private lists
         uint32_t n_lists = 0, wave_cap = 0;
         if (pp) {
             // wave-private lists: 4x the expected appends per wave (about `target`..2*target per query)
-            n_lists = pp_launches(Q) * pp_waves_per_launch();
+            n_lists = gemm_launches(h, b, rs) * pp_waves_per_launch();
             const double per_wave = 2.0 * target * (double)Q / (double)n_lists;
             wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(1024.0, 4.0 * per_wave));
         }
@@ -1099,32 +1495,44 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         const size_t o_pivots = reserve(b->q_pad * 4);
         const size_t o_counters = reserve(b->q_pad * kCounterStride * 4);
         const size_t o_wcounts = reserve((uint64_t)n_lists * 4);
-        const size_t o_overflow = reserve(4);
         const size_t zero_bytes = arena_bytes;
-        const size_t o_codes = reserve((uint64_t)(S + 512) * ad);  // + one (largest) tile of zero rows
-        const size_t o_offs = reserve((uint64_t)(S + 512) * 4);
+        // the sample sub-store: the handle's cached one (a prefix of it), else gathered into the arena
+        const uint32_t rows_all = (uint32_t)std::min<double>(524288.0, std::max<double>(s_min, (double)round_up((uint64_t)(8.0 * (double)n / 512.0), 256)));
+        const uint8_t *s_codes = nullptr;
+        const float *s_offs = nullptr;
+        const bool cached = S <= rows_all && sample_store(h, rows_all, s, &s_codes, &s_offs) == QAMD_OK;
+        const size_t o_codes = reserve(cached ? 16 : (uint64_t)(S + 512) * ad);  // + one (largest) tile of zero rows
+        const size_t o_offs = reserve(cached ? 16 : (uint64_t)(S + 512) * 4);
         const size_t o_scores = reserve(Q * (uint64_t)S * 4);
         const size_t o_cand = reserve(Q * (uint64_t)kBatchCap * 8);
-        const size_t o_status = reserve(Q * 4);
+        const size_t o_status = reserve((Q + 1) * 4);  // per-query status, then the wave-list overflow flag
         const size_t o_wcand = reserve((uint64_t)n_lists * wave_cap * sizeof(uint4));
         StreamBuf arena;
         QAMD_TRY(arena.alloc(arena_bytes, s));
         char *base = arena.as<char>();
         QAMD_HIP(hipMemsetAsync(base, 0, zero_bytes, s));
-        QAMD_HIP(hipMemsetAsync(base + o_codes + (uint64_t)S * ad, 0, (uint64_t)512 * ad, s));  // the padding tile
-        QAMD_HIP(hipMemsetAsync(base + o_offs + (uint64_t)S * 4, 0, 512 * 4, s));
-        uint8_t *s_codes = reinterpret_cast<uint8_t *>(base + o_codes);
-        float *s_offs = reinterpret_cast<float *>(base + o_offs);
         float *pivots = reinterpret_cast<float *>(base + o_pivots);
         uint32_t *counters = reinterpret_cast<uint32_t *>(base + o_counters);
         uint32_t *wave_counts = reinterpret_cast<uint32_t *>(base + o_wcounts);
-        uint32_t *overflow_dev = reinterpret_cast<uint32_t *>(base + o_overflow);
         float *s_scores = reinterpret_cast<float *>(base + o_scores);
         unsigned long long *cand = reinterpret_cast<unsigned long long *>(base + o_cand);
-        uint32_t *status_dev = reinterpret_cast<uint32_t *>(base + o_status);
+        // The per-query status words and the overflow flag come back through the calling thread's mapped
+        // host scratch when they fit (the kernels write host memory directly: one stream sync, no copy
+        // calls), else through one copy from the arena.
+        const HostScratch hs = Q + 1 <= 2048 ? host_scratch() : HostScratch{};
+        uint32_t *status_dev = hs.dev ? hs.dev : reinterpret_cast<uint32_t *>(base + o_status);
+        uint32_t *overflow_dev = status_dev + Q;
+        if (hs.host) hs.host[Q] = 0;
+        else QAMD_HIP(hipMemsetAsync(overflow_dev, 0, 4, s));
         uint4 *wave_cand = reinterpret_cast<uint4 *>(base + o_wcand);
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->codes.as<uint4>(),
-                           h->offsets.as<float>(), h->row_chunks, n, S, reinterpret_cast<uint4 *>(s_codes), s_offs);
+        if (!cached) {
+            uint8_t *g_codes = reinterpret_cast<uint8_t *>(base + o_codes);
+            float *g_offs = reinterpret_cast<float *>(base + o_offs);
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->codes.as<uint4>(),
+                               h->offsets.as<float>(), h->row_chunks, n, S, 512u, reinterpret_cast<uint4 *>(g_codes), g_offs);
+            s_codes = g_codes;
+            s_offs = g_offs;
+        }
         QAMD_TRY(launch_gemm<0>(h, b, s_codes, s_offs, S, s_scores, S, BatchFilter{}, s));
         hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores, S, (uint64_t)S, r,
                            largest, (uint32_t)Q, pivots, counters);
@@ -1148,12 +1556,18 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand, counters, n, k, largest, ids_dev,
                            sc_dev, status_dev);
         QAMD_HIP(hipGetLastError());
-        QAMD_TRY(copy_out(status.data(), QAMD_MEM_HOST, status_dev, Q * 4, s));  // synchronises
-        if (pp) {
-            uint32_t overflow = 0;
-            QAMD_TRY(copy_out(&overflow, QAMD_MEM_HOST, overflow_dev, 4, s));
-            if (overflow) std::fill(status.begin(), status.end(), 1u);  // a wave list overflowed: redo all exactly
+        uint32_t overflow = 0;
+        if (hs.host) {
+            QAMD_HIP(hipStreamSynchronize(s));
+            std::copy(hs.host, hs.host + Q, status.begin());
+            overflow = hs.host[Q];
+        } else {
+            std::vector<uint32_t> back(Q + 1);
+            QAMD_TRY(copy_out(back.data(), QAMD_MEM_HOST, status_dev, (Q + 1) * 4, s));  // synchronises
+            std::copy(back.begin(), back.begin() + Q, status.begin());
+            overflow = back[Q];
         }
+        if (pp && overflow) std::fill(status.begin(), status.end(), 1u);  // a wave list overflowed: redo all exactly
         static const bool debug_topk = getenv("QAMD_DEBUG_TOPK") != nullptr;
         if (debug_topk) {
             std::vector<uint32_t> cnt(b->q_pad * kCounterStride);

@@ -1,6 +1,9 @@
 // Handle layouts of the scalar-u8 quantizer, shared by u8.hip (single-query path) and
 // u8_batch.hip (multi-query MFMA path).  Not part of the C ABI.
 #pragma once
+#include <atomic>
+#include <mutex>
+
 #include "common.hpp"
 
 struct qamd_u8 {
@@ -12,6 +15,11 @@ struct qamd_u8 {
     int lane_mode = 0;         // 0: integer sum rounded once; 1: avx2.c lane order
     qamd::DevBuf codes;        // [padded_rows][actual_dim]
     qamd::DevBuf offsets;      // [padded_rows] f32
+    // The batched top-k's pivot sample (u8_batch.hip): rows hash(j) of the store, j < sample_rows, then 512
+    // zero rows; gathered once on first use (count / 64 rows at most: 1.6 % of the store), immutable after.
+    mutable std::mutex sample_mu;
+    mutable qamd::DevBuf sample_codes, sample_offsets;
+    mutable uint32_t sample_rows = 0;
 };
 
 struct qamd_u8_query {
