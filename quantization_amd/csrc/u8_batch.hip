@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
 constexpr int PP_KT = 64;  // K-tile bytes per row
-constexpr uint64_t kRsMaxTiles = 1;  // query tiles up to which the row-streaming kernel is preferred
+constexpr uint64_t kRsMaxQueries = 768;  // batch size up to which several 128-query tiles of the row-streaming kernel are preferred
 // Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
 //   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
 //   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
@@ -1285,7 +1285,13 @@ bool rs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
     const int mi = rs_frags(b->n_queries, h->meta.actual_dim);
     if (mi == 0 || h->meta.actual_dim > 32768) return false;
     if (cfg) return true;
-    return b->n_queries <= (uint64_t)32 * mi * kRsMaxTiles;
+    // One query tile: every row byte leaves HBM once, at the plain scan's rate.  Several tiles re-read the
+    // rows (at HBM pace a line lives ~5 us in the XCD's L2, too short for the tiles' workgroups to share
+    // it), which still beats the ping-pong kernel for 128-query tiles up to 768 queries (measured at
+    // 10M x 768: 160 q 2.22 vs 2.41 ms, 384 q 3.39 vs 4.51, 512 q 4.29 vs 4.66, 1024 q 8.64 vs 8.70)
+    // and loses with the 64-query tiles of longer rows (12.5M x 1536: 96 q 3.88 vs 3.74, 256 q 6.83 vs 5.58).
+    const uint64_t tiles = (b->n_queries + 32 * mi - 1) / (32 * mi);
+    return tiles == 1 || (mi == 4 && b->n_queries <= kRsMaxQueries);
 }
 
 template <int MODE>

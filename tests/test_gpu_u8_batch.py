@@ -270,3 +270,86 @@ def test_handful_of_queries_take_the_vector_alu_multi_query_scan(dim, nq, dist, 
         order = qo.ORDER_AVX2 if md["actual_dim"] <= 1040 else qo.ORDER_SIMPLE
         assert_bits_equal(sb[qi][rows_idx].cpu().numpy(), qo.u8_score_all(o_meta, o_rows, codes, qoff, order=order),
                           f"query {qi} vs oracle")
+
+
+# ---- row-streaming kernel (u8_gemm_rs_kernel): batches whose query tile fits in LDS
+@pytest.mark.parametrize("n,dim,nq", [
+    (70_001, 96, 20),      # one K-block per row (odd count), 32-query tile
+    (50_000, 200, 64),     # row length 208: the last K-block runs into the next row (query image is zero there)
+    (300_017, 384, 100),   # three K-blocks, 128-query tile, more than one row tile per workgroup, ragged tail
+    (140_000, 512, 300),   # three 128-query tiles per row lane (the last one partly filled)
+    (20_000, 1000, 128),   # eight K-blocks, row length not a multiple of 128
+    (9_000, 1152, 128),    # the longest row a 128-query tile holds
+    (9_000, 1168, 128),    # one step longer: only 64-query tiles fit, two would be needed -> ping-pong kernel
+    (6_000, 2304, 33),     # the longest row a 64-query tile holds
+    (3_000, 4600, 32),     # 32-query tile
+    (3_000, 4600, 40),     # ... two of them would be needed -> ping-pong kernel
+    (2_000, 4700, 8),      # no tile fits: the ping-pong kernel serves it
+])
+def test_row_streaming_kernel_shapes(n, dim, nq, qo):
+    rng = np.random.default_rng(n + dim + nq)
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    for dist, invert, largest in ((D.Dot, False, True), (D.L2, True, False)):
+        enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
+        batch = enc.encode_query_batch(queries)
+        got = enc.score_batch(batch)
+        rows, meta = qo.u8_encode(data, int(dist), invert)
+        for qi in sorted({0, nq // 2, nq - 1}):
+            codes, qoff = qo.u8_encode_query(meta, queries[qi])
+            want = qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_SIMPLE)
+            assert_bits_equal(got[qi], want, f"{dist} query {qi} vs oracle")
+        if n < 32768:
+            continue  # top-k of small stores takes the exact single-query path
+        ids, sc = enc.topk_batch(batch, 30, largest=largest)
+        qobj = None
+        for qi in sorted({0, 1, nq // 3, nq // 2, nq - 2, nq - 1}):
+            qobj = enc.encode_query(queries[qi], reuse=qobj)
+            wi, ws = enc.topk(qobj, 30, largest=largest)
+            assert np.array_equal(ids[qi], wi), (qi, n, dim)
+            assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (qi, n, dim)
+
+
+def test_row_streaming_kernel_pivot_sample_is_cached_and_stable():
+    """The pivot sample is gathered once per handle; later calls (other batch sizes, k, direction)
+    use prefixes of it and must keep returning the exact lists."""
+    rng = np.random.default_rng(77)
+    n, dim = 150_000, 256
+    data = rng.random((n, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    for nq, k, largest in ((7, 10, True), (90, 200, False), (300, 30, True), (7, 10, True)):
+        queries = rng.random((nq, dim), dtype=np.float32)
+        ids, sc = enc.topk_batch(enc.encode_query_batch(queries), k, largest=largest)
+        for qi in (0, nq - 1):
+            wi, ws = enc.topk(enc.encode_query(queries[qi]), k, largest=largest)
+            assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (nq, qi)
+
+
+def test_row_streaming_kernel_forced_for_many_query_tiles():
+    """QAMD_GEMM_CFG=r (developer switch, read once per process) sends every batch whose tile fits
+    through the row-streaming kernel: several query tiles per row lane, rows shared through the XCD's L2."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, quantization_amd as qa
+D = qa.DistanceType
+rng = np.random.default_rng(5)
+n, dim, nq = 200_003, 192, 300
+data = rng.random((n, dim), dtype=np.float32)
+queries = rng.random((nq, dim), dtype=np.float32)
+enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.L2, False))
+b = enc.encode_query_batch(queries)
+ids, sc = enc.topk_batch(b, 30, largest=False)
+got = enc.score_batch(b)
+for qi in (0, 127, 128, 255, 256, 299):
+    q = enc.encode_query(queries[qi])
+    wi, ws = enc.topk(q, 30, largest=False)
+    assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), qi
+    assert np.array_equal(got[qi].view(np.uint32), enc.score_all(q).view(np.uint32)), qi
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QAMD_GEMM_CFG="r", PYTHONPATH=root)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0 and "ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
