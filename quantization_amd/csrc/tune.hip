@@ -299,6 +299,81 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_stream_sw
     return QAMD_OK;
 }
 
+// ---------------------------------------------------------------- int8 MFMA issue-rate ceiling
+// What the matrix pipe delivers on this box with nothing else in the way: every wave keeps NACC
+// independent 32x32 accumulators and issues v_mfma_i32_32x32x32_i8 back to back on operands held in
+// registers (pseudo-random bytes, so the multipliers toggle like real codes), WPS waves per SIMD.
+namespace {
+typedef int mv4 __attribute__((ext_vector_type(4)));
+typedef int mv16 __attribute__((ext_vector_type(16)));
+template <int NACC>
+__global__ __launch_bounds__(512) void tune_mfma_peak(uint32_t iters, uint32_t seed, int *__restrict__ sink) {
+    mv16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[a][e] = 0;
+    uint32_t x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+    auto rnd = [&]() {
+        x = x * 1664525u + 1013904223u;
+        return (int)(x & 0x7F7F7F7Fu);  // codes <= 127
+    };
+    mv4 a0 = {rnd(), rnd(), rnd(), rnd()}, a1 = {rnd(), rnd(), rnd(), rnd()};
+    mv4 b0 = {rnd(), rnd(), rnd(), rnd()}, b1 = {rnd(), rnd(), rnd(), rnd()};
+    for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+        for (int a = 0; a < NACC; a++)
+            acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8((a & 1) ? a1 : a0, (a & 2) ? b1 : b0, acc[a], 0, 0, 0);
+        // rotate the operands a little between rounds (two VALU ops per NACC MFMAs)
+        a0.x ^= (int)it;
+        b1.y ^= (int)(it << 3);
+    }
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < NACC; a++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) t ^= acc[a][e];
+    if (t == 0x7fffffff) sink[0] = t;
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_mfma_peak(int *sink, char *report, size_t cap) {
+    QAMD_ON_DEVICE(current_device());
+    const int cu = device_info().cu_count;
+    hipEvent_t e0, e1;
+    QAMD_HIP(hipEventCreate(&e0));
+    QAMD_HIP(hipEventCreate(&e1));
+    std::string rep;
+    auto run = [&](const char *name, int threads, int nacc, auto kernel) -> qamd_status {
+        const uint32_t iters = 20000;
+        std::vector<float> ms;
+        for (int r = 0; r < 5; r++) {
+            QAMD_HIP(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(kernel, dim3(cu), dim3(threads), 0, nullptr, iters, 12345u + r, sink);
+            QAMD_HIP(hipEventRecord(e1, nullptr));
+            QAMD_HIP(hipEventSynchronize(e1));
+            float t = 0;
+            QAMD_HIP(hipEventElapsedTime(&t, e0, e1));
+            ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        const double ops = (double)cu * (threads / 64) * (double)iters * nacc * 32.0 * 32.0 * 32.0 * 2.0;
+        char line[256];
+        snprintf(line, sizeof line, "%-34s median %.3f ms  %.0f TOP/s  (%.3f of 5000)\n", name, ms[2], ops / (ms[2] * 1e-3) / 1e12,
+                 ops / (ms[2] * 1e-3) / 5e15);
+        rep += line;
+        return QAMD_OK;
+    };
+    QAMD_TRY(run("4 waves/CU, 8 accumulators", 256, 8, tune_mfma_peak<8>));
+    QAMD_TRY(run("8 waves/CU, 8 accumulators", 512, 8, tune_mfma_peak<8>));
+    QAMD_TRY(run("8 waves/CU, 4 accumulators", 512, 4, tune_mfma_peak<4>));
+    QAMD_TRY(run("4 waves/CU, 16 accumulators", 256, 16, tune_mfma_peak<16>));
+    snprintf(report, cap, "%s", rep.c_str());
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return QAMD_OK;
+}
+
 // ---------------------------------------------------------------- binary scan sweep (dim 1024)
 namespace {
 template <int UNROLL, int BLOCK, int STORE_MODE>

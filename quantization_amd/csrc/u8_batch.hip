@@ -66,6 +66,7 @@ struct BatchFilter {
     uint32_t wave_cap;
     uint32_t wave_base;     // first wave list of this launch
     uint32_t query_base;    // global index of the launch's query 0
+    int *query_bounds;      // [Qpad] scratch for the query-streaming kernel's integer bounds
 };
 
 // Developer timeline (tools/gemm_timeline.py): when set, lane 0 of every wave of the first 4096
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
 constexpr int PP_KT = 64;  // K-tile bytes per row
-constexpr uint64_t kRsMaxQueries = 768;  // batch size up to which several 128-query tiles of the row-streaming kernel are preferred
+constexpr uint64_t kQsMinQueries = 704;  // batch size from which the query-streaming kernel is preferred (rows <= 1152 B)
+constexpr uint64_t kRsMaxQueries = 703;  // batch size up to which several 128-query tiles of the row-streaming kernel are preferred
 // Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
 //   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
 //   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
@@ -962,6 +964,317 @@ __global__ __launch_bounds__(512) void u8_gemm_rs_kernel(const uint8_t *__restri
     if (MODE != 0 && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Query-streaming kernel (many queries, rows of up to 1152 code bytes).  The roles of the two
+// operands are swapped against the row-streaming kernel: a workgroup keeps a block of 128 STORE ROWS
+// resident in LDS and streams the whole query batch past it, then takes the next row block.
+//   * every row byte leaves HBM exactly once (nt), whatever the number of queries; what is re-read
+//     per row block is the QUERY batch (n_queries x row bytes, < 1 MiB per 1024 queries), and that
+//     stays in every XCD's L2 for the whole launch — no co-scheduling of workgroups needed for the
+//     reuse (the ping-pong and row-streaming kernels re-read ROWS through L2, which only works while
+//     the workgroups sharing them stay within microseconds of each other);
+//   * the batch carries a second copy of its codes in MFMA fragment order (swizzle_queries_kernel:
+//     per 32 queries and 128-byte K-block four 1 KiB pieces, lane (r, h) of piece x holding bytes
+//     [64h + 16x, +16) of query r), so a wave's streamed operand is eight fully coalesced 1 KiB
+//     loads per K-block straight into operand registers, one K-block ahead; no LDS, no transposition;
+//   * a wave takes 64 queries at a time (2 x 4 accumulator tiles of 32 x 32 against the 128 resident
+//     rows): per 32-byte k-step 4 ds_read_b128 + 8 MFMAs, half the LDS traffic per MFMA of the other
+//     two kernels; the 8 waves run independently between the two barriers of a row-block change.
+// Integer pre-filter, exact epilogue and wave-private candidate lists as in the ping-pong kernel; the
+// per-query integer bounds come precomputed from qs_bounds_kernel.
+constexpr int QS_ROWS = 128;  // resident rows per workgroup
+__global__ __launch_bounds__(256) void swizzle_queries_kernel(const uint8_t *__restrict__ codes, uint32_t pitch,
+                                                             uint32_t q_pad, uint32_t nkb, uint4 *__restrict__ out) {
+    // out[((f * nkb + kb) * 4 + x) * 64 + lane] = bytes [128 kb + 64 h + 16 x, +16) of query 32 f + r
+    const uint64_t total = (uint64_t)(q_pad / 32) * nkb * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t lane = (uint32_t)(i & 63u), x = (uint32_t)(i >> 6) & 3u;
+        const uint64_t fk = i >> 8;
+        const uint32_t kb = (uint32_t)(fk % nkb), f = (uint32_t)(fk / nkb);
+        const uint32_t r = lane & 31u, h = lane >> 5, k = kb * 128u + 64u * h + 16u * x;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < pitch) v = *reinterpret_cast<const uint4 *>(codes + (uint64_t)(32u * f + r) * pitch + k);
+        out[i] = v;
+    }
+}
+
+template <bool LOW>
+__global__ __launch_bounds__(256) void qs_bounds_kernel(const float *__restrict__ pivots, const float *__restrict__ q_offsets,
+                                                       float multiplier, int largest, uint32_t q_pad, int *__restrict__ bq) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= q_pad) return;
+    const float pv = pivots[q], qo = q_offsets[q];
+    int b = pp_bound<LOW>(pv - qo, fabsf(pv) + fabsf(qo), multiplier, 1);
+    if (__builtin_isinf(pv)) b = ((pv > 0.0f) == (largest != 0)) == LOW ? -(int)kPpLim : (int)kPpLim;
+    bq[q] = b;
+}
+
+template <int MODE, bool LOW>
+__global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restrict__ codes,
+                                                        const float *__restrict__ v_offsets,
+                                                        const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
+                                                        const int *__restrict__ bq_all, float multiplier, uint32_t n_rows,
+                                                        uint32_t n_queries, uint32_t q_pad, uint32_t ad,
+                                                        float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr int MI = 2, MJ = 4, KB = 128;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t nkb = __builtin_amdgcn_readfirstlane((ad + KB - 1) / KB);
+    const uint32_t PA = nkb * KB + 16;  // LDS pitch of a row
+    const uint32_t n_blocks = (n_rows + QS_ROWS - 1) / QS_ROWS;
+    const uint32_t n_chunks = q_pad / 64;  // 64-query chunks (q_pad is a multiple of 256: whole chunks, zero queries at the end)
+    const uint32_t live_chunks = (n_queries + 63) / 64;
+    float *voff_s = reinterpret_cast<float *>(lds_raw + (size_t)QS_ROWS * PA);  // [128]
+    int *br_s = reinterpret_cast<int *>(voff_s + QS_ROWS);                       // [128]
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(br_s + QS_ROWS) + wave;
+    int *bq_s = reinterpret_cast<int *>(br_s + QS_ROWS) + 16;                    // [64 * live_chunks] integer query bounds
+    constexpr bool LARGEST = MODE == 1;
+    if (MODE != 0 && lane == 0) *wcount_s = 0;
+    if (MODE != 0)
+        for (uint32_t i = t; i < 64 * live_chunks; i += 512) bq_s[i] = bq_all[i];
+    const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
+    (void)n_chunks;
+
+    // streamed operand: chunk c, K-block kb -> fragments 2c and 2c + 1, 4 KiB each, contiguous per fragment
+    const uint4 *q_lane = qfrag + lane;
+    v4i A0[MI][4], A1[MI][4];
+    auto load_q = [&](v4i(&a)[MI][4], uint32_t c, uint32_t kb) {
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            const uint4 *p = q_lane + ((uint64_t)(2 * c + i) * nkb + kb) * 256;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const uint4 v = p[64 * x];
+                a[i][x] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            }
+        }
+    };
+    const uint8_t *b_base = lds_raw + r * PA + 64 * h;
+
+    // Row-block fill: the block is 128 * ad contiguous bytes of the store; thread t takes the 16-byte
+    // pieces t, t + 512, ... (at most 18), requested BEFORE the barrier that frees the LDS rows (a
+    // wave that finishes its queries early has its share of the next block in flight while the others
+    // compute) and written after it.  Bytes [ad, nkb * 128) of an LDS row are never written: the
+    // query image is zero there, so whatever they hold adds nothing (integer arithmetic).
+    const uint32_t per = ad / 16;                                  // pieces per row
+    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane((QS_ROWS * per + 511) / 512);  // per thread (the last one may fall past the block)
+    const uint32_t p_row0 = (uint32_t)t / per, p_c0 = (uint32_t)t % per, d_row = 512 / per, d_c = 512 % per;
+    constexpr int MAXP = 18;
+    v4i st[MAXP];
+    float vo_pf = 0.0f;  // v_offset of row t of the requested block (threads 0..127)
+    // every element is (re)defined on every call (pieces past the count re-read the last one): a
+    // conditional definition would keep the old value alive through the whole query loop (spills).
+    // A thread's last piece may lie just past the block: in the store's row padding, never written.
+    // (Requesting the pieces BEFORE the wave's last epilogue, to take the last wave's HBM round trip
+    // out of the block change, was tried: accumulators + pieces + epilogue temporaries do not fit in
+    // 256 registers, and the spills cost more than the round trip.)
+    auto fill_request = [&](uint32_t blk) {
+        const uint8_t *p = codes + (uint64_t)blk * QS_ROWS * ad + (size_t)t * 16;
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;  // wave-uniform
+            st[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + (size_t)ii * 8192));
+        }
+        vo_pf = v_offsets[(uint64_t)blk * QS_ROWS + (t & (QS_ROWS - 1))];  // padded like codes[]
+    };
+    auto fill_write = [&]() {
+        uint32_t row = p_row0, c = p_c0;
+        asm volatile("" : "+v"(row), "+v"(c));  // the 18 LDS addresses are recomputed per block, not kept (and spilled)
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            if ((uint32_t)i < n_pieces && row < (uint32_t)QS_ROWS) *reinterpret_cast<v4i *>(lds_raw + row * PA + c * 16) = st[i];
+            row += d_row;
+            c += d_c;
+            if (c >= per) {
+                c -= per;
+                row++;
+            }
+        }
+    };
+    const uint32_t my_first = wave;  // this wave's first chunk of every row block
+    // developer timeline (libquantization_amd_dev.so only): cycles per phase, summed over the row blocks
+    unsigned long long *stamps = QAMD_GEMM_STAMPS();
+    const bool timed = stamps != nullptr;
+    unsigned long long tm_prev = timed ? __builtin_amdgcn_s_memtime() : 0ull, tm_acc[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int slot) {
+        if (timed) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tm_acc[slot] += now - tm_prev;
+            tm_prev = now;
+        }
+    };
+    fill_request(blockIdx.x < n_blocks ? blockIdx.x : 0u);
+    if (my_first < live_chunks) load_q(A0, my_first, 0);
+
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t row0 = (uint64_t)blk * QS_ROWS;
+        const uint32_t next_blk = blk + gridDim.x < n_blocks ? blk + gridDim.x : blk;  // past the end: re-request (always defined)
+        lap(5);  // (request issue, loop overhead)
+        __syncthreads();  // every wave is done with the previous block's rows
+        lap(0);  // waiting for the other waves
+        fill_write();
+        if (t < QS_ROWS) {
+            const bool ok = row0 + t < n_rows;
+            const float vo = vo_pf;  // requested with the rows
+            voff_s[t] = ok ? vo : never;
+            if (MODE != 0) br_s[t] = ok ? pp_bound<LOW>(-vo, fabsf(vo), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+        }
+        __syncthreads();
+        lap(1);  // own pieces landing + LDS writes + second barrier
+
+        for (uint32_t c = wave; c < live_chunks; c += 8) {
+            // the chunk whose first K-block is requested under this chunk's last MFMAs (of this row
+            // block, or the first one of the next: the queries do not depend on the rows)
+            const uint32_t c_next = c + 8 < live_chunks ? c + 8 : my_first;
+            v16i acc[MI][MJ];
+            int br[MJ];
+#pragma unroll
+            for (int jj = 0; jj < MJ; jj++) br[jj] = MODE != 0 ? br_s[jj * 32 + r] : 0;
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int jj = 0; jj < MJ; jj++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[i][jj][e] = 0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + 64 * c + i * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+#pragma unroll
+                            for (int jj = 0; jj < MJ; jj++) acc[i][jj][4 * gq + e] = -(bq4[e] + br[jj]);
+                    }
+            }
+            auto compute = [&](const v4i(&a)[MI][4], uint32_t kb) {
+                const uint8_t *pb = b_base + kb * KB;
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    v4i bf[MJ];
+#pragma unroll
+                    for (int jj = 0; jj < MJ; jj++) bf[jj] = *reinterpret_cast<const v4i *>(pb + (uint32_t)jj * 32u * PA + 16 * x);
+#pragma unroll
+                    for (int i = 0; i < MI; i++)
+#pragma unroll
+                        for (int jj = 0; jj < MJ; jj++)
+                            acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][x], bf[jj], acc[i][jj], 0, 0, 0);
+                }
+            };
+            // Two K-blocks per turn, each requested a K-block ahead (sched_barrier: the eight loads are
+            // issued HERE; left alone the scheduler sinks each load to just before its first use and
+            // the wave stalls on every L2 round trip).  The request after the chunk's last K-block is
+            // the next chunk's first one.
+            lap(2);  // accumulator set-up
+            // The two waves of a SIMD take turns at instruction priority, chunk by chunk: left alone the
+            // older wave (0..3) wins the MFMA arbitration every time, finishes its chunks a quarter
+            // earlier and idles at the barrier while the other one runs alone.
+            if (((c >> 3) + ((uint32_t)wave >> 2)) & 1u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+            uint32_t kb = 0;
+            for (; kb + 1 < nkb; kb += 2) {
+                load_q(A1, c, kb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(A0, kb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + 2 < nkb) load_q(A0, c, kb + 2);
+                else load_q(A0, c_next, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(A1, kb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool odd = kb < nkb;
+            if (odd) {  // odd K-block count: the next chunk's first block arrives in A1 and is moved after the epilogue
+                load_q(A1, c_next, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(A0, kb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            lap(3);  // K loop
+            // ---- epilogue: 64 queries x 128 rows of this wave
+            uint32_t c_e = c, wave_e = (uint32_t)wave, lane_e = (uint32_t)lane;
+            asm volatile("" : "+s"(c_e), "+s"(wave_e), "+v"(lane_e));
+            uint4 *wave_list = MODE != 0 ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
+            const uint32_t r_e = lane_e & 31u, h_e = lane_e >> 5;
+#pragma unroll
+            for (int jj = 0; jj < MJ; jj++) {
+                const uint64_t row = row0 + jj * 32 + r_e;
+                const bool row_ok = row < n_rows;
+                const float v_off = voff_s[jj * 32 + r_e];
+                const int brj = br[jj];
+#pragma unroll
+                for (int i = 0; i < MI; i++) {
+                    if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
+                    if (MODE != 0) {
+                        int all = acc[i][jj][0];
+#pragma unroll
+                        for (int e = 1; e < 16; e++) all = LOW ? (all | acc[i][jj][e]) : (all & acc[i][jj][e]);
+                        if (!__builtin_amdgcn_readfirstlane(__ballot(LOW ? all < 0 : all >= 0) != 0)) continue;
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const uint32_t q = 64 * c_e + i * 32 + 8 * gq + 4 * h_e;  // first of four consecutive queries
+                        if (MODE == 0) {
+                            const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+                            const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float sc = (multiplier * (float)acc[i][jj][4 * gq + e] + qo[e]) + v_off;
+                                if (row_ok && q + e < n_queries) out[(uint64_t)(q + e) * out_pitch + row] = sc;
+                            }
+                        } else {
+                            const int a0 = acc[i][jj][4 * gq], a1 = acc[i][jj][4 * gq + 1], a2 = acc[i][jj][4 * gq + 2],
+                                      a3 = acc[i][jj][4 * gq + 3];
+                            const bool may_pass = LOW ? ((a0 | a1 | a2 | a3) < 0) : ((a0 & a1 & a2 & a3) >= 0);
+                            if (may_pass) {
+                                const v4i bq4 = *reinterpret_cast<const v4i *>(bq_all + q);
+                                const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+                                const float4 pv4 = *reinterpret_cast<const float4 *>(filt.pivot_scores + q);
+                                const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                                const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                                const int av[4] = {a0, a1, a2, a3};
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int s_int = av[e] + bq4[e] + brj;  // the plain integer dot product
+                                    const float sc = (multiplier * (float)s_int + qo[e]) + v_off;
+                                    const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
+                                    if (d >= 0.0f) {
+                                        const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                        if (pos < filt.wave_cap)
+                                            wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row,
+                                                                        filt.query_base + q + e, 0u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (odd) {
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) A0[i][x] = A1[i][x];
+            }
+            lap(4);  // epilogue
+        }
+        // this wave's share of the next row block: requested as soon as its own chunks are done (the
+        // accumulators are dead, their registers hold the pieces until the barrier)
+        fill_request(next_blk);
+    }
+    if (timed && lane == 0 && blockIdx.x < kStampBlocks) {
+        unsigned long long *o = stamps + ((uint64_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 6; i++) o[i] = tm_acc[i];
+        o[15] = 1;
+    }
+    if (MODE != 0 && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+}
+
 // Gather `n` sampled rows (codes + offsets) into a dense sub-store for the pivot pass, followed by
 // `pad` zero rows (the GEMM kernels read whole row tiles).
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *__restrict__ codes,
@@ -1104,6 +1417,8 @@ struct qamd_u8_query_batch {
     uint64_t pitch = 0;  // round_up(actual_dim, 64): whole 64-byte K-tiles, zero padded
     DevBuf codes;        // [q_pad][pitch], zero rows past n_queries
     DevBuf offsets;      // [q_pad] f32
+    DevBuf frag;         // the codes again in MFMA fragment order (swizzle_queries_kernel), for u8_gemm_qs_kernel
+    uint32_t frag_nkb = 0;  // 128-byte K-blocks per query in `frag`
 };
 
 namespace {
@@ -1260,7 +1575,8 @@ qamd_status launch_gemm_rs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
 }
 
 // Queries per launch slice of the kernel that serves this batch (wave-list bookkeeping).
-inline uint32_t gemm_launches(const qamd_u8 *h, const qamd_u8_query_batch *b, bool rs) {
+inline uint32_t gemm_launches(const qamd_u8 *h, const qamd_u8_query_batch *b, bool rs, bool qs) {
+    if (qs) return (uint32_t)((b->n_queries + 2048 - 1) / 2048);
     if (!rs) return pp_launches(b->n_queries);
     const uint64_t per = (uint64_t)std::max(1, device_info().cu_count / 8) * 32 * rs_frags(b->n_queries, h->meta.actual_dim);
     return (uint32_t)((b->n_queries + per - 1) / per);
@@ -1273,6 +1589,70 @@ bool pp_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
     if (cfg && cfg[0] != 'p') return false;
     const float m = h->meta.multiplier;
     return h->meta.actual_dim > 128 && h->meta.actual_dim <= 32768 && (!filter_mode || (std::isfinite(m) && m != 0.0f));
+}
+
+// Query-streaming kernel launch: one persistent workgroup per CU, slices of kQsSlice queries (the
+// slice's fragment-order codes, 1.5 MiB at 768-byte rows, stay in every XCD's L2).
+constexpr uint64_t kQsSlice = 2048;
+template <int MODE, bool LOW>
+qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                               const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                               const BatchFilter &filt, const int *bq, hipStream_t s) {
+    static std::atomic<uint64_t> set_on{0};
+    if (first_use_on_device(set_on))
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs_kernel<MODE, LOW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const uint32_t nkb = b->frag_nkb;
+    const size_t lds_bytes = (size_t)QS_ROWS * (nkb * 128 + 16) + 2 * QS_ROWS * 4 + 64 + kQsSlice * 4;
+    const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
+    for (uint64_t q_base = 0; q_base < b->n_queries; q_base += kQsSlice) {
+        const uint32_t nq = (uint32_t)std::min<uint64_t>(kQsSlice, b->n_queries - q_base);
+        BatchFilter f = filt;
+        if (MODE != 0) {
+            f.pivot_scores += q_base;
+            f.query_base = (uint32_t)q_base;
+            f.wave_base = (uint32_t)(q_base / kQsSlice) * pp_waves_per_launch();
+        }
+        hipLaunchKernelGGL((u8_gemm_qs_kernel<MODE, LOW>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
+                           b->frag.as<uint4>() + (q_base / 32) * nkb * 256, b->offsets.as<float>() + q_base,
+                           MODE != 0 ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,
+                           (uint32_t)round_up((uint64_t)nq, 64), (uint32_t)h->meta.actual_dim,
+                           MODE == 0 ? out + q_base * out_pitch : out, out_pitch, f);
+        QAMD_HIP(hipGetLastError());
+    }
+    return QAMD_OK;
+}
+
+template <int MODE>
+qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                           const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                           const BatchFilter &filt, hipStream_t s) {
+    if (MODE == 0) return launch_gemm_qs_cfg<0, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    constexpr int M = MODE == 0 ? 1 : MODE;
+    const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
+    // per-query integer bounds of the pre-filter, behind the pivots in stream order
+    int *bq = filt.query_bounds;
+    if (low)
+        hipLaunchKernelGGL(qs_bounds_kernel<true>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
+                           b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
+    else
+        hipLaunchKernelGGL(qs_bounds_kernel<false>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
+                           b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
+    QAMD_HIP(hipGetLastError());
+    return low ? launch_gemm_qs_cfg<M, true>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
+               : launch_gemm_qs_cfg<M, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
+}
+
+// The query-streaming kernel: rows short enough for a 128-row block in LDS, a fragment-order copy in
+// the batch, enough queries to keep the 8 waves of a workgroup busy (64 queries per wave and turn).
+bool qs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
+    static const char *cfg = getenv("QAMD_GEMM_CFG");
+    if (cfg && cfg[0] != 'q') return false;
+    const float m = h->meta.multiplier;
+    if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
+    if (!b->frag.ptr || b->frag_nkb == 0 || b->frag_nkb > 9) return false;
+    if (cfg) return true;
+    return b->n_queries >= kQsMinQueries;
 }
 
 // The row-streaming kernel: where the ping-pong kernel could run (same pre-filter conditions), the
@@ -1300,6 +1680,7 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
                         const BatchFilter &filt, hipStream_t s) {
     if (n_rows == 0 || b->n_queries == 0) return QAMD_OK;
     // q_pad is a multiple of 256 and the row padding of every store covers a 256-row tile.
+    if (qs_selected(h, b, MODE != 0)) return launch_gemm_qs<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (rs_selected(h, b, MODE != 0)) return launch_gemm_rs<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (pp_selected(h, b, MODE != 0)) return launch_gemm_pp<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (b->n_queries > 128) {
@@ -1393,6 +1774,17 @@ qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, u
             qd = tmp.as<float>();
         }
         QAMD_TRY(u8_encode_queries_device(h, qd, n_queries, qdim, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), s));
+        const uint32_t nkb = (uint32_t)((ad + 127) / 128);
+        if (nkb <= 9) {  // rows the query-streaming kernel can hold: the codes again, in MFMA fragment order
+            const size_t frag_bytes = (size_t)(q_pad / 32) * nkb * 4096;
+            if (b->frag.bytes < frag_bytes) QAMD_TRY(b->frag.alloc(frag_bytes));
+            b->frag_nkb = nkb;
+            hipLaunchKernelGGL(swizzle_queries_kernel, dim3((unsigned)std::min<uint64_t>(2048, (frag_bytes / 16 + 255) / 256)),
+                               dim3(256), 0, s, b->codes.as<uint8_t>(), (uint32_t)b->pitch, (uint32_t)q_pad, nkb, b->frag.as<uint4>());
+            QAMD_HIP(hipGetLastError());
+        } else {
+            b->frag_nkb = 0;
+        }
         if (queries_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
     }
     if (fresh) *batch_io = fresh.release();
@@ -1482,12 +1874,13 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         const uint64_t ad = h->meta.actual_dim;
         // ONE stream-ordered allocation for all scratch of the call, carved up below: hipFreeAsync
         // costs ~65 us per buffer on this runtime, and ten buffers were a third of a small batch's time.
-        const bool rs = rs_selected(h, b, true);
-        const bool pp = rs || pp_selected(h, b, true);  // both append to wave-private lists
+        const bool qs = qs_selected(h, b, true);
+        const bool rs = !qs && rs_selected(h, b, true);
+        const bool pp = qs || rs || pp_selected(h, b, true);  // all three append to wave-private lists
         uint32_t n_lists = 0, wave_cap = 0;
         if (pp) {
             // wave-private lists: 4x the expected appends per wave (about `target`..2*target per query)
-            n_lists = gemm_launches(h, b, rs) * pp_waves_per_launch();
+            n_lists = gemm_launches(h, b, rs, qs) * pp_waves_per_launch();
             const double per_wave = 2.0 * target * (double)Q / (double)n_lists;
             wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(1024.0, 4.0 * per_wave));
         }
@@ -1512,6 +1905,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         const size_t o_scores = reserve(Q * (uint64_t)S * 4);
         const size_t o_cand = reserve(Q * (uint64_t)kBatchCap * 8);
         const size_t o_status = reserve((Q + 1) * 4);  // per-query status, then the wave-list overflow flag
+        const size_t o_bounds = reserve(b->q_pad * 4);
         const size_t o_wcand = reserve((uint64_t)n_lists * wave_cap * sizeof(uint4));
         StreamBuf arena;
         QAMD_TRY(arena.alloc(arena_bytes, s));
@@ -1547,6 +1941,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         f.counters = counters;
         f.candidates = cand;
         f.largest = largest;
+        f.query_bounds = reinterpret_cast<int *>(base + o_bounds);
         if (pp) {
             f.wave_cap = wave_cap;
             f.wave_cand = wave_cand;

@@ -353,3 +353,53 @@ print("ok")
     env = dict(os.environ, QAMD_GEMM_CFG="r", PYTHONPATH=root)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0 and "ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
+
+
+# ---- query-streaming kernel (u8_gemm_qs_kernel): 704 queries or more, rows of up to 1152 code bytes
+@pytest.mark.parametrize("n,dim,nq", [
+    (40_003, 96, 704),      # one K-block per row (odd count)
+    (35_000, 200, 800),     # row length 208, two K-blocks; 13 query chunks over 8 waves
+    (70_001, 384, 1024),    # three K-blocks (odd), two chunks per wave, several row blocks per workgroup, ragged tail
+    (33_000, 1152, 720),    # the longest row the resident block holds
+    (33_000, 1168, 720),    # one step longer: ping-pong kernel
+    (34_000, 128, 2100),    # two launch slices of 2048 queries
+])
+def test_query_streaming_kernel_shapes(n, dim, nq, qo):
+    rng = np.random.default_rng(n + dim + nq)
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    for dist, invert, largest in ((D.Dot, False, True), (D.L2, True, False)):
+        enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
+        batch = enc.encode_query_batch(queries)
+        picks = sorted({0, 1, 63, 64, nq // 3, nq // 2, nq - 65, nq - 2, nq - 1})
+        if dist == D.Dot:  # scores of the whole batch: a few queries against the oracle
+            got = enc.score_batch(batch)
+            rows, meta = qo.u8_encode(data, int(dist), invert)
+            for qi in picks[::3]:
+                codes, qoff = qo.u8_encode_query(meta, queries[qi])
+                want = qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_SIMPLE)
+                assert_bits_equal(got[qi], want, f"{dist} query {qi} vs oracle")
+            del got
+        ids, sc = enc.topk_batch(batch, 30, largest=largest)
+        qobj = None
+        for qi in picks:
+            qobj = enc.encode_query(queries[qi], reuse=qobj)
+            wi, ws = enc.topk(qobj, 30, largest=largest)
+            assert np.array_equal(ids[qi], wi), (qi, n, dim)
+            assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (qi, n, dim)
+
+
+def test_query_streaming_kernel_reused_batch_object():
+    """A batch object re-encoded with other queries (same shape) rebuilds its fragment-order copy."""
+    rng = np.random.default_rng(11)
+    n, dim, nq = 50_000, 256, 768
+    data = rng.random((n, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    batch = None
+    for rep in range(2):
+        queries = rng.random((nq, dim), dtype=np.float32)
+        batch = enc.encode_query_batch(queries, reuse=batch)
+        ids, sc = enc.topk_batch(batch, 10)
+        for qi in (0, 400, nq - 1):
+            wi, ws = enc.topk(enc.encode_query(queries[qi]), 10)
+            assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (rep, qi)

@@ -40,7 +40,25 @@ torch.cuda.synchronize()
 L.qamd_dev_gemm_stamps(None)
 print(f"topk_batch with stamps: {e0.elapsed_time(e1):.2f} ms")
 st = stamps.cpu().numpy().reshape(4096, WAVES, 16)
-if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "p":
+if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "q":
+    # query-streaming kernel: per wave, cycles summed over its row blocks
+    blk = st[:256]
+    ok = (blk[:, :, 15] > 0).all(axis=1)
+    blk = blk[ok].astype(np.float64)
+    tot = blk[:, :, :6].sum(axis=2).mean()
+    names = ["barrier 1 (waiting for the other waves)", "row pieces landing + LDS writes + barrier 2", "accumulator set-up",
+             "K loop", "epilogue", "row request + loop overhead"]
+    print("workgroups with stamps:", blk.shape[0], " cycles per wave (mean):", int(tot))
+    for i, nm in enumerate(names):
+        x = blk[:, :, i]
+        print(f"  {nm:46s} {x.mean():12.0f}  {100 * x.mean() / tot:5.1f} %   (p10 {np.percentile(x, 10):10.0f}, p90 {np.percentile(x, 90):10.0f})")
+    n_blocks = (n + 127) // 128 / 256
+    mf = n_blocks * ((nq + 63) // 64) / 8 * ((enc.metadata["actual_dim"] + 127) // 128) * 32
+    print(f"  MFMAs per wave {mf:.0f}: K loop cycles per MFMA {blk[:, :, 3].mean() / mf:.1f} (two waves share a SIMD: 64 nominal)")
+    for i in (0, 3, 4):
+        print("  per wave index,", names[i][:24], ":", " ".join(f"{v/1e3:8.0f}k" for v in blk[:, :, i].mean(axis=0)))
+    sys.exit(0)
+elif os.environ.get("QAMD_GEMM_CFG", "p")[0] == "p":
     # ping-pong kernel: persistent workgroups; slot 0 entry, 1 prologue done, 2..9 MFMAs of tile
     # 0..7 issued, 10 end of the last stamped epilogue, 12 exit
     blk = st[:256]
