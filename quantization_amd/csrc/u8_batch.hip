@@ -982,7 +982,6 @@ __global__ __launch_bounds__(512) void u8_gemm_rs_kernel(const uint8_t *__restri
 //     two kernels; the 8 waves run independently between the two barriers of a row-block change.
 // Integer pre-filter, exact epilogue and wave-private candidate lists as in the ping-pong kernel; the
 // per-query integer bounds come precomputed from qs_bounds_kernel.
-constexpr int QS_ROWS = 128;  // resident rows per workgroup
 __global__ __launch_bounds__(256) void swizzle_queries_kernel(const uint8_t *__restrict__ codes, uint32_t pitch,
                                                              uint32_t q_pad, uint32_t nkb, uint4 *__restrict__ out) {
     // out[((f * nkb + kb) * 4 + x) * 64 + lane] = bytes [128 kb + 64 h + 16 x, +16) of query 32 f + r
@@ -1009,7 +1008,7 @@ __global__ __launch_bounds__(256) void qs_bounds_kernel(const float *__restrict_
     bq[q] = b;
 }
 
-template <int MODE, bool LOW>
+template <int MODE, bool LOW, int MJ>  // MJ: 32-row fragments resident (4: rows of up to 1152 B; 3: up to 1536 B)
 __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restrict__ codes,
                                                         const float *__restrict__ v_offsets,
                                                         const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
@@ -1017,7 +1016,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
                                                         uint32_t n_queries, uint32_t q_pad, uint32_t ad,
                                                         float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
-    constexpr int MI = 2, MJ = 4, KB = 128;
+    constexpr int MI = 2, KB = 128, QS_ROWS = 32 * MJ;  // resident rows per workgroup
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -1077,7 +1076,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
             const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;  // wave-uniform
             st[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + (size_t)ii * 8192));
         }
-        vo_pf = v_offsets[(uint64_t)blk * QS_ROWS + (t & (QS_ROWS - 1))];  // padded like codes[]
+        vo_pf = v_offsets[(uint64_t)blk * QS_ROWS + (t < QS_ROWS ? t : 0)];  // padded like codes[]
     };
     auto fill_write = [&]() {
         uint32_t row = p_row0, c = p_c0;
@@ -1594,15 +1593,16 @@ bool pp_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
 // Query-streaming kernel launch: one persistent workgroup per CU, slices of kQsSlice queries (the
 // slice's fragment-order codes, 1.5 MiB at 768-byte rows, stay in every XCD's L2).
 constexpr uint64_t kQsSlice = 2048;
-template <int MODE, bool LOW>
+template <int MODE, bool LOW, int MJ>
 qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                                const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                                const BatchFilter &filt, const int *bq, hipStream_t s) {
     static std::atomic<uint64_t> set_on{0};
     if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs_kernel<MODE, LOW>),
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs_kernel<MODE, LOW, MJ>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t nkb = b->frag_nkb;
+    constexpr int QS_ROWS = 32 * MJ;
     const size_t lds_bytes = (size_t)QS_ROWS * (nkb * 128 + 16) + 2 * QS_ROWS * 4 + 64 + kQsSlice * 4;
     const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
     for (uint64_t q_base = 0; q_base < b->n_queries; q_base += kQsSlice) {
@@ -1613,7 +1613,7 @@ qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
             f.query_base = (uint32_t)q_base;
             f.wave_base = (uint32_t)(q_base / kQsSlice) * pp_waves_per_launch();
         }
-        hipLaunchKernelGGL((u8_gemm_qs_kernel<MODE, LOW>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
+        hipLaunchKernelGGL((u8_gemm_qs_kernel<MODE, LOW, MJ>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
                            b->frag.as<uint4>() + (q_base / 32) * nkb * 256, b->offsets.as<float>() + q_base,
                            MODE != 0 ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,
                            (uint32_t)round_up((uint64_t)nq, 64), (uint32_t)h->meta.actual_dim,
@@ -1627,7 +1627,10 @@ template <int MODE>
 qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
-    if (MODE == 0) return launch_gemm_qs_cfg<0, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    const bool wide = b->frag_nkb <= 9;  // 128 resident rows fit (rows of up to 1152 B), else 96
+    if (MODE == 0)
+        return wide ? launch_gemm_qs_cfg<0, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
+                    : launch_gemm_qs_cfg<0, false, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
     constexpr int M = MODE == 0 ? 1 : MODE;
     const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
     // per-query integer bounds of the pre-filter, behind the pivots in stream order
@@ -1639,8 +1642,11 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
         hipLaunchKernelGGL(qs_bounds_kernel<false>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
                            b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
     QAMD_HIP(hipGetLastError());
-    return low ? launch_gemm_qs_cfg<M, true>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
-               : launch_gemm_qs_cfg<M, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
+    if (wide)
+        return low ? launch_gemm_qs_cfg<M, true, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
+                   : launch_gemm_qs_cfg<M, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
+    return low ? launch_gemm_qs_cfg<M, true, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
+               : launch_gemm_qs_cfg<M, false, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
 }
 
 // The query-streaming kernel: rows short enough for a 128-row block in LDS, a fragment-order copy in
@@ -1650,7 +1656,7 @@ bool qs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
     if (cfg && cfg[0] != 'q') return false;
     const float m = h->meta.multiplier;
     if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
-    if (!b->frag.ptr || b->frag_nkb == 0 || b->frag_nkb > 9) return false;
+    if (!b->frag.ptr || b->frag_nkb == 0 || b->frag_nkb > 12) return false;
     if (cfg) return true;
     return b->n_queries >= kQsMinQueries;
 }
@@ -1775,7 +1781,7 @@ qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, u
         }
         QAMD_TRY(u8_encode_queries_device(h, qd, n_queries, qdim, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), s));
         const uint32_t nkb = (uint32_t)((ad + 127) / 128);
-        if (nkb <= 9) {  // rows the query-streaming kernel can hold: the codes again, in MFMA fragment order
+        if (nkb <= 12) {  // rows the query-streaming kernel can hold: the codes again, in MFMA fragment order
             const size_t frag_bytes = (size_t)(q_pad / 32) * nkb * 4096;
             if (b->frag.bytes < frag_bytes) QAMD_TRY(b->frag.alloc(frag_bytes));
             b->frag_nkb = nkb;

@@ -355,13 +355,15 @@ print("ok")
     assert res.returncode == 0 and "ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
 
 
-# ---- query-streaming kernel (u8_gemm_qs_kernel): 704 queries or more, rows of up to 1152 code bytes
+# ---- query-streaming kernel (u8_gemm_qs_kernel): 704 queries or more, rows of up to 1536 code bytes
 @pytest.mark.parametrize("n,dim,nq", [
     (40_003, 96, 704),      # one K-block per row (odd count)
     (35_000, 200, 800),     # row length 208, two K-blocks; 13 query chunks over 8 waves
     (70_001, 384, 1024),    # three K-blocks (odd), two chunks per wave, several row blocks per workgroup, ragged tail
-    (33_000, 1152, 720),    # the longest row the resident block holds
-    (33_000, 1168, 720),    # one step longer: ping-pong kernel
+    (33_000, 1152, 720),    # the longest row a 128-row resident block holds
+    (33_000, 1168, 720),    # one step longer: 96 resident rows
+    (40_000, 1536, 800),    # the longest row 96 resident rows hold
+    (33_000, 1552, 704),    # one step longer: ping-pong kernel
     (34_000, 128, 2100),    # two launch slices of 2048 queries
 ])
 def test_query_streaming_kernel_shapes(n, dim, nq, qo):
