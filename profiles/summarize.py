@@ -5,7 +5,8 @@ profiles/.  Kernel names are shortened (torch's are kilobytes long).
     python profiles/summarize.py stats <kernel_stats.csv> <out.csv>
     python profiles/summarize.py pmc   <fetch_counter_collection.csv> <write_counter_collection.csv> \
                                        <kernel-substring> <rows_per_launch> <row_read_bytes> <out.json> [commit]
-(profiles/collect.sh runs both on the GPU box.)
+    python profiles/summarize.py counters <counter_collection.csv> <kernel-substring> <out.txt> [more csv ...]
+(profiles/collect.sh and profiles/collect_batch.sh run them on the GPU box.)
 
 PMC correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so
@@ -33,6 +34,28 @@ def kernel_source_hash(root=None):
     b = src.find(b"// NQ (2, 4, 8) queries per row read on the vector ALU")
     region = src[a:b] if 0 <= a < b else src
     return hashlib.sha256(region).hexdigest()[:16]
+
+
+def counters(paths, needle, dst):
+    """Mean per launch of every counter collected for kernels whose name contains `needle`."""
+    acc, durs = {}, []
+    for path in paths:
+        seen = set()
+        for r in csv.DictReader(open(path)):
+            if needle not in r["Kernel_Name"]:
+                continue
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            key = r.get("Dispatch_Id", r["Start_Timestamp"])
+            if key not in seen:
+                seen.add(key)
+                durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    lines = [f"kernel name contains: {needle}",
+             f"launches sampled: {len(durs)}   mean duration under the counter passes: {sum(durs) / max(1, len(durs)) / 1e6:.3f} ms"]
+    for name in sorted(acc):
+        v = acc[name]
+        lines.append(f"{name:34s} mean per launch {sum(v) / len(v):.4e}   ({len(v)} samples)")
+    open(dst, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
 
 
 def stats(src, dst):
@@ -78,6 +101,10 @@ def pmc(fetch_csv, write_csv, needle, rows_per_launch, row_read_bytes, dst, comm
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "counters":
+    counters([sys.argv[2]] + sys.argv[5:], sys.argv[3], sys.argv[4])
+    sys.exit(0)
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":

@@ -136,7 +136,7 @@ if "batch" in which:
         pass  # no empty_cache: returning tens of GB to the driver starts a VRAM scrub that slows (up to 4x) whatever runs next
         torch.cuda.synchronize()
         time.sleep(3)  # let the driver finish clearing what the encode allocated / freed
-        for nq in [int(x) for x in os.environ.get("BATCH_NQ", "4,8,16,32,64,256,1024").split(",")]:
+        for nq in [int(x) for x in os.environ.get("BATCH_NQ", "2,3,4,5,16,64,128,256,512,768,1024,2048").split(",")]:
             queries = torch.rand((nq, dim), device=dev)
             batch = enc.encode_query_batch(queries)
             ids = torch.empty(nq * 30, dtype=torch.int32, device=dev)
@@ -148,6 +148,7 @@ if "batch" in which:
                               "query_rows_per_s": round(nq * n / med / 1e6, 2), "unit": "G (query,row) pairs/s",
                               "int8_TOPs": round(ops / med / 1e9, 1),
                               "frac_of_5000_TOPs_dense_i8_peak": round(ops / med / 1e9 / 5000, 4),
+                              "frac_of_3650_TOPs_measured_mfma_issue_ceiling": round(ops / med / 1e9 / 3650, 4),
                               "store_GBps_if_read_once": round(n * enc.scan_bytes_per_row() / med / 1e6, 1),
                               "speedup_vs_single_query_loop_at_1.12ms": round(nq * 1.12 * (n / 1e7) * (dim / 768) / med, 1)}),
                   flush=True)
