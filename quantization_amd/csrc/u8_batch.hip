@@ -295,8 +295,13 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
 constexpr int PP_KT = 64;  // K-tile bytes per row
-constexpr uint64_t kQsMinQueries = 704;  // batch size from which the query-streaming kernel is preferred (rows <= 1152 B)
-constexpr uint64_t kRsMaxQueries = 703;  // batch size up to which several 128-query tiles of the row-streaming kernel are preferred
+// Batch size from which the query-streaming kernel is preferred, by 128-byte K-blocks per row (measured,
+// whole topk_batch(30) calls at 7.68 GB of rows; below it several 128-query tiles of the row-streaming
+// kernel, or the ping-pong kernel where only 64-query tiles fit):
+//   rows <= 384 B : 30M x 256:    640 q  rs 7.1  qs 8.5  pp 9.5 ms;  1024 q  qs 10.3  pp 11.4
+//   rows <= 1152 B: 10M x 768:    640 q  rs 5.65 qs 6.0  pp 7.2;      768 q  rs 6.6   qs 6.2
+//   rows <= 1536 B: 12.5M x 1536: 256 q  pp 5.84 qs 6.34; 384 q  pp 10.3 qs 8.8; 640 q  pp 16.1 qs 13.8
+inline uint64_t qs_min_queries(uint32_t nkb) { return nkb <= 3 ? 960 : nkb <= 9 ? 704 : 320; }
 // Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
 //   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
 //   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
@@ -1072,9 +1077,19 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
     auto fill_request = [&](uint32_t blk) {
         const uint8_t *p = codes + (uint64_t)blk * QS_ROWS * ad + (size_t)t * 16;
 #pragma unroll
-        for (int i = 0; i < MAXP; i++) {
+        for (int i = 0; i < 12; i++) {
             const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;  // wave-uniform
             st[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + (size_t)ii * 8192));
+        }
+        if (n_pieces > 12) {  // rows longer than 768 B
+#pragma unroll
+            for (int i = 12; i < MAXP; i++) {
+                const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;
+                st[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + (size_t)ii * 8192));
+            }
+        } else {  // "defined" without an instruction: keeps the old values from staying alive (see above)
+#pragma unroll
+            for (int i = 12; i < MAXP; i++) asm volatile("" : "=v"(st[i]));
         }
         vo_pf = v_offsets[(uint64_t)blk * QS_ROWS + (t < QS_ROWS ? t : 0)];  // padded like codes[]
     };
@@ -1210,10 +1225,15 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
                 for (int i = 0; i < MI; i++) {
                     if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
                     if (MODE != 0) {
-                        int all = acc[i][jj][0];
+                        // "some accumulator of the tile may pass" = the smallest is negative (LOW) / the
+                        // largest is not: v_min3 / v_max3 fold two values per instruction
+                        int ext = acc[i][jj][0];
 #pragma unroll
-                        for (int e = 1; e < 16; e++) all = LOW ? (all | acc[i][jj][e]) : (all & acc[i][jj][e]);
-                        if (!__builtin_amdgcn_readfirstlane(__ballot(LOW ? all < 0 : all >= 0) != 0)) continue;
+                        for (int e = 1; e < 15; e += 2)
+                            ext = LOW ? min(min(ext, acc[i][jj][e]), acc[i][jj][e + 1])
+                                      : max(max(ext, acc[i][jj][e]), acc[i][jj][e + 1]);
+                        ext = LOW ? min(ext, acc[i][jj][15]) : max(ext, acc[i][jj][15]);
+                        if (!__builtin_amdgcn_readfirstlane(__ballot(LOW ? ext < 0 : ext >= 0) != 0)) continue;
                     }
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++) {
@@ -1658,7 +1678,7 @@ bool qs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
     if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
     if (!b->frag.ptr || b->frag_nkb == 0 || b->frag_nkb > 12) return false;
     if (cfg) return true;
-    return b->n_queries >= kQsMinQueries;
+    return b->n_queries >= qs_min_queries(b->frag_nkb);
 }
 
 // The row-streaming kernel: where the ping-pong kernel could run (same pre-filter conditions), the
@@ -1677,7 +1697,7 @@ bool rs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
     // 10M x 768: 160 q 2.22 vs 2.41 ms, 384 q 3.39 vs 4.51, 512 q 4.29 vs 4.66, 1024 q 8.64 vs 8.70)
     // and loses with the 64-query tiles of longer rows (12.5M x 1536: 96 q 3.88 vs 3.74, 256 q 6.83 vs 5.58).
     const uint64_t tiles = (b->n_queries + 32 * mi - 1) / (32 * mi);
-    return tiles == 1 || (mi == 4 && b->n_queries <= kRsMaxQueries);
+    return tiles == 1 || (mi == 4 && b->n_queries < qs_min_queries((uint32_t)((h->meta.actual_dim + 127) / 128)));
 }
 
 template <int MODE>
