@@ -1834,7 +1834,9 @@ qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, 
         out_dev = tmp.as<float>();
     }
     const uint32_t width = u8_multi_width(h);
-    if (h->meta.vector_parameters.distance_type == QAMD_L1 || (width && b->n_queries >= 2 && b->n_queries <= width)) {
+    // (from three queries on the row-streaming MFMA kernel streams the rows as fast and does not slow down per query)
+    if (h->meta.vector_parameters.distance_type == QAMD_L1 ||
+        (width && b->n_queries >= 2 && b->n_queries <= width && (b->n_queries == 2 || !rs_selected(h, b, false)))) {
         // sum |q - v| is not a contraction (no MFMA form), and for a handful of queries the vector-ALU
         // multi-query scan streams the rows faster than the matrix-core kernel's LDS-DMA path
         QAMD_TRY(u8_score_batch_scans(h, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), (uint32_t)b->n_queries,
@@ -1857,10 +1859,10 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     hipStream_t s = as_stream(stream);
     const uint64_t Q = b->n_queries, n = h->count;
     const bool l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
-    if (n > (2u << 20) && (l1 || (Q <= u8_multi_width(h) && Q >= 2)))
-        // L1 has no matrix form; and a handful of queries (one pass of the vector-ALU multi-query scan)
-        // stream the rows at the single-query scan's rate, which the matrix-core kernel's LDS-DMA
-        // path does not reach.  Per-query sample + pivot, ONE filtering pass per group of queries, one
+    if (n > (2u << 20) && (l1 || (Q <= u8_multi_width(h) && Q >= 2 && (Q == 2 || !rs_selected(h, b, true)))))
+        // L1 has no matrix form; and two queries (one pass of the vector-ALU multi-query scan) stream the
+        // rows at the single-query scan's rate with less overhead around it than the matrix-core pass (from
+        // three queries on the row-streaming kernel wins: 1.26 against 1.31-1.39 ms per 10M x 768).  Per-query sample + pivot, ONE filtering pass per group of queries, one
         // status read-back per 32 queries.
         return u8_topk_batch_scans(h, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), (uint32_t)Q, k, largest,
                                    out_ids, out_scores, out_mem, s);
