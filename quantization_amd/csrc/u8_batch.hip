@@ -1022,6 +1022,9 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
                                                         float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
     constexpr int MI = 2, KB = 128, QS_ROWS = 32 * MJ;  // resident rows per workgroup
+    // MODE 0: scores out; 1 / 2: filter for the largest / smallest; 3: the best score of every (query, row block)
+    // out[q * out_pitch + block] (direction filt.largest) - the pivot sample of a large batch without its Q x S score matrix
+    constexpr bool FILTER = MODE == 1 || MODE == 2;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -1035,10 +1038,10 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
     uint32_t *wcount_s = reinterpret_cast<uint32_t *>(br_s + QS_ROWS) + wave;
     int *bq_s = reinterpret_cast<int *>(br_s + QS_ROWS) + 16;                    // [64 * live_chunks] integer query bounds
     constexpr bool LARGEST = MODE == 1;
-    if (MODE != 0 && lane == 0) *wcount_s = 0;
-    if (MODE != 0)
+    if (FILTER && lane == 0) *wcount_s = 0;
+    if (FILTER)
         for (uint32_t i = t; i < 64 * live_chunks; i += 512) bq_s[i] = bq_all[i];
-    const float never = LARGEST ? -__builtin_huge_valf() : __builtin_huge_valf();
+    const float never = (MODE == 3 ? filt.largest != 0 : LARGEST) ? -__builtin_huge_valf() : __builtin_huge_valf();
     (void)n_chunks;
 
     // streamed operand: chunk c, K-block kb -> fragments 2c and 2c + 1, 4 KiB each, contiguous per fragment
@@ -1133,7 +1136,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
             const bool ok = row0 + t < n_rows;
             const float vo = vo_pf;  // requested with the rows
             voff_s[t] = ok ? vo : never;
-            if (MODE != 0) br_s[t] = ok ? pp_bound<LOW>(-vo, fabsf(vo), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+            if (FILTER) br_s[t] = ok ? pp_bound<LOW>(-vo, fabsf(vo), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
         }
         __syncthreads();
         lap(1);  // own pieces landing + LDS writes + second barrier
@@ -1145,8 +1148,8 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
             v16i acc[MI][MJ];
             int br[MJ];
 #pragma unroll
-            for (int jj = 0; jj < MJ; jj++) br[jj] = MODE != 0 ? br_s[jj * 32 + r] : 0;
-            if (MODE == 0) {
+            for (int jj = 0; jj < MJ; jj++) br[jj] = FILTER ? br_s[jj * 32 + r] : 0;
+            if (!FILTER) {
 #pragma unroll
                 for (int i = 0; i < MI; i++)
 #pragma unroll
@@ -1213,7 +1216,37 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
             // ---- epilogue: 64 queries x 128 rows of this wave
             uint32_t c_e = c, wave_e = (uint32_t)wave, lane_e = (uint32_t)lane;
             asm volatile("" : "+s"(c_e), "+s"(wave_e), "+v"(lane_e));
-            uint4 *wave_list = MODE != 0 ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
+            if (MODE == 3) {  // best score per query over the block's rows (rows on the lanes of each half wave)
+                const bool lg = filt.largest != 0;
+                const uint32_t r3 = lane_e & 31u, h3 = lane_e >> 5;
+                float vo3[MJ];
+#pragma unroll
+                for (int jj = 0; jj < MJ; jj++) vo3[jj] = voff_s[jj * 32 + r3];  // `never` for rows past the end
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const uint32_t q = 64 * c_e + i * 32 + 8 * gq + 4 * h3;
+                        const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+                        const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            float best = never;
+#pragma unroll
+                            for (int jj = 0; jj < MJ; jj++) {
+                                const float sc = (multiplier * (float)acc[i][jj][4 * gq + e] + qo[e]) + vo3[jj];
+                                best = lg ? fmaxf(best, sc) : fminf(best, sc);
+                            }
+#pragma unroll
+                            for (int d = 16; d >= 1; d >>= 1) {
+                                const float o = __shfl_xor(best, d);
+                                best = lg ? fmaxf(best, o) : fminf(best, o);
+                            }
+                            if (r3 == 0 && q + e < n_queries) out[(uint64_t)(q + e) * out_pitch + blk] = best;
+                        }
+                    }
+            } else {
+            uint4 *wave_list = FILTER ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
             const uint32_t r_e = lane_e & 31u, h_e = lane_e >> 5;
 #pragma unroll
             for (int jj = 0; jj < MJ; jj++) {
@@ -1223,8 +1256,8 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
                 const int brj = br[jj];
 #pragma unroll
                 for (int i = 0; i < MI; i++) {
-                    if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
-                    if (MODE != 0) {
+                    if (!FILTER) __builtin_amdgcn_sched_barrier(0);
+                    if (FILTER) {
                         // "some accumulator of the tile may pass" = the smallest is negative (LOW) / the
                         // largest is not: v_min3 / v_max3 fold two values per instruction
                         int ext = acc[i][jj][0];
@@ -1238,7 +1271,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++) {
                         const uint32_t q = 64 * c_e + i * 32 + 8 * gq + 4 * h_e;  // first of four consecutive queries
-                        if (MODE == 0) {
+                        if (!FILTER) {
                             const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
                             const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
 #pragma unroll
@@ -1274,6 +1307,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
                     }
                 }
             }
+            }  // MODE != 3
             if (odd) {
 #pragma unroll
                 for (int i = 0; i < MI; i++)
@@ -1291,7 +1325,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
         for (int i = 0; i < 6; i++) o[i] = tm_acc[i];
         o[15] = 1;
     }
-    if (MODE != 0 && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+    if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
 // Gather `n` sampled rows (codes + offsets) into a dense sub-store for the pivot pass, followed by
@@ -1628,16 +1662,16 @@ qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
     for (uint64_t q_base = 0; q_base < b->n_queries; q_base += kQsSlice) {
         const uint32_t nq = (uint32_t)std::min<uint64_t>(kQsSlice, b->n_queries - q_base);
         BatchFilter f = filt;
-        if (MODE != 0) {
+        if (MODE == 1 || MODE == 2) {
             f.pivot_scores += q_base;
             f.query_base = (uint32_t)q_base;
             f.wave_base = (uint32_t)(q_base / kQsSlice) * pp_waves_per_launch();
         }
         hipLaunchKernelGGL((u8_gemm_qs_kernel<MODE, LOW, MJ>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
                            b->frag.as<uint4>() + (q_base / 32) * nkb * 256, b->offsets.as<float>() + q_base,
-                           MODE != 0 ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,
+                           (MODE == 1 || MODE == 2) ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,
                            (uint32_t)round_up((uint64_t)nq, 64), (uint32_t)h->meta.actual_dim,
-                           MODE == 0 ? out + q_base * out_pitch : out, out_pitch, f);
+                           (MODE == 0 || MODE == 3) ? out + q_base * out_pitch : out, out_pitch, f);
         QAMD_HIP(hipGetLastError());
     }
     return QAMD_OK;
@@ -1651,7 +1685,10 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
     if (MODE == 0)
         return wide ? launch_gemm_qs_cfg<0, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
                     : launch_gemm_qs_cfg<0, false, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
-    constexpr int M = MODE == 0 ? 1 : MODE;
+    if (MODE == 3)
+        return wide ? launch_gemm_qs_cfg<3, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
+                    : launch_gemm_qs_cfg<3, false, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    constexpr int M = (MODE == 1 || MODE == 2) ? MODE : 1;
     const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
     // per-query integer bounds of the pre-filter, behind the pivots in stream order
     int *bq = filt.query_bounds;
@@ -1930,7 +1967,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         const bool cached = S <= rows_all && sample_store(h, rows_all, s, &s_codes, &s_offs) == QAMD_OK;
         const size_t o_codes = reserve(cached ? 16 : (uint64_t)(S + 512) * ad);  // + one (largest) tile of zero rows
         const size_t o_offs = reserve(cached ? 16 : (uint64_t)(S + 512) * 4);
-        const size_t o_scores = reserve(Q * (uint64_t)S * 4);
+        const size_t o_scores = reserve(qs ? Q * ((uint64_t)S / 96 + 2) * 4 : Q * (uint64_t)S * 4);  // sample scores, or block bests
         const size_t o_cand = reserve(Q * (uint64_t)kBatchCap * 8);
         const size_t o_status = reserve((Q + 1) * 4);  // per-query status, then the wave-list overflow flag
         const size_t o_bounds = reserve(b->q_pad * 4);
@@ -1961,9 +1998,23 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
             s_codes = g_codes;
             s_offs = g_offs;
         }
-        QAMD_TRY(launch_gemm<0>(h, b, s_codes, s_offs, S, s_scores, S, BatchFilter{}, s));
-        hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores, S, (uint64_t)S, r,
-                           largest, (uint32_t)Q, pivots, counters);
+        if (qs) {
+            // the query-streaming kernel hands back the best sample score of every (query, 128- or 96-row
+            // block) instead of the Q x S score matrix (0.64 GB written and read back at 1024 queries and
+            // 10M rows); the pivot is the r-th best of those: the r best sample rows of a query share a
+            // block with probability ~ r^2 / (2 blocks), and a pivot that is a little off only moves the
+            // candidate count (the filter pass, not the pivot, decides what is in the result)
+            const uint32_t rows_per_block = b->frag_nkb <= 9 ? 128 : 96, s_blocks = (S + rows_per_block - 1) / rows_per_block;
+            BatchFilter fs{};
+            fs.largest = largest;
+            QAMD_TRY(launch_gemm_qs<3>(h, b, s_codes, s_offs, S, s_scores, s_blocks, fs, s));
+            hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores, s_blocks,
+                               (uint64_t)s_blocks, r, largest, (uint32_t)Q, pivots, counters);
+        } else {
+            QAMD_TRY(launch_gemm<0>(h, b, s_codes, s_offs, S, s_scores, S, BatchFilter{}, s));
+            hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)b->q_pad), dim3(1024), 0, s, s_scores, S, (uint64_t)S, r,
+                               largest, (uint32_t)Q, pivots, counters);
+        }
         BatchFilter f{};
         f.pivot_scores = pivots;
         f.counters = counters;
