@@ -14,16 +14,20 @@
 // K index is only a summation index, so lane (r, h) simply takes bytes [32s + 16h, +16) of
 // query/row r in k-step s: fragments are plain 16-byte pieces, no transposition anywhere.
 //
-// Two kernels (launch_gemm picks):
-//   * u8_gemm_pp_kernel<MODE, LOW, MI, MJ> -- the main one: persistent workgroups, LDS-DMA ring,
-//     two wave groups half a phase apart, integer pre-filter folded into the accumulators,
-//     wave-private candidate lists.  Described above its definition.
+// Four kernels share the arithmetic, the integer pre-filter and the epilogue; launch_gemm picks by what
+// is re-read and from where (DESIGN.md 3.3b has the table and the measurements):
+//   * u8_gemm_rs_kernel<MODE, LOW, MI, NT> -- row-streaming: up to 128 queries (and several 128-query
+//     tiles up to ~700): the query tile resident in LDS, every wave streams its own rows HBM ->
+//     registers (coalesced, nt) -> wave-private LDS transpose -> MFMA.  HBM-bound, no barriers.
+//   * u8_gemm_qs_kernel<MODE, LOW, MJ> -- query-streaming: many queries on rows of up to 1536 B: 128
+//     (96) store rows resident in LDS, the batch streamed from L2 in MFMA fragment order straight
+//     into operand registers.  Rows leave HBM once; the reuse needs no co-scheduling of workgroups.
+//   * u8_gemm_pp_kernel<MODE, LOW, MI, MJ> -- ping-pong (round 1): both operands through an LDS-DMA
+//     ring, two wave groups half a phase apart; now for what the two above do not take.
 //   * u8_gemm_kernel<MODE, TQ, TR, WQ, WR, BK> -- the first version (128-byte K slabs through
 //     registers -> ds_write -> LDS at a 144-byte pitch, one barrier per slab, float-compare filter,
-//     per-query global atomics); now only for rows of fewer than three 64-byte K-tiles, a
-//     zero / non-finite multiplier, and the developer switch QAMD_GEMM_CFG.
-// In both, the workgroups that share a row tile run on one XCD, so a row tile comes from HBM
-// once and from that XCD's L2 for the other query tiles (measured: 1.03x the store bytes).
+//     per-query global atomics); now only for short rows no tile applies to, a zero / non-finite
+//     multiplier, and the developer switch QAMD_GEMM_CFG (r / q / p force one of the three above).
 //
 // Top-k per query is fused as in topk.hip: a pivot per query from S sampled rows (scored by the
 // same kernel on a gathered sub-store; S grows with the store, see qamd_u8_topk_batch), a filter
