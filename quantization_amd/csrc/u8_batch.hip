@@ -1915,9 +1915,10 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
     // measured +7..10 % on the whole call).  So: about max(512, 3k) rows expected to pass at pivot
     // rank >= 8 (P(fewer than k) < 1e-7, P(more than 8192) ~ 0); S = 8 n / that, capped at 524288
     // sampled rows (beyond 33M rows the expected count grows instead of r shrinking).
-    // Few queries: a smaller sample (cheaper pivot pass) and more candidates per query instead; the
-    // extra exact epilogues and list appends are then a few thousand per query in a whole-store pass.
-    const double want = std::max<double>(Q <= 32 ? 2048.0 : Q <= 128 ? 1024.0 : 512.0, 3.0 * k);
+    // Few queries: a smaller sample (cheaper pivot pass) and more candidates per query instead (measured at
+    // 10M x 768, 5-128 queries: 1024 expected beats 512 by 0.01-0.02 ms and 2048 by 0.03-0.08 ms - the
+    // per-query scatter and sort of the candidates grow faster than the sample pass shrinks).
+    const double want = std::max<double>(Q <= 128 ? 1024.0 : 512.0, 3.0 * k);
     // small stores (Qdrant segments: 1e5..1e6 rows) take the same route with a smaller sample: the
     // per-query fallback costs a launch chain per query, the matrix-core pass one for the whole batch
     const double s_min = n < (1u << 20) ? 2048.0 : (double)kTopkSample;
