@@ -1375,14 +1375,58 @@ __global__ __launch_bounds__(256) void wave_scatter_kernel(const uint4 *__restri
     }
 }
 
+// The same with the global atomics aggregated: a workgroup takes a range of wave lists, counts its entries per
+// query in LDS, reserves one range per (workgroup, query) with ONE global atomic and places the entries by
+// LDS ranks.  Same-address global atomics serialise at ~25 ns each: one per candidate was 15-50 us of every
+// call (1024-2048 per query); this way a query's counter sees one add per workgroup.  n_queries <= 4096.
+__global__ __launch_bounds__(1024) void wave_scatter_grouped_kernel(const uint4 *__restrict__ wave_cand,
+                                                                   const uint32_t *__restrict__ wave_counts,
+                                                                   uint32_t wave_cap, uint32_t n_lists, uint32_t n_queries,
+                                                                   uint32_t *__restrict__ counters,
+                                                                   unsigned long long *__restrict__ candidates,
+                                                                   uint32_t *__restrict__ overflow) {
+    extern __shared__ uint32_t scatter_lds[];
+    uint32_t *hist = scatter_lds, *base = scatter_lds + n_queries;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (uint32_t i = t; i < n_queries; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const uint32_t l0 = (uint32_t)((uint64_t)blockIdx.x * n_lists / gridDim.x);
+    const uint32_t l1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * n_lists / gridDim.x);
+    for (uint32_t l = l0 + wave; l < l1; l += 16) {  // one wave per list
+        uint32_t count = wave_counts[l];
+        if (count > wave_cap) {
+            if (lane == 0) *overflow = 1;
+            count = wave_cap;
+        }
+        const uint4 *list = wave_cand + (uint64_t)l * wave_cap;
+        for (uint32_t i = lane; i < count; i += 64) atomicAdd(&hist[list[i].z], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n_queries; i += 1024) {
+        const uint32_t cnt = hist[i];
+        base[i] = cnt ? atomicAdd(counters + (uint64_t)i * kCounterStride, cnt) : 0u;
+        hist[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t l = l0 + wave; l < l1; l += 16) {
+        const uint32_t count = min(wave_counts[l], wave_cap);
+        const uint4 *list = wave_cand + (uint64_t)l * wave_cap;
+        for (uint32_t i = lane; i < count; i += 64) {
+            const uint4 c = list[i];
+            const uint32_t pos = base[c.z] + atomicAdd(&hist[c.z], 1u);
+            if (pos < kBatchCap) candidates[(uint64_t)c.z * kBatchCap + pos] = ((unsigned long long)c.x << 32) | c.y;
+        }
+    }
+}
+
 // Per-query pivot (grid = queries): r-th best of 1024 per-thread bests of the query's sample
 // scores (see pivot_kernel in topk.hip), and counter reset.
 __global__ __launch_bounds__(1024) void batch_pivot_kernel(const float *__restrict__ sample, uint32_t S,
                                                           uint64_t pitch, uint32_t r, int largest,
                                                           uint32_t n_queries, float *__restrict__ pivot_scores,
                                                           uint32_t *__restrict__ counters) {
-    __shared__ uint32_t best[1024];
-    const int t = threadIdx.x;
+    __shared__ unsigned long long lists[kSmallTopkWaves][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (blockIdx.x >= n_queries) {  // padding query of the last tile: nothing may pass
         if (t == 0) pivot_scores[blockIdx.x] = largest ? __builtin_huge_valf() : -__builtin_huge_valf();
         return;
@@ -1393,25 +1437,13 @@ __global__ __launch_bounds__(1024) void batch_pivot_kernel(const float *__restri
         const uint32_t key = topk_ordered_bits(mine_row[i], largest != 0);
         mine = key < mine ? key : mine;
     }
-    best[t] = mine;
-    __syncthreads();
-    for (int size = 2; size <= 1024; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int partner = t ^ stride;
-            if (partner > t) {
-                const bool up = (t & size) == 0;
-                const uint32_t a = best[t], bb = best[partner];
-                if ((a > bb) == up) {
-                    best[t] = bb;
-                    best[partner] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (t == 0) {
-        r = r < 1 ? 1 : (r > 1024 ? 1024 : r);
-        pivot_scores[blockIdx.x] = topk_score_of_key(best[r - 1], largest != 0);
+    // the r-th best (r <= 64) of the 1024 per-thread bests: a sort per wave, the 16 waves folded pairwise
+    // (21 + 4 x 6 register stages instead of the 55 barrier stages of a 1024-key bitonic sort)
+    unsigned long long best = wave_sort64((unsigned long long)mine << 32, lane);
+    best = small_topk_fold_waves(best, lists, wave, lane);
+    r = r < 1 ? 1 : (r > 64 ? 64 : r);
+    if (wave == 0 && lane == (int)r - 1) {
+        pivot_scores[blockIdx.x] = topk_score_of_key((uint32_t)(best >> 32), largest != 0);
         counters[(uint64_t)blockIdx.x * kCounterStride] = 0;
     }
 }
@@ -1462,6 +1494,46 @@ __global__ __launch_bounds__(1024) void batch_emit_kernel(const unsigned long lo
         }
     }
     if (t == 0) status[q] = 0;
+}
+
+// The same for k <= 64 without the full sort: every wave keeps the 64 best of its share of the candidates
+// (wave_sort64 of 64 at a time + a 6-stage merge, all in registers), the 16 waves fold pairwise through
+// LDS: ~30 DPP/LDS stages instead of the 66-91 barrier stages of the bitonic sort above (15-40 us per
+// call whatever the batch size, since the queries' workgroups run side by side).
+__global__ __launch_bounds__(1024) void batch_emit_wave_kernel(const unsigned long long *__restrict__ cand,
+                                                              const uint32_t *__restrict__ counters, uint64_t n,
+                                                              uint32_t k, int largest, uint32_t *__restrict__ out_ids,
+                                                              float *__restrict__ out_scores,
+                                                              uint32_t *__restrict__ status) {
+    __shared__ unsigned long long lists[kSmallTopkWaves][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint32_t pushed = counters[(uint64_t)q * kCounterStride];
+    const uint32_t k_eff = n < k ? (uint32_t)n : k;
+    if (pushed > kBatchCap || pushed < k_eff) {
+        if (t == 0) status[q] = 1;
+        return;
+    }
+    const unsigned long long *mine = cand + (uint64_t)q * kBatchCap;
+    unsigned long long best = ~0ull;
+    for (uint32_t base = (uint32_t)wave * 64; base < pushed; base += 1024) {
+        unsigned long long v = base + lane < pushed ? mine[base + lane] : ~0ull;
+        v = wave_sort64(v, lane);
+        best = wave_merge64_rev(best, shfl_u64(v, 63 - lane), lane);
+    }
+    best = small_topk_fold_waves(best, lists, wave, lane);
+    if (wave == 0) {
+        for (uint32_t i = lane; i < k; i += 64) {
+            if (i < k_eff) {
+                out_ids[(uint64_t)q * k + i] = (uint32_t)(best & 0xFFFFFFFFull);
+                out_scores[(uint64_t)q * k + i] = topk_score_of_key((uint32_t)(best >> 32), largest != 0);
+            } else {
+                out_ids[(uint64_t)q * k + i] = 0xFFFFFFFFu;
+                out_scores[(uint64_t)q * k + i] = largest ? -__builtin_huge_valf() : __builtin_huge_valf();
+            }
+        }
+        if (lane == 0) status[q] = 0;
+    }
 }
 
 }  // namespace
@@ -2035,11 +2107,18 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
             QAMD_TRY(launch_gemm<1>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
         else
             QAMD_TRY(launch_gemm<2>(h, b, h->codes.as<uint8_t>(), h->offsets.as<float>(), n, nullptr, 0, f, s));
-        if (pp)
+        if (pp && Q <= 4096)
+            hipLaunchKernelGGL(wave_scatter_grouped_kernel, dim3(std::min<uint32_t>(n_lists, 128)), dim3(1024), (size_t)Q * 8, s,
+                               wave_cand, wave_counts, f.wave_cap, n_lists, (uint32_t)Q, counters, cand, overflow_dev);
+        else if (pp)
             hipLaunchKernelGGL(wave_scatter_kernel, dim3(n_lists), dim3(256), 0, s, wave_cand, wave_counts, f.wave_cap,
                                counters, cand, overflow_dev);
-        hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand, counters, n, k, largest, ids_dev,
-                           sc_dev, status_dev);
+        if (k <= kSmallTopkMaxK)
+            hipLaunchKernelGGL(batch_emit_wave_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand, counters, n, k, largest,
+                               ids_dev, sc_dev, status_dev);
+        else
+            hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand, counters, n, k, largest, ids_dev,
+                               sc_dev, status_dev);
         QAMD_HIP(hipGetLastError());
         uint32_t overflow = 0;
         if (hs.host) {
