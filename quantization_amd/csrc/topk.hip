@@ -233,25 +233,37 @@ __global__ __launch_bounds__(1024) void pivot_kernel(const float *__restrict__ s
         const uint32_t key = topk_ordered_bits(sample[i], largest != 0);
         mine = key < mine ? key : mine;
     }
-    best[t] = mine;
-    __syncthreads();
-    for (int size = 2; size <= 1024; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int partner = t ^ stride;
-            if (partner > t) {
-                const bool up = (t & size) == 0;
-                const uint32_t a = best[t], b = best[partner];
-                if ((a > b) == up) {
-                    best[t] = b;
-                    best[partner] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
     r = r < 1 ? 1 : (r > 1024 ? 1024 : r);
+    uint32_t pivot_key;
+    if (r <= 64) {
+        // the usual case (fused_policy keeps r <= 64): a sort per wave and a pairwise fold of the 16 waves'
+        // 64 best, in registers (21 + 4 x 6 DPP stages) instead of 55 barrier stages
+        __shared__ unsigned long long lists[kSmallTopkWaves][64];
+        const int lane = t & 63, wave = t >> 6;
+        unsigned long long b64 = wave_sort64((unsigned long long)mine << 32, lane);
+        b64 = small_topk_fold_waves(b64, lists, wave, lane);
+        pivot_key = (uint32_t)(shfl_u64(b64, (int)r - 1) >> 32);  // meaningful in wave 0 only
+    } else {
+        best[t] = mine;
+        __syncthreads();
+        for (int size = 2; size <= 1024; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const int partner = t ^ stride;
+                if (partner > t) {
+                    const bool up = (t & size) == 0;
+                    const uint32_t a = best[t], b = best[partner];
+                    if ((a > b) == up) {
+                        best[t] = b;
+                        best[partner] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        pivot_key = best[r - 1];
+    }
     if (t == 0) {
-        st->pivot_key = best[r - 1];
+        st->pivot_key = pivot_key;
         st->status = 0;
         st->total = 0;
     }
@@ -287,6 +299,42 @@ __global__ __launch_bounds__(1024) void fused_emit_kernel(const unsigned long lo
         if (t == 0) {
             st->status = 1;
             if (status_host) *status_host = 1;
+        }
+        return;
+    }
+    if (k <= kSmallTopkMaxK) {
+        // k <= 64: every wave keeps the 64 best of its share of the candidates (wave_sort64 of 64 at a time +
+        // a 6-stage merge, in registers), the 16 waves fold pairwise; the lists alias the sort buffer
+        unsigned long long(*lists)[64] = reinterpret_cast<unsigned long long(*)[64]>(s);
+        const int lane = t & 63, wave = t >> 6;
+        unsigned long long best = ~0ull;
+        for (uint32_t base = (uint32_t)wave * 64; base < pushed; base += 1024) {
+            unsigned long long v = ~0ull;
+            const uint32_t f = base + lane;
+            if (f < pushed) {  // flat index -> (shard, slot): the last shard whose offset is <= f
+                uint32_t lo = 0, hi = kTopkShards;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (offs[mid] <= f) lo = mid;
+                    else hi = mid;
+                }
+                v = cand[lo * kTopkShardCap + (f - offs[lo])];
+            }
+            v = wave_sort64(v, lane);
+            best = wave_merge64_rev(best, shfl_u64(v, 63 - lane), lane);
+        }
+        best = small_topk_fold_waves(best, lists, wave, lane);
+        if (wave == 0) {
+            for (uint32_t i = lane; i < k; i += 64) {
+                if (i < k_eff) {
+                    out_ids[i] = (uint32_t)(best & 0xFFFFFFFFull);
+                    out_scores[i] = topk_score_of_key((uint32_t)(best >> 32), largest != 0);
+                } else {
+                    out_ids[i] = 0xFFFFFFFFu;
+                    out_scores[i] = largest ? -__builtin_huge_valf() : __builtin_huge_valf();
+                }
+            }
+            if (lane == 0 && status_host) *status_host = 0;
         }
         return;
     }
