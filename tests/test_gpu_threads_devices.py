@@ -97,3 +97,39 @@ def test_calls_leave_the_current_device_and_check_buffer_devices():
         for _ in range(10):  # one thread alternating between two DEVICES: per-device workspaces
             enc.score_all(q)
             far.score_all(far.encode_query(data[0]))
+
+
+def test_batched_topk_from_several_threads_on_one_handle():
+    """Search threads share one store (the reference's scorer is `&self`): concurrent topk_batch calls of
+    different sizes - row-streaming, several tiles, query-streaming - on their own streams, the first of
+    them racing to gather the handle's pivot sample; every list equals the serial result."""
+    rng = np.random.default_rng(5)
+    n, dim = 120_000, 256
+    enc = qa.EncodedVectorsU8.encode(rng.random((n, dim), dtype=np.float32), qa.VectorParameters(dim, n, D.Dot, False))
+    sizes = [7, 100, 300, 1000]
+    queries = [rng.random((q, dim), dtype=np.float32) for q in sizes]
+    results = [None] * len(sizes)
+    errors = []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    results[i] = enc.topk_batch(enc.encode_query_batch(queries[i]), 20)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+        finally:
+            qa.thread_release()
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(sizes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, qs in enumerate(queries):
+        ids, sc = enc.topk_batch(enc.encode_query_batch(qs), 20)
+        assert np.array_equal(results[i][0], ids), sizes[i]
+        assert_bits_equal(results[i][1], sc, f"{sizes[i]} queries, concurrent vs serial")
+        wi, ws = enc.topk(enc.encode_query(qs[0]), 20)
+        assert np.array_equal(ids[0], wi) and np.array_equal(sc[0].view(np.uint32), ws.view(np.uint32))
