@@ -405,3 +405,22 @@ def test_query_streaming_kernel_reused_batch_object():
         for qi in (0, 400, nq - 1):
             wi, ws = enc.topk(enc.encode_query(queries[qi]), 10)
             assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (rep, qi)
+
+
+def test_topk_batch_more_than_4096_queries():
+    """Above 4096 queries the per-candidate scatter kernel serves (the grouped one keeps two words per query
+    in LDS), the query-streaming kernel runs three slices of 2048 queries and k = 100 takes the sorting emit."""
+    rng = np.random.default_rng(17)
+    n, dim, nq = 60_000, 64, 4200
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    batch = enc.encode_query_batch(queries)
+    for k in (30, 100):
+        ids, sc = enc.topk_batch(batch, k)
+        qobj = None
+        for qi in (0, 2047, 2048, 4095, 4096, nq - 1):
+            qobj = enc.encode_query(queries[qi], reuse=qobj)
+            wi, ws = enc.topk(qobj, k)
+            assert np.array_equal(ids[qi], wi), (k, qi)
+            assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (k, qi)
