@@ -374,6 +374,123 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_mfma_peak
     return QAMD_OK;
 }
 
+// ---------------------------------------------------------------- binary rows on the matrix cores (probe)
+// Feasibility probe for a many-queries-at-once binary path: a wave streams 64 rows of 1024 bits (128 B), expands
+// bits to 0/1 bytes in registers (nibble * 0x00204081 & 0x01010101) and feeds int8 MFMAs against a query
+// tile of 0/1 bytes resident in LDS; acc = popcount(q AND v).  No epilogue: this measures the K loop only.
+namespace {
+typedef int bv4 __attribute__((ext_vector_type(4)));
+typedef int bv16 __attribute__((ext_vector_type(16)));
+template <int MI>
+__global__ __launch_bounds__(512) void tune_bits_gemm(const uint8_t *__restrict__ rows, uint32_t n_rows, int *__restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t bits_lds[];
+    constexpr int PA = 1024 + 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    for (uint32_t i = t; i < (uint32_t)(32 * MI) * PA / 4; i += 512)
+        reinterpret_cast<uint32_t *>(bits_lds)[i] = (i * 2654435761u >> 7) & 0x01010101u;
+    __syncthreads();
+    const uint32_t n_chunks = n_rows / 64, stride = gridDim.x * 8;
+    const uint8_t *a_base = bits_lds + r * PA + 64 * h;
+    bv16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jj][e] = 0;
+    uint2 cur[2][8], nxt[2][8];
+    auto load = [&](uint2(&w)[2][8], uint32_t chunk) {
+        const uint32_t c = chunk < n_chunks ? chunk : n_chunks - 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const uint8_t *p = rows + ((uint64_t)c * 64 + jj * 32 + r) * 128 + 8 * h;
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) w[jj][kb] = *reinterpret_cast<const uint2 *>(p + 16 * kb);
+        }
+    };
+    auto expand = [&](uint32_t bits16) {  // 16 bits -> 16 bytes of 0/1
+        bv4 v;
+        v.x = (int)(((bits16 & 0xFu) * 0x00204081u) & 0x01010101u);
+        v.y = (int)((((bits16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+        v.z = (int)((((bits16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+        v.w = (int)((((bits16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+        return v;
+    };
+    uint32_t chunk = blockIdx.x * 8 + wave;
+    load(cur, chunk);
+    for (; chunk < n_chunks; chunk += stride) {
+        load(nxt, chunk + stride);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                bv4 bf[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const uint32_t word = (x < 2) ? cur[jj][kb].x : cur[jj][kb].y;
+                    bf[jj] = expand((word >> (16 * (x & 1))) & 0xFFFFu);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; i++) {
+                    const bv4 a = *reinterpret_cast<const bv4 *>(a_base + i * 32 * PA + kb * 128 + 16 * x);
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[jj], acc[i][jj], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) cur[jj][kb] = nxt[jj][kb];
+    }
+    int tsum = 0;
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) tsum ^= acc[i][jj][e];
+    if (tsum == 0x7fffffff) sink[0] = tsum;
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_bits_gemm_probe(const void *rows, uint32_t n_rows, int *sink,
+                                                                                     char *report, size_t cap) {
+    QAMD_ON_DEVICE(current_device());
+    const int cu = device_info().cu_count;
+    hipEvent_t e0, e1;
+    QAMD_HIP(hipEventCreate(&e0));
+    QAMD_HIP(hipEventCreate(&e1));
+    std::string rep;
+    auto run = [&](const char *name, int mi, auto kernel) -> qamd_status {
+        const size_t lds = (size_t)32 * mi * (1024 + 16);
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        std::vector<float> ms;
+        for (int rr = 0; rr < 6; rr++) {
+            QAMD_HIP(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(kernel, dim3(cu), dim3(512), lds, nullptr, static_cast<const uint8_t *>(rows), n_rows, sink);
+            QAMD_HIP(hipEventRecord(e1, nullptr));
+            QAMD_HIP(hipEventSynchronize(e1));
+            float t = 0;
+            QAMD_HIP(hipEventElapsedTime(&t, e0, e1));
+            ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        char line[256];
+        snprintf(line, sizeof line, "%-28s median %.3f ms  %.0f G (query,row) pairs/s  %.0f int8 TOP/s\n", name, ms[3],
+                 32.0 * mi * n_rows / (ms[3] * 1e-3) / 1e9, 32.0 * mi * n_rows * 2048.0 / (ms[3] * 1e-3) / 1e12);
+        rep += line;
+        return QAMD_OK;
+    };
+    QAMD_TRY(run("32 queries per tile", 1, tune_bits_gemm<1>));
+    QAMD_TRY(run("64 queries per tile", 2, tune_bits_gemm<2>));
+    QAMD_TRY(run("128 queries per tile", 4, tune_bits_gemm<4>));
+    snprintf(report, cap, "%s", rep.c_str());
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return QAMD_OK;
+}
+
 // ---------------------------------------------------------------- binary scan sweep (dim 1024)
 namespace {
 template <int UNROLL, int BLOCK, int STORE_MODE>
