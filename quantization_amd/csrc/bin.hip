@@ -17,6 +17,9 @@
 #include <memory>
 #include <vector>
 
+#include <mutex>
+
+#include "batch_common.hpp"
 #include "common.hpp"
 #include "multi_reduce.hpp"
 #include "topk.hpp"
@@ -387,6 +390,11 @@ struct qamd_bin {
     uint64_t nb = 0;  // reference row bytes
     uint64_t ds = 0;  // device row stride (bytes)
     DevBuf rows;      // [padded_rows][ds]
+    // the batched top-k's pivot sample (rows hash(j) of the store, j < sample_count, then 512 zero rows);
+    // gathered once on first use (count / 64 rows at most), immutable after
+    mutable std::mutex sample_mu;
+    mutable DevBuf sample_rows;
+    mutable uint32_t sample_count = 0;
 };
 
 struct qamd_bin_query {
@@ -879,6 +887,354 @@ template <int NQ> bool multi_step(const qamd_bin *h, const uint8_t *qbits, uint6
 
 }  // namespace
 
+// ============================================================================= many queries on the matrix cores
+// A binary store is a u8 store in disguise: bits as 0/1 bytes, a = popcount(q AND v) as the int8 contraction,
+// xor = pop(q) + pop(v) - 2a, and the reference's metric (calculate_metric, :237-252)
+//   zeros - xor = dim - 2 xor = (4a + (dim - 2 pop_q)) + (-2 pop_v)        (Dot, or L1/L2 inverted)
+//   xor - zeros = 2 xor - dim = (-4a + (2 pop_q - dim)) + (2 pop_v)        (the other two cases)
+// is the u8 epilogue (multiplier * s + q_offset) + v_offset with integer operands below 2^23: every f32 in it is
+// exact, so the scores are the reference's bit for bit.  bin_gemm_rs_kernel is u8_gemm_rs_kernel's structure
+// (csrc/u8_batch.hip: query tile resident in LDS, every wave streams its own 64 rows, no barrier after the
+// set-up) with the rows kept as BITS up to the registers: lane (r, h) loads the 8 bytes [16 kb + 8h, +8) of row
+// r per 128-bit K-block and expands 16 bits to 16 operand bytes (nibble * 0x00204081 & 0x01010101) right before
+// the MFMAs that use them; the row's popcount falls out of the same loads.  HBM sees 1/8 of the bytes the
+// contraction works on, so the kernel is matrix-pipe / VALU-bound from the first query tile on.
+// The pre-filter starts the accumulators at -B_q and compares against the row's bound after the K loop (the
+// row term is only known once the row has been read); the rest - pivots from a sample, wave-private candidate
+// lists, scatter, emit - is batch_common.hpp's, as for u8.
+namespace {
+
+template <int MODE, bool LOW, int MI>  // MODE 0: scores out; 1 / 2: filter for the largest / smallest
+__global__ __launch_bounds__(512) void bin_gemm_rs_kernel(const uint8_t *__restrict__ rows, uint32_t ds,
+                                                         const uint8_t *__restrict__ qbits, uint32_t q_stride, float dim_f,
+                                                         int zx, uint32_t n_rows, uint32_t n_queries, uint32_t q0,
+                                                         float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr int MJ = 2, TQ = 32 * MI, CHUNK = 64;
+    constexpr bool FILTER = MODE != 0, LARGEST = MODE == 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t nkb = __builtin_amdgcn_readfirstlane(ds / 16);  // 128-bit K-blocks per row
+    const uint32_t PA = nkb * 128 + 16;                            // LDS pitch of a query (one byte per bit)
+    const float multiplier = zx ? 4.0f : -4.0f;
+    float *q_off_s = reinterpret_cast<float *>(lds_raw + (size_t)TQ * PA);  // [64]
+    float *pivot_s = q_off_s + 64;                                          // [64]
+    int *bq_s = reinterpret_cast<int *>(pivot_s + 64);                      // [64]
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(bq_s + 64) + wave;
+    if (FILTER && lane == 0) *wcount_s = 0;
+    auto expand = [](uint32_t bits16) {  // 16 bits -> 16 bytes of 0 / 1
+        v4i v;
+        v.x = (int)(((bits16 & 0xFu) * 0x00204081u) & 0x01010101u);
+        v.y = (int)((((bits16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+        v.z = (int)((((bits16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+        v.w = (int)((((bits16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+        return v;
+    };
+    // the query tile as bytes (queries past the batch: zero), its offsets and integer bounds
+    for (uint32_t idx = t; idx < (uint32_t)TQ * nkb * 8; idx += 512) {  // 16 bits each
+        const uint32_t q = idx / (nkb * 8), piece = idx % (nkb * 8);
+        uint32_t bits16 = 0;
+        if (q0 + q < n_queries) bits16 = *reinterpret_cast<const uint16_t *>(qbits + (uint64_t)(q0 + q) * q_stride + piece * 2);
+        *reinterpret_cast<v4i *>(lds_raw + q * PA + piece * 16) = expand(bits16);
+    }
+    if (t < TQ) {
+        uint32_t pq = 0;
+        if (q0 + t < n_queries)
+            for (uint32_t w = 0; w < nkb * 4; w++) pq += __popc(*reinterpret_cast<const uint32_t *>(qbits + (uint64_t)(q0 + t) * q_stride + w * 4));
+        const float qo = zx ? dim_f - 2.0f * (float)pq : 2.0f * (float)pq - dim_f;
+        q_off_s[t] = qo;
+        if (FILTER) {
+            const float pv = q0 + t < n_queries ? filt.pivot_scores[q0 + t] : (LARGEST ? __builtin_huge_valf() : -__builtin_huge_valf());
+            pivot_s[t] = pv;
+            int bq = pp_bound<LOW>(pv - qo, fabsf(pv) + fabsf(qo), multiplier, 1);
+            if (__builtin_isinf(pv)) bq = ((pv > 0.0f) == LARGEST) == LOW ? -(int)kPpLim : (int)kPpLim;
+            bq_s[t] = bq;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t n_chunks = (n_rows + CHUNK - 1) / CHUNK, stride = gridDim.x * 8;
+    const uint8_t *a_base = lds_raw + r * PA + 64 * h;
+    uint2 cur[MJ][8], nxt[MJ][8];  // up to 8 K-blocks in registers at a time (rows of up to 1024 bits per pass)
+    (void)nxt;
+    for (uint32_t chunk = blockIdx.x * 8 + wave; chunk < n_chunks; chunk += stride) {
+        const uint64_t row0 = (uint64_t)chunk * CHUNK;
+        v16i acc[MI][MJ];
+        uint32_t pop[MJ] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                v4i b4 = {0, 0, 0, 0};
+                if (FILTER) b4 = *reinterpret_cast<const v4i *>(bq_s + i * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int jj = 0; jj < MJ; jj++) acc[i][jj][4 * gq + e] = -b4[e];
+            }
+        for (uint32_t kb0 = 0; kb0 < nkb; kb0 += 8) {  // the store's rows are padded: reads past a row stay in bounds
+            const uint32_t nk = nkb - kb0 < 8 ? nkb - kb0 : 8;
+#pragma unroll
+            for (int jj = 0; jj < MJ; jj++) {
+                const uint8_t *p = rows + (row0 + jj * 32 + r) * ds + (size_t)kb0 * 16 + 8 * h;
+#pragma unroll
+                for (int kb = 0; kb < 8; kb++)
+                    cur[jj][kb] = (uint32_t)kb < nk ? *reinterpret_cast<const uint2 *>(p + 16 * kb) : make_uint2(0, 0);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                if ((uint32_t)kb >= nk) break;
+#pragma unroll
+                for (int jj = 0; jj < MJ; jj++) pop[jj] += __popc(cur[jj][kb].x) + __popc(cur[jj][kb].y);
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    v4i bf[MJ];
+#pragma unroll
+                    for (int jj = 0; jj < MJ; jj++) {
+                        const uint32_t word = (x < 2) ? cur[jj][kb].x : cur[jj][kb].y;
+                        bf[jj] = expand((word >> (16 * (x & 1))) & 0xFFFFu);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MI; i++) {
+                        const v4i a = *reinterpret_cast<const v4i *>(a_base + (uint32_t)i * 32u * PA + (kb0 + kb) * 128 + 16 * x);
+#pragma unroll
+                        for (int jj = 0; jj < MJ; jj++) acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[jj], acc[i][jj], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- epilogue: rows on the lanes (r; the two halves h hold the two halves of every K-block's bits)
+        uint4 *wave_list = FILTER ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave) * filt.wave_cap : nullptr;
+#pragma unroll
+        for (int jj = 0; jj < MJ; jj++) {
+            const uint32_t pv = pop[jj] + (uint32_t)__shfl_xor((int)pop[jj], 32);
+            const uint64_t row = row0 + jj * 32 + r;
+            const bool row_ok = row < n_rows;
+            const float v_off = zx ? -2.0f * (float)pv : 2.0f * (float)pv;
+            int br = 0;
+            if (FILTER) br = row_ok ? pp_bound<LOW>(-v_off, fabsf(v_off), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                if (FILTER) {  // "some accumulator of the tile may pass": the largest is >= the row bound (LOW: the smallest <)
+                    int ext = acc[i][jj][0];
+#pragma unroll
+                    for (int e = 1; e < 15; e += 2)
+                        ext = LOW ? min(min(ext, acc[i][jj][e]), acc[i][jj][e + 1]) : max(max(ext, acc[i][jj][e]), acc[i][jj][e + 1]);
+                    ext = LOW ? min(ext, acc[i][jj][15]) : max(ext, acc[i][jj][15]);
+                    if (!__builtin_amdgcn_readfirstlane(__ballot(LOW ? ext < br : ext >= br) != 0)) continue;
+                }
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const uint32_t ql = i * 32 + 8 * gq + 4 * h;
+                    const float4 qo4 = *reinterpret_cast<const float4 *>(q_off_s + ql);
+                    const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                    if (!FILTER) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float sc = (multiplier * (float)acc[i][jj][4 * gq + e] + qo[e]) + v_off;
+                            const uint32_t q = q0 + ql + e;
+                            if (row_ok && q < n_queries) out[(uint64_t)q * out_pitch + row] = sc;
+                        }
+                    } else {
+                        const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + ql);
+                        const float4 pv4 = *reinterpret_cast<const float4 *>(pivot_s + ql);
+                        const float pvt[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int av = acc[i][jj][4 * gq + e];
+                            if (LOW ? av < br : av >= br) {  // may pass: the exact f32 comparison decides
+                                const float sc = (multiplier * (float)(av + bq4[e]) + qo[e]) + v_off;
+                                const float d = LARGEST ? sc - pvt[e] : pvt[e] - sc;
+                                if (d >= 0.0f) {
+                                    const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                    if (pos < filt.wave_cap)
+                                        wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row, q0 + ql + e, 0u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+}
+
+// Sample rows for the pivots (rows only; the golden-ratio scatter of topk.hip), then `pad` zero rows.
+__global__ __launch_bounds__(256) void bin_gather_rows_kernel(const uint4 *__restrict__ rows, uint32_t row_chunks, uint64_t n_rows,
+                                                             uint32_t n, uint32_t pad, uint4 *__restrict__ out) {
+    const uint64_t total = (uint64_t)(n + pad) * row_chunks;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t j = (uint32_t)(i / row_chunks), c = (uint32_t)(i % row_chunks);
+        if (j >= n) {
+            out[i] = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        const unsigned long long hsh = (unsigned long long)j * 0x9E3779B97F4A7C15ull;
+        const uint64_t src = ((hsh >> 32) * n_rows) >> 32;
+        out[i] = rows[src * row_chunks + c];
+    }
+}
+
+}  // namespace
+
+
+namespace {
+
+// Query fragments per workgroup tile that fit in LDS for this row length (0: none).
+inline int bin_mfma_frags(uint64_t ds) {
+    const uint64_t nkb = ds / 16;
+    if ((size_t)64 * (nkb * 128 + 16) + 2048 <= 160 * 1024) return 2;
+    if ((size_t)32 * (nkb * 128 + 16) + 2048 <= 160 * 1024) return 1;
+    return 0;
+}
+
+template <int MODE>
+qamd_status launch_bin_gemm(const qamd_bin *h, const qamd_bin_query_batch *b, const uint8_t *rows, uint64_t n_rows, uint32_t q0,
+                            int mi, float *out, uint64_t out_pitch, const BatchFilter &filt, hipStream_t s) {
+    const bool zx = (h->vp.distance_type == QAMD_DOT) != (h->vp.invert != 0);
+    const bool low = MODE != 0 && (!zx) != (MODE == 2);  // multiplier = zx ? +4 : -4
+    const size_t lds = (size_t)32 * mi * ((h->ds / 16) * 128 + 16) + 3 * 64 * 4 + 64;
+    const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
+#define QAMD_BIN_GEMM(M_, LOW_, MI_)                                                                                        \
+    do {                                                                                                                   \
+        static std::atomic<uint64_t> set_on{0};                                                                            \
+        if (first_use_on_device(set_on))                                                                                   \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gemm_rs_kernel<M_, LOW_, MI_>),               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+        hipLaunchKernelGGL((bin_gemm_rs_kernel<M_, LOW_, MI_>), dim3(grid), dim3(512), lds, s, rows, (uint32_t)h->ds,      \
+                           b->bits.as<uint8_t>(), (uint32_t)b->q_stride, (float)h->vp.dim, zx ? 1 : 0, (uint32_t)n_rows,   \
+                           (uint32_t)b->n_queries, q0, out, out_pitch, filt);                                              \
+    } while (0)
+    constexpr int M = MODE == 0 ? 1 : MODE;
+    if (MODE == 0) {
+        if (mi == 2) QAMD_BIN_GEMM(0, false, 2);
+        else QAMD_BIN_GEMM(0, false, 1);
+    } else if (low) {
+        if (mi == 2) QAMD_BIN_GEMM(M, true, 2);
+        else QAMD_BIN_GEMM(M, true, 1);
+    } else {
+        if (mi == 2) QAMD_BIN_GEMM(M, false, 2);
+        else QAMD_BIN_GEMM(M, false, 1);
+    }
+#undef QAMD_BIN_GEMM
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+// The batch on the matrix cores: per-query pivot from a cached row sample, one filtering pass per query tile
+// (32 or 64 queries), candidates scattered to per-query lists, one emit.  status[q] != 0: query q must be redone
+// by the exact path (its list over- or underflowed: heavy ties, an unlucky sample).
+qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b, uint32_t k, int largest, uint32_t *ids_dev,
+                                float *sc_dev, std::vector<uint32_t> &status, hipStream_t s) {
+    const uint64_t Q = b->n_queries, n = h->count;
+    const int mi = bin_mfma_frags(h->ds);
+    const uint32_t TQ = 32u * (uint32_t)mi;
+    const uint64_t q_pad = round_up(Q, 64);
+    const double want = std::max<double>(Q <= 128 ? 1024.0 : 512.0, 3.0 * k);
+    const double s_min = n < (1u << 20) ? 2048.0 : (double)kTopkSample;
+    const double s_mem_cap = std::max<double>(s_min, std::floor((double)(6ull << 30) / (4.0 * (double)Q) / 256.0) * 256.0);
+    const uint32_t S = (uint32_t)std::min<double>(std::min<double>(524288.0, s_mem_cap),
+                                                  std::max<double>(s_min, round_up((uint64_t)(8.0 * (double)n / want), 256)));
+    const double target = std::max<double>(want, 8.0 * (double)n / (double)S);
+    const uint32_t r = (uint32_t)std::ceil((double)S * target / (double)n);
+    if (r > 64) {  // (tiny stores are not routed here)
+        std::fill(status.begin(), status.end(), 1u);
+        return QAMD_OK;
+    }
+    // the pivot sample of the store: gathered once per handle, every call uses a prefix (see u8_batch.hip)
+    const uint32_t rows_all = (uint32_t)std::min<double>(524288.0, std::max<double>(s_min, (double)round_up((uint64_t)(8.0 * (double)n / 512.0), 256)));
+    const uint32_t rc = (uint32_t)(h->ds / 16);
+    {
+        std::lock_guard<std::mutex> lk(h->sample_mu);
+        if (h->sample_count < rows_all) {
+            DevBuf c;
+            QAMD_TRY(c.alloc((uint64_t)(rows_all + 512) * h->ds));
+            hipLaunchKernelGGL(bin_gather_rows_kernel, dim3(device_info().cu_count * 8), dim3(256), 0, s, h->rows.as<uint4>(), rc, n,
+                               rows_all, 512u, c.as<uint4>());
+            QAMD_HIP(hipGetLastError());
+            QAMD_HIP(hipStreamSynchronize(s));
+            h->sample_rows = std::move(c);
+            h->sample_count = rows_all;
+        }
+    }
+    const uint32_t n_lists = pp_waves_per_launch();
+    const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, TQ) / (double)n_lists;
+    const uint32_t wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(256.0, 4.0 * per_wave));
+    size_t arena_bytes = 0;
+    auto reserve = [&](size_t bytes) {
+        const size_t off = arena_bytes;
+        arena_bytes += round_up(std::max<size_t>(bytes, 16), 256);
+        return off;
+    };
+    const size_t o_pivots = reserve(q_pad * 4), o_counters = reserve(q_pad * kCounterStride * 4), o_wcounts = reserve((size_t)n_lists * 4);
+    const size_t zero_bytes = arena_bytes;
+    const size_t o_scores = reserve(Q * (uint64_t)S * 4), o_cand = reserve(Q * (uint64_t)kBatchCap * 8), o_status = reserve((Q + 1) * 4),
+                 o_wcand = reserve((uint64_t)n_lists * wave_cap * sizeof(uint4));
+    StreamBuf arena;
+    QAMD_TRY(arena.alloc(arena_bytes, s));
+    char *base = arena.as<char>();
+    QAMD_HIP(hipMemsetAsync(base, 0, zero_bytes, s));
+    float *pivots = reinterpret_cast<float *>(base + o_pivots);
+    uint32_t *counters = reinterpret_cast<uint32_t *>(base + o_counters);
+    uint32_t *wave_counts = reinterpret_cast<uint32_t *>(base + o_wcounts);
+    float *s_scores = reinterpret_cast<float *>(base + o_scores);
+    unsigned long long *cand = reinterpret_cast<unsigned long long *>(base + o_cand);
+    uint4 *wave_cand = reinterpret_cast<uint4 *>(base + o_wcand);
+    const HostScratch hs = Q + 1 <= 2048 ? host_scratch() : HostScratch{};
+    uint32_t *status_dev = hs.dev ? hs.dev : reinterpret_cast<uint32_t *>(base + o_status);
+    uint32_t *overflow_dev = status_dev + Q;
+    if (hs.host) hs.host[Q] = 0;
+    else QAMD_HIP(hipMemsetAsync(overflow_dev, 0, 4, s));
+    // sample scores of every query, then every query's pivot
+    for (uint32_t q0 = 0; q0 < Q; q0 += TQ)
+        QAMD_TRY(launch_bin_gemm<0>(h, b, h->sample_rows.as<uint8_t>(), S, q0, mi, s_scores, S, BatchFilter{}, s));
+    hipLaunchKernelGGL(batch_pivot_kernel, dim3((unsigned)q_pad), dim3(1024), 0, s, s_scores, S, (uint64_t)S, r, largest, (uint32_t)Q,
+                       pivots, counters);
+    BatchFilter f{};
+    f.pivot_scores = pivots;
+    f.counters = counters;
+    f.candidates = cand;
+    f.largest = largest;
+    f.wave_cap = wave_cap;
+    f.wave_cand = wave_cand;
+    f.wave_counts = wave_counts;
+    for (uint32_t q0 = 0; q0 < Q; q0 += TQ) {  // one pass over the rows per query tile; its lists are scattered right away
+        if (largest) QAMD_TRY(launch_bin_gemm<1>(h, b, h->rows.as<uint8_t>(), n, q0, mi, nullptr, 0, f, s));
+        else QAMD_TRY(launch_bin_gemm<2>(h, b, h->rows.as<uint8_t>(), n, q0, mi, nullptr, 0, f, s));
+        if (Q <= 4096)
+            hipLaunchKernelGGL(wave_scatter_grouped_kernel, dim3(std::min<uint32_t>(n_lists, 128)), dim3(1024), (size_t)Q * 8, s, wave_cand,
+                               wave_counts, wave_cap, n_lists, (uint32_t)Q, counters, cand, overflow_dev);
+        else
+            hipLaunchKernelGGL(wave_scatter_kernel, dim3(n_lists), dim3(256), 0, s, wave_cand, wave_counts, wave_cap, counters, cand,
+                               overflow_dev);
+    }
+    if (k <= kSmallTopkMaxK)
+        hipLaunchKernelGGL(batch_emit_wave_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand, counters, n, k, largest, ids_dev, sc_dev,
+                           status_dev);
+    else
+        hipLaunchKernelGGL(batch_emit_kernel, dim3((unsigned)Q), dim3(1024), 0, s, cand, counters, n, k, largest, ids_dev, sc_dev,
+                           status_dev);
+    QAMD_HIP(hipGetLastError());
+    uint32_t overflow = 0;
+    if (hs.host) {
+        QAMD_HIP(hipStreamSynchronize(s));
+        std::copy(hs.host, hs.host + Q, status.begin());
+        overflow = hs.host[Q];
+    } else {
+        std::vector<uint32_t> back(Q + 1);
+        QAMD_TRY(copy_out(back.data(), QAMD_MEM_HOST, status_dev, (Q + 1) * 4, s));
+        std::copy(back.begin(), back.begin() + Q, status.begin());
+        overflow = back[Q];
+    }
+    if (overflow) std::fill(status.begin(), status.end(), 1u);
+    return QAMD_OK;
+}
+
+}  // namespace
+
+
 extern "C" {
 
 qamd_status qamd_bin_encode_query_batch(const qamd_bin *h, const float *queries, uint64_t n_queries, uint64_t qdim,
@@ -992,11 +1348,49 @@ qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b
         if (took && hipGetLastError() != hipSuccess) status = fail(QAMD_ERR_DEVICE, "binary multi-query filter launch failed");
         return took;
     };
-    return fused_topk_batch(h->count, (uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, as_stream(stream),
-                            scan);
+    // 16 queries and more on stores of 32k rows and more: the matrix cores (bin_gemm_rs_kernel); queries whose
+    // candidate list over- or underflowed there (heavy ties at small dims) go through the path below one by one
+    const uint64_t Q = b->n_queries;
+    hipStream_t s = as_stream(stream);
+    if (Q >= 16 && h->count >= 32768 && k <= 1024 && fused_capable(h) && bin_mfma_frags(h->ds) != 0 && h->vp.dim >= 64) {
+        StreamBuf ids_tmp, sc_tmp;
+        uint32_t *ids_dev = out_ids;
+        float *sc_dev = out_scores;
+        if (out_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(ids_tmp.alloc(Q * k * 4, s));
+            QAMD_TRY(sc_tmp.alloc(Q * k * 4, s));
+            ids_dev = ids_tmp.as<uint32_t>();
+            sc_dev = sc_tmp.as<float>();
+        }
+        std::vector<uint32_t> status(Q, 1);
+        QAMD_TRY(bin_topk_batch_mfma(h, b, k, largest, ids_dev, sc_dev, status, s));
+        for (uint64_t q = 0; q < Q; q++) {
+            if (!status[q]) continue;
+            BatchScan one;
+            one.filter_capable = scan.filter_capable;
+            one.scan_scores = [&, q](uint32_t, float *scores, hipStream_t st) { return scan.scan_scores((uint32_t)q, scores, st); };
+            one.scan_filter = [&, q](uint32_t, const TopkFilter &f, hipStream_t st) { return scan.scan_filter((uint32_t)q, f, st); };
+            one.score_ids = [&, q](uint32_t, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
+                return scan.score_ids((uint32_t)q, ids, n_ids, out, st);
+            };
+            one.topk_small = [&, q](uint32_t, uint32_t *ids, float *sc, hipStream_t st, qamd_status &status1) {
+                return scan.topk_small((uint32_t)q, ids, sc, st, status1);
+            };
+            QAMD_TRY(fused_topk_batch(h->count, 1, k, largest, ids_dev + q * k, sc_dev + q * k, QAMD_MEM_DEVICE, s, one));
+        }
+        if (out_mem == QAMD_MEM_HOST) {
+            QAMD_TRY(copy_out(out_ids, QAMD_MEM_HOST, ids_dev, Q * k * 4, s));
+            QAMD_TRY(copy_out(out_scores, QAMD_MEM_HOST, sc_dev, Q * k * 4, s));
+        } else {
+            QAMD_HIP(hipStreamSynchronize(s));
+        }
+        return QAMD_OK;
+    }
+    return fused_topk_batch(h->count, (uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, s, scan);
 }
 
 }  // extern "C"
+
 
 // ============================================================================= streaming encode
 // EncodedVectorsBin::encode (:165-191) walks its iterator ONCE, pushing one packed row per vector

@@ -85,3 +85,27 @@ def test_batch_edge_cases():
     assert penc.score_batch(pb).shape == (2, 10)
     with pytest.raises(qa.EncodingError):
         penc.encode_query_batch(rng.random((2, dim + 1), dtype=np.float32))
+
+
+@pytest.mark.parametrize("dim,n,nq", [
+    (1024, 100_003, 64),    # one 64-query tile, eight K-blocks
+    (1000, 70_000, 100),    # dim not a multiple of 128: pad bits are zero in rows and queries; two tiles
+    (128, 300_000, 40),     # one K-block, heavy ties (129 distinct scores): lists overflow -> exact path per query
+    (2304, 40_000, 16),     # 18 K-blocks: three register passes per row
+    (4992, 33_000, 33),     # 39 K-blocks: only a 32-query tile fits in LDS
+    (640, 50_000, 300),     # five tiles
+])
+def test_binary_batch_on_the_matrix_cores(dim, n, nq):
+    """16 queries and more on 32k rows and more take bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
+    registers, int8 MFMA, u8-style epilogue with integer operands): every list must equal the single-query
+    top-k, for the four metric variants and both directions."""
+    rng = np.random.default_rng(dim + nq)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    for dist, invert, largest in ((D.Dot, False, True), (D.L2, False, False), (D.Dot, True, False), (D.L1, True, True)):
+        enc = qa.EncodedVectorsBin.encode(data, qa.VectorParameters(dim, n, dist, invert))
+        ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30, largest=largest)
+        for qi in sorted({0, 1, min(31, nq - 1), min(32, nq - 1), nq // 2, nq - 2, nq - 1}):
+            wi, ws = enc.topk(enc.encode_query(queries[qi]), 30, largest=largest)
+            assert np.array_equal(ids[qi], wi), (dist, invert, largest, qi)
+            assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (dist, invert, largest, qi)
