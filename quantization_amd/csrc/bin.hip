@@ -1083,9 +1083,9 @@ __global__ __launch_bounds__(256) void bin_gather_rows_kernel(const uint4 *__res
 namespace {
 
 // Query fragments per workgroup tile that fit in LDS for this row length (0: none).
-inline int bin_mfma_frags(uint64_t ds) {
+inline int bin_mfma_frags(uint64_t ds, uint64_t n_queries = ~0ull) {
     const uint64_t nkb = ds / 16;
-    if ((size_t)64 * (nkb * 128 + 16) + 2048 <= 160 * 1024) return 2;
+    if (n_queries > 32 && (size_t)64 * (nkb * 128 + 16) + 2048 <= 160 * 1024) return 2;
     if ((size_t)32 * (nkb * 128 + 16) + 2048 <= 160 * 1024) return 1;
     return 0;
 }
@@ -1129,7 +1129,7 @@ qamd_status launch_bin_gemm(const qamd_bin *h, const qamd_bin_query_batch *b, co
 qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b, uint32_t k, int largest, uint32_t *ids_dev,
                                 float *sc_dev, std::vector<uint32_t> &status, hipStream_t s) {
     const uint64_t Q = b->n_queries, n = h->count;
-    const int mi = bin_mfma_frags(h->ds);
+    const int mi = bin_mfma_frags(h->ds, Q);
     const uint32_t TQ = 32u * (uint32_t)mi;
     const uint64_t q_pad = round_up(Q, 64);
     const double want = std::max<double>(Q <= 128 ? 1024.0 : 512.0, 3.0 * k);
@@ -1301,6 +1301,15 @@ qamd_status qamd_bin_score_batch(const qamd_bin *h, const qamd_bin_query_batch *
     }
     const uint8_t *bits = b->bits.as<uint8_t>();
     uint64_t q = 0;
+    // 5 queries and more: tiles of 32 / 64 queries on the matrix cores (same scores bit for bit: every f32
+    // of the epilogue is an exact integer); the row bits are read once per tile instead of once per 8 queries
+    // (measured at 50M x 1024: one 32-query tile 2.28 ms whatever the batch; the vector-ALU passes 1.81 ms for 4
+    // queries, 2.6 for 8, and from there 2.6 ms per 8)
+    if (b->n_queries >= 5 && h->count >= 4096 && fused_capable(h) && bin_mfma_frags(h->ds) != 0 && h->vp.dim >= 64) {
+        const int mi = bin_mfma_frags(h->ds, b->n_queries);
+        for (; q < b->n_queries; q += 32 * mi)  // (a partly filled last tile computes zero queries and stores nothing for them)
+            QAMD_TRY(launch_bin_gemm<0>(h, b, h->rows.as<uint8_t>(), h->count, (uint32_t)q, mi, out_dev, h->count, BatchFilter{}, s));
+    }
     while (q < b->n_queries) {
         const uint64_t left = b->n_queries - q;
         const uint8_t *qb = bits + q * b->q_stride;
@@ -1348,11 +1357,12 @@ qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b
         if (took && hipGetLastError() != hipSuccess) status = fail(QAMD_ERR_DEVICE, "binary multi-query filter launch failed");
         return took;
     };
-    // 16 queries and more on stores of 32k rows and more: the matrix cores (bin_gemm_rs_kernel); queries whose
+    // 12 queries and more on stores of 32k rows and more (below that the filtering vector-ALU passes, 0.22 ms per
+    // query at 50M rows, are cheaper than one matrix-core pass): bin_gemm_rs_kernel; queries whose
     // candidate list over- or underflowed there (heavy ties at small dims) go through the path below one by one
     const uint64_t Q = b->n_queries;
     hipStream_t s = as_stream(stream);
-    if (Q >= 16 && h->count >= 32768 && k <= 1024 && fused_capable(h) && bin_mfma_frags(h->ds) != 0 && h->vp.dim >= 64) {
+    if (Q >= 12 && h->count >= 32768 && k <= 1024 && fused_capable(h) && bin_mfma_frags(h->ds) != 0 && h->vp.dim >= 64) {
         StreamBuf ids_tmp, sc_tmp;
         uint32_t *ids_dev = out_ids;
         float *sc_dev = out_scores;

@@ -96,7 +96,7 @@ def test_batch_edge_cases():
     (640, 50_000, 300),     # five tiles
 ])
 def test_binary_batch_on_the_matrix_cores(dim, n, nq):
-    """16 queries and more on 32k rows and more take bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
+    """12 queries and more on 32k rows and more take bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
     registers, int8 MFMA, u8-style epilogue with integer operands): every list must equal the single-query
     top-k, for the four metric variants and both directions."""
     rng = np.random.default_rng(dim + nq)
