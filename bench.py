@@ -318,8 +318,8 @@ def main():
         return el
 
     if args.batch_queries > 0:
-        if args.quantizer != "u8":
-            raise SystemExit("--batch-queries is the scalar-u8 multi-query path")
+        if args.quantizer not in ("u8", "binary"):
+            raise SystemExit("--batch-queries is the matrix-core multi-query path (u8, binary)")
         from quantization_amd.sharded import ShardedTopKBatch
         Q, k = args.batch_queries, args.k
         bq = torch.rand((Q, dim), generator=qgen, device=dev, dtype=torch.float32)
@@ -337,16 +337,18 @@ def main():
             bstep(i)
         elapsed = timed_region(bstep, args.steps)
         if rank == 0:
-            ad = enc.metadata["actual_dim"]
+            is_bin = args.quantizer == "binary"
+            ad = dim if is_bin else enc.metadata["actual_dim"]  # binary: one 0/1 operand byte per bit on the matrix cores
             ops = 2.0 * Q * n * ad  # per GPU and step
             per_gpu_tops = ops * args.steps / elapsed / 1e12
             print(json.dumps({
-                "metric": f"(query, vector) pairs scored/sec, {Q} queries x {total_rows}x{dim} u8 dot, top-{k} each",
+                "metric": f"(query, vector) pairs scored/sec, {Q} queries x {total_rows}x{dim} {args.quantizer} dot, top-{k} each",
                 "value": float(Q) * total_rows * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": scaling_field, "vs_baseline": None,
-                "dtype": "u8 x u8 -> i32 (MFMA int8)", "data": "synthetic",
-                "config": {"workload": f"{Q} queries x {total_rows} x {dim} scalar-u8 rows ({n} on rank 0), per step: "
+                "dtype": "1-bit x 1-bit -> i32 (bits expanded to 0/1 bytes, MFMA int8)" if is_bin else "u8 x u8 -> i32 (MFMA int8)",
+                "data": "synthetic",
+                "config": {"workload": f"{Q} queries x {total_rows} x {dim} {'binary' if is_bin else 'scalar-u8'} rows ({n} on rank 0), per step: "
                                        f"topk_batch over the shard + all-gather of world*Q*k pairs + per-query merge "
                                        f"on the GPU",
                            "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows},

@@ -12,3 +12,5 @@ run pq --quantizer pq
 run batch1024 --batch-queries 1024 --k 30 --steps 5 --warmup 3
 run batch1024_1536 --batch-queries 1024 --k 30 --steps 5 --warmup 3 --dim 1536 --rows 12500000
 run batch64 --batch-queries 64 --k 30 --steps 10 --warmup 5
+run bin_batch64 --quantizer binary --dim 1024 --rows 50000000 --batch-queries 64 --k 30 --steps 10 --warmup 5
+run bin_batch1024 --quantizer binary --dim 1024 --rows 50000000 --batch-queries 1024 --k 30 --steps 3 --warmup 2

@@ -1161,7 +1161,9 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     }
     const uint32_t n_lists = pp_waves_per_launch();
     const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, TQ) / (double)n_lists;
-    const uint32_t wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(256.0, 4.0 * per_wave));
+    // (at least 1024 slots: queries of one batch can be near-duplicates, and then a passing row appends to every
+    // query's list at once - 64 entries in one wave's list per such row)
+    const uint32_t wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(1024.0, 16.0 * per_wave));
     size_t arena_bytes = 0;
     auto reserve = [&](size_t bytes) {
         const size_t off = arena_bytes;

@@ -109,3 +109,18 @@ def test_binary_batch_on_the_matrix_cores(dim, n, nq):
             wi, ws = enc.topk(enc.encode_query(queries[qi]), 30, largest=largest)
             assert np.array_equal(ids[qi], wi), (dist, invert, largest, qi)
             assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (dist, invert, largest, qi)
+
+
+def test_binary_batch_of_identical_queries():
+    """Near-duplicate queries make every passing row append to all lists at once (bursts in one wave's
+    candidate list): the result must still be exact, and the fast path must hold (no wave-list overflow)."""
+    rng = np.random.default_rng(3)
+    n, dim, nq = 400_000, 512, 64
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    enc = qa.EncodedVectorsBin.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    q = rng.standard_normal(dim).astype(np.float32)
+    queries = np.repeat(q[None, :], nq, axis=0)
+    ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30)
+    wi, ws = enc.topk(enc.encode_query(q), 30)
+    for qi in (0, 31, 63):
+        assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi], ws), qi

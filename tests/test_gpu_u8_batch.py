@@ -424,3 +424,18 @@ def test_topk_batch_more_than_4096_queries():
             wi, ws = enc.topk(qobj, k)
             assert np.array_equal(ids[qi], wi), (k, qi)
             assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (k, qi)
+
+
+@pytest.mark.parametrize("nq", [100, 1024])
+def test_topk_batch_of_identical_queries(nq):
+    """Duplicate queries in one batch: every passing row appends to all their lists at once (bursts in the
+    wave-private candidate lists); results must be exact and identical for every copy."""
+    rng = np.random.default_rng(23)
+    n, dim = 200_000, 128
+    data = rng.random((n, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    q = rng.random(dim, dtype=np.float32)
+    ids, sc = enc.topk_batch(enc.encode_query_batch(np.repeat(q[None, :], nq, axis=0)), 30)
+    wi, ws = enc.topk(enc.encode_query(q), 30)
+    for qi in (0, nq // 2, nq - 1):
+        assert np.array_equal(ids[qi], wi) and np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), qi
