@@ -956,8 +956,7 @@ __global__ __launch_bounds__(512) void bin_gemm_rs_kernel(const uint8_t *__restr
 
     const uint32_t n_chunks = (n_rows + CHUNK - 1) / CHUNK, stride = gridDim.x * 8;
     const uint8_t *a_base = lds_raw + r * PA + 64 * h;
-    uint2 cur[MJ][8], nxt[MJ][8];  // up to 8 K-blocks in registers at a time (rows of up to 1024 bits per pass)
-    (void)nxt;
+    uint2 cur[MJ][8];  // up to 8 K-blocks in registers at a time (rows of up to 1024 bits per pass)
     for (uint32_t chunk = blockIdx.x * 8 + wave; chunk < n_chunks; chunk += stride) {
         const uint64_t row0 = (uint64_t)chunk * CHUNK;
         v16i acc[MI][MJ];
