@@ -896,7 +896,7 @@ template <int NQ> bool multi_step(const qamd_bin *h, const uint8_t *qbits, uint6
 // exact, so the scores are the reference's bit for bit.  bin_gemm_rs_kernel is u8_gemm_rs_kernel's structure
 // (csrc/u8_batch.hip: query tile resident in LDS, every wave streams its own 64 rows, no barrier after the
 // set-up) with the rows kept as BITS up to the registers: lane (r, h) loads the 8 bytes [16 kb + 8h, +8) of row
-// r per 128-bit K-block and expands 16 bits to 16 operand bytes (nibble * 0x00204081 & 0x01010101) right before
+// r per 128-bit K-block and expands 16 bits to 16 operand bytes (umul24(nibble, 0x00204081) & 0x01010101) right before
 // the MFMAs that use them; the row's popcount falls out of the same loads.  HBM sees 1/8 of the bytes the
 // contraction works on, so the kernel is matrix-pipe / VALU-bound from the first query tile on.
 // The pre-filter starts the accumulators at -B_q and compares against the row's bound after the K loop (the
@@ -924,11 +924,13 @@ __global__ __launch_bounds__(512) void bin_gemm_rs_kernel(const uint8_t *__restr
     uint32_t *wcount_s = reinterpret_cast<uint32_t *>(bq_s + 64) + wave;
     if (FILTER && lane == 0) *wcount_s = 0;
     auto expand = [](uint32_t bits16) {  // 16 bits -> 16 bytes of 0 / 1
+        // nibble * (1 + 2^7 + 2^14 + 2^21) puts bit j at position 8j; both factors fit the full-rate 24-bit
+        // multiply (v_mul_u32_u24: 4 cycles; v_mul_lo_u32 is quarter rate and made this the kernel's bound)
         v4i v;
-        v.x = (int)(((bits16 & 0xFu) * 0x00204081u) & 0x01010101u);
-        v.y = (int)((((bits16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-        v.z = (int)((((bits16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-        v.w = (int)((((bits16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+        v.x = (int)(__umul24(bits16 & 0xFu, 0x00204081u) & 0x01010101u);
+        v.y = (int)(__umul24((bits16 >> 4) & 0xFu, 0x00204081u) & 0x01010101u);
+        v.z = (int)(__umul24((bits16 >> 8) & 0xFu, 0x00204081u) & 0x01010101u);
+        v.w = (int)(__umul24((bits16 >> 12) & 0xFu, 0x00204081u) & 0x01010101u);
         return v;
     };
     // the query tile as bytes (queries past the batch: zero), its offsets and integer bounds
