@@ -4,6 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Launch.  `python bench.py --gpus N` with N > 1 and no rank environment starts its own ranks: the
+parent, before it touches torch.cuda or HIP, runs `python -m torch.distributed.run --nproc-per-node N
+... bench.py <same flags>` as a CHILD process (never exec), relays rank 0's JSON line and exits with
+the child's code; under torch.distributed.run (RANK/WORLD_SIZE set) it is a rank.  `--single-process`
+instead drives all N GPUs from this one process through the row-sharded C ABI (`qamd_u8_sharded_*`,
+what INTEGRATION.md tells a single-process caller like Qdrant to hold) and prints the same line.
+
 One "step" = one query against the whole store: encode_query -> score_all over the rank's shard ->
 the exchange of per-shard results.  Inputs are resident in HBM before the timed region.  Rank 0
 prints ONE JSON line (metric, value, roofline, cpu_baseline, ...).
@@ -24,6 +31,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,9 +61,19 @@ def parse_args():
                     help="u8 = the headline metric (BASELINE configs[1]); binary / pq run configs[3] / [2] "
                          "through the same harness (e.g. --quantizer binary --dim 1024 --rows 50000000)")
     ap.add_argument("--pq-chunk", type=int, default=8)
-    ap.add_argument("--exchange", choices=["scores", "topk", "none"], default="scores",
+    ap.add_argument("--exchange", choices=["auto", "scores", "topk", "none"], default="auto",
                     help="per-query result exchange across ranks (N>1): gather of per-shard scores "
-                         "(overlapped with the next scan), per-shard top-k + all-gather + device merge, or none")
+                         "(overlapped with the next scan), per-shard top-k + all-gather + device merge, or none.  "
+                         "auto = scores for u8 / pq (the north_star's 'RCCL gather of per-shard scores'), topk for "
+                         "binary at N>1: a 128 B/row scan is faster than the 4 B/row score gather over xGMI "
+                         "(SURVEY 8e: 25 MB per rank and query against a 0.125 ms shard scan at 50M x 1024)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive --gpus N devices from THIS process through the row-sharded C ABI "
+                         "(qamd_*_sharded_*: worker threads per GPU, peer copies over xGMI, device-side top-k merge) "
+                         "instead of one rank per GPU over RCCL")
+    ap.add_argument("--devices", default=None,
+                    help="--single-process: comma-separated device list, repeats allowed (logical shards, e.g. 0,0 "
+                         "to rehearse two shards on a one-GPU box); default 0..N-1")
     ap.add_argument("--gather-root", default="rotate",
                     help="--exchange scores: 'rotate' (step i gathers to rank i %% N: consecutive gathers use "
                          "disjoint inbound xGMI links) or a rank number (every step to that rank)")
@@ -206,8 +225,169 @@ def pmc_traffic(quantizer, n, bytes_per_row):
     return None, None
 
 
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """--gpus N > 1 without a rank environment: start the N ranks as a child torch.distributed.run
+    (nothing in this process has touched the GPU yet, and it never will), relay its output, return its
+    exit code."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    for line in child.stdout:  # rank 0's JSON line (and anything else the ranks print) goes straight through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def resolve_exchange(args, world: int) -> tuple[str, str]:
+    """(exchange, why) for this run: `auto` picks the mode that can meet the scaling target."""
+    if args.exchange != "auto":
+        return args.exchange, "given on the command line"
+    if args.quantizer == "binary" and world > 1:
+        return "topk", ("auto: binary rows are 128 B at dim 1024, the per-shard score gather (4 B/row over xGMI) "
+                        "costs more than the scan itself (SURVEY 8e) - per-shard top-k + all-gather of world*k pairs")
+    return "scores", "auto: the north_star's gather of per-shard scores (asynchronous, grouped, rotating root)"
+
+
+def run_single_process(args):
+    """All --gpus N devices driven from this one process through qamd_u8_sharded_* (csrc/sharded.hip):
+    per step encode_query + score_all into a device buffer on devices[0] (exchange scores: each shard's
+    scores peer-copied over xGMI into their slice) or + topk (per-shard top-k, G*k pairs peer-copied,
+    one merge kernel on devices[0]).  Same JSON line as the rank form."""
+    import numpy as np
+    import torch
+
+    import quantization_amd as qa
+    from quantization_amd import _lib
+
+    if args.quantizer != "u8" or args.batch_queries:
+        raise SystemExit("--single-process runs the headline u8 single-query workload")
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit("--devices must name exactly --gpus devices")
+    L = _lib.lib()
+    G, dim, n_total = args.gpus, args.dim, args.rows
+    scaling = "strong" if (args.scaling in ("auto", "strong")) else "weak"
+    if scaling == "weak":
+        n_total = args.rows * G
+    dist_t = qa.DistanceType.Dot if args.distance == "dot" else qa.DistanceType.L2
+    exchange, why = resolve_exchange(args, G)
+    if exchange == "none":
+        raise SystemExit("--single-process: the sharded handle always delivers (scores or top-k); use scores or topk")
+    root = devices[0]
+    torch.cuda.set_device(root)
+    dev = torch.device("cuda", root)
+    vp = qa.VectorParameters(dim, n_total, dist_t, False)
+    alpha_offset = (float(np.float32(1.0) / np.float32(127.0)), 0.0)  # U[0,1): the analytic interval, as the rank form
+    # The store is encoded piece by piece on devices[0] (the 30.7 GB of f32 never exist as one buffer), exported
+    # as reference-format rows and adopted by the sharded handle with from_rows -- what a caller holding a store
+    # encoded elsewhere (Qdrant's mmap) does; every shard peer-copies its own row range.  Never timed.
+    stride = qa.EncodedVectorsU8.get_quantized_vector_size(vp)
+    rows = torch.empty((n_total, stride), dtype=torch.uint8, device=dev)
+    piece = 2_500_000
+    for r0 in range(0, n_total, piece):
+        nr = min(piece, n_total - r0)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(42 + r0 // piece)
+        part = torch.rand((nr, dim), generator=gen, device=dev, dtype=torch.float32)
+        enc = qa.EncodedVectorsU8.encode(part, qa.VectorParameters(dim, nr, dist_t, False), alpha_offset=alpha_offset)
+        enc.storage_bytes(out=rows[r0:r0 + nr])
+        meta = enc.metadata
+        del part, enc
+    meta["vector_parameters"] = vp
+    sh = qa.ShardedVectorsU8.from_storage(rows, meta, devices)
+    del rows
+    qgen = torch.Generator(device=dev)
+    qgen.manual_seed(43)
+    queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
+    torch.cuda.synchronize()
+
+    f_encode, f_score, f_topk = L.qamd_u8_sharded_encode_query, L.qamd_u8_sharded_score_all, L.qamd_u8_sharded_topk
+    hq = C.c_void_p()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = torch.empty(max(n_total, 1), dtype=torch.float32, device=dev)
+    ids = torch.empty(args.k, dtype=torch.int32, device=dev)
+    sc = torch.empty(args.k, dtype=torch.float32, device=dev)
+    q_ptrs = [C.c_void_p(queries[i].data_ptr()) for i in range(args.queries)]
+
+    def step(i):
+        st = f_encode(sh._h, q_ptrs[i % args.queries], dim, _lib.MEM_DEVICE, stream, C.byref(hq))
+        if exchange == "scores":
+            st |= f_score(sh._h, hq, C.c_void_p(out.data_ptr()), _lib.MEM_DEVICE, stream)
+        else:
+            st |= f_topk(sh._h, hq, args.k, 1, C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()), _lib.MEM_DEVICE, stream)
+        if st:
+            raise RuntimeError(L.qamd_last_error().decode())
+
+    for i in range(20 + args.warmup):
+        step(i)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)  # every sharded call is synchronous: its workers have finished when it returns
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+
+    # the dominant kernel, timed on shard 0's own handle with HIP events on the stream it is launched on
+    view, _base = sh.shard(0)
+    n0 = view.count
+    with torch.cuda.device(devices[0]):
+        q0 = view.encode_query(queries[0])
+        o0 = torch.empty(max(n0, 1), dtype=torch.float32, device=dev)
+        for _ in range(10):
+            view.score_all(q0, out=o0)
+        evs = []
+        for _ in range(20):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            view.score_all(q0, out=o0)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+    kern_all = [a.elapsed_time(b) for a, b in evs]
+    kern_ms = float(np.mean(kern_all))
+    bytes_per_row = view.scan_bytes_per_row()
+    achieved = bytes_per_row * n0 / (kern_ms * 1e-3) / 1e9
+    names = [torch.cuda.get_device_name(d) for d in devices]
+    headline = (n_total == 10_000_000 and dim == 768 and args.distance == "dot")
+    print(json.dumps({
+        "metric": "scored vectors/sec, 10Mx768 u8 dot" if headline else f"scored vectors/sec, {n_total}x{dim} u8 {args.distance}",
+        "value": n_total * args.steps / elapsed, "unit": "vectors/s", "n_gpus": G, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if (G == 1 or scaling == "weak") else "strong", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": f"{n_total} x {dim} store row-sharded over {G} GPUs behind ONE handle "
+                               f"(qamd_u8_sharded_*, {n0} rows on shard 0); per step: encode_query + "
+                               + ("score_all into a device buffer on devices[0] (peer copies of 4 B/row)"
+                                  if exchange == "scores" else f"topk({args.k}) (per-shard top-k, device-side merge)"),
+                   "launch": "single-process", "devices": devices, "device_names": names, "quantizer": "u8",
+                   "rows_per_gpu": n0, "dim": dim, "distance": args.distance, "exchange": exchange,
+                   "exchange_reason": why, "total_rows": n_total, "queries": args.queries,
+                   "shard_lanes": int(os.environ.get("QAMD_SHARD_LANES", "2"))},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "u8_scan_kernel", "kernel_ms": kern_ms,
+                     "kernel_ms_min": float(np.min(kern_all)), "kernel_ms_median": float(np.median(kern_all)),
+                     "kernel_ms_mean": kern_ms, "algorithmic_bytes_per_row": bytes_per_row, "rows_per_launch": n0,
+                     "note": "shard 0's scan timed on its own handle after the timed region (the sharded calls launch "
+                             "on the library's worker streams)"},
+    }), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.single_process:
+        return run_single_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -220,9 +400,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world  # the launcher's world size wins
+    args.exchange, exchange_reason = resolve_exchange(args, world)
     dev_index = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
     torch.cuda.set_device(dev_index)
     qa.set_device(dev_index)
@@ -238,6 +417,25 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev, **kw)
         else:
             dist.init_process_group(backend=args.backend, **kw)
+
+    # What the process group really is, for the record: backend, the world size torch.distributed reports,
+    # the RCCL version, and which device every rank sits on (all-gathered through the group itself).
+    dist_info = {"launch": "torch.distributed.run ranks" if "RANK" in os.environ else "single rank",
+                 "dist_backend": None, "world_size_seen": 1, "rccl_version": None,
+                 "rank_devices": [f"cuda:{dev_index} {torch.cuda.get_device_name(dev_index)}"]}
+    if use_dist:
+        mine = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index),
+                "uuid": str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", "")), "pid": os.getpid()}
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        dist_info.update({"dist_backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                          "rccl_version": rccl if args.backend == "nccl" else None,
+                          "rank_devices": [f"rank {e['rank']}: cuda:{e['device']} {e['name']} {e['uuid']} pid {e['pid']}"
+                                           for e in everyone]})
 
     scaling = args.scaling if args.scaling != "auto" else "strong"
     if world == 1:
@@ -351,7 +549,7 @@ def main():
                 "config": {"workload": f"{Q} queries x {total_rows} x {dim} {'binary' if is_bin else 'scalar-u8'} rows ({n} on rank 0), per step: "
                                        f"topk_batch over the shard + all-gather of world*Q*k pairs + per-query merge "
                                        f"on the GPU",
-                           "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows},
+                           "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows, **dist_info},
                 "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": MFMA_INT8_PEAK_TOPS, "unit": "TFLOP/s",
                              "frac": per_gpu_tops / MFMA_INT8_PEAK_TOPS, "traffic": None,
                              "note": "int8 op/s per GPU over the whole step (sample pass, filter GEMM, scatter, "
@@ -518,7 +716,8 @@ def main():
                                    f"per step: encode_query + score_all over the shard"
                                    + (f" + {args.exchange} exchange" if world > 1 and args.exchange != "none" else ""),
                        "quantizer": args.quantizer, "rows_per_gpu": n, "dim": dim, "distance": args.distance,
-                       "exchange": args.exchange, "gather_group": group if gather is not None else None,
+                       "exchange": args.exchange, "exchange_reason": exchange_reason,
+                       "gather_group": group if gather is not None else None, **dist_info,
                        "encode_ahead": encode_ahead, "kernel_timed_every": time_every,
                        "gather_root": args.gather_root if (world > 1 and args.exchange == "scores") else None,
                        "total_rows": total_rows, "queries": args.queries},

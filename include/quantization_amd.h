@@ -25,6 +25,10 @@
  *     whether the exact fallback has to run.  They cannot be captured into a hipGraph; score_all can.
  *   - every call runs on the handle's device and leaves the calling thread's current HIP device
  *     as it found it.
+ *   - a call that only enqueues keeps using the calling thread's cached workspace until its work has
+ *     run: the next call of that thread waits for it on the device (an event), whatever its stream.
+ *     A hipGraph that captured such a call must not be replayed concurrently with other calls of the
+ *     capturing thread.
  *   - handles own device memory; row bytes handed in stay caller-owned.
  *   - all score_* / topk calls are thread-safe on a shared handle (no interior mutation),
  *     matching `&self` in the reference.
@@ -378,14 +382,22 @@ QAMD_API qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_ba
  * ann_benchmark_data.rs:151-167).  Shard g of G owns rows [g*N/G, (g+1)*N/G) as an ordinary
  * handle on devices[g]; global row id = shard base + local id; metadata is replicated.
  * `devices` may repeat a device (logical shards on one GPU).  Every call is synchronous: it
- * fans out to one worker thread per shard (its own stream on the shard's device), waits, and does
- * ONE exchange -- score_all: each shard's scores land in their slice of `out` (host: one D2H
- * per GPU; device: peer copy of 4 B/row over xGMI to the device owning `out`); topk: G*k
- * (id, score) pairs are peer-copied to devices[0] and merged by one kernel there with the
- * single-handle ordering (best first, ties to the lower global id).  Results are bit-identical
- * to the same call on a single handle holding all rows.  Host buffers or device buffers; a
- * device output of topk must live on devices[0].  One call at a time per handle (calls from
- * several threads serialise).
+ * posts one job per shard (served by worker threads bound to the shard's device, each with its own
+ * stream), waits for ITS jobs, and does ONE exchange -- score_all: each shard's scores land in their
+ * slice of `out` (host: one D2H per GPU; device: peer copy of 4 B/row over xGMI to the device owning
+ * `out`); topk: G*k (id, score) pairs are peer-copied to devices[0] and merged by one kernel there
+ * with the single-handle ordering (best first, ties to the lower global id).  Results are
+ * bit-identical to the same call on a single handle holding all rows.  Host buffers or device
+ * buffers; a device output of topk must live on devices[0].
+ * Threads: encode_query / score_all / topk / topk_batch may be called from any number of threads on
+ * one sharded handle at once, like the `&self` methods they stand for (encoded_vectors.rs:21-35):
+ * there is no per-handle lock, the callers' jobs interleave on the shards' queues and each call
+ * leases its own exchange buffers.
+ * `stream`: the hipStream_t that produced the call's device INPUT buffers / still uses the buffers
+ * its device OUTPUTS overwrite (NULL = the null stream of the device owning the buffer).  It is
+ * synchronised on entry when a buffer of the call is device memory (the workers run on their own
+ * streams, which nothing else orders against the caller's); ignored for host buffers.  At return
+ * every output is complete.
  * =================================================================================== */
 typedef struct qamd_u8_sharded qamd_u8_sharded;
 typedef struct qamd_u8_sharded_query qamd_u8_sharded_query;
@@ -395,32 +407,35 @@ typedef struct qamd_u8_sharded_query_batch qamd_u8_sharded_query_batch;
 QAMD_API qamd_status qamd_u8_sharded_encode(const float *data, qamd_mem data_mem,
                                             const qamd_vector_parameters *vp, const float *quantile,
                                             const float *alpha_offset, qamd_stop_fn stop, void *stop_user,
-                                            const int *devices, uint32_t n_shards, qamd_u8_sharded **out);
+                                            const int *devices, uint32_t n_shards, void *stream,
+                                             qamd_u8_sharded **out);
 QAMD_API qamd_status qamd_u8_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                                const qamd_u8_metadata *meta, const int *devices,
-                                               uint32_t n_shards, qamd_u8_sharded **out);
+                                               uint32_t n_shards, void *stream,
+                                             qamd_u8_sharded **out);
 QAMD_API uint32_t qamd_u8_sharded_shard_count(const qamd_u8_sharded *h);
 /* Borrow shard g (owned by the sharded handle): its single-device handle, first global row, device. */
 QAMD_API qamd_status qamd_u8_sharded_shard(const qamd_u8_sharded *h, uint32_t g, const qamd_u8 **shard,
                                            uint64_t *row_begin, int *device);
 QAMD_API qamd_status qamd_u8_sharded_get_metadata(const qamd_u8_sharded *h, qamd_u8_metadata *out);
 QAMD_API qamd_status qamd_u8_sharded_encode_query(qamd_u8_sharded *h, const float *query, uint64_t qdim,
-                                                  qamd_mem query_mem, qamd_u8_sharded_query **query_io);
+                                                  qamd_mem query_mem, void *stream,
+                                             qamd_u8_sharded_query **query_io);
 QAMD_API void qamd_u8_sharded_query_free(qamd_u8_sharded_query *q);
 QAMD_API qamd_status qamd_u8_sharded_score_all(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, float *out,
-                                               qamd_mem out_mem);
+                                               qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_u8_sharded_topk(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, uint32_t k,
                                           int largest, uint32_t *out_ids, float *out_scores,
-                                          qamd_mem out_mem);
+                                          qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_u8_sharded_encode_query_batch(qamd_u8_sharded *h, const float *queries,
                                                         uint64_t n_queries, uint64_t qdim,
-                                                        qamd_mem queries_mem,
-                                                        qamd_u8_sharded_query_batch **batch_io);
+                                                        qamd_mem queries_mem, void *stream,
+                                             qamd_u8_sharded_query_batch **batch_io);
 QAMD_API void qamd_u8_sharded_query_batch_free(qamd_u8_sharded_query_batch *b);
 /* n_queries x k; shards x k <= 8192. */
 QAMD_API qamd_status qamd_u8_sharded_topk_batch(qamd_u8_sharded *h, const qamd_u8_sharded_query_batch *b,
                                                 uint32_t k, int largest, uint32_t *out_ids,
-                                                float *out_scores, qamd_mem out_mem);
+                                                float *out_scores, qamd_mem out_mem, void *stream);
 QAMD_API void qamd_u8_sharded_free(qamd_u8_sharded *h);
 
 typedef struct qamd_bin_sharded qamd_bin_sharded;
@@ -428,31 +443,33 @@ typedef struct qamd_bin_sharded_query qamd_bin_sharded_query;
 QAMD_API qamd_status qamd_bin_sharded_encode(const float *data, qamd_mem data_mem,
                                              const qamd_vector_parameters *vp, qamd_bits_store store,
                                              qamd_stop_fn stop, void *stop_user, const int *devices,
-                                             uint32_t n_shards, qamd_bin_sharded **out);
+                                             uint32_t n_shards, void *stream,
+                                             qamd_bin_sharded **out);
 QAMD_API qamd_status qamd_bin_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                                 const qamd_vector_parameters *vp, qamd_bits_store store,
-                                                const int *devices, uint32_t n_shards,
-                                                qamd_bin_sharded **out);
+                                                const int *devices, uint32_t n_shards, void *stream,
+                                             qamd_bin_sharded **out);
 QAMD_API uint32_t qamd_bin_sharded_shard_count(const qamd_bin_sharded *h);
 QAMD_API qamd_status qamd_bin_sharded_shard(const qamd_bin_sharded *h, uint32_t g, const qamd_bin **shard,
                                             uint64_t *row_begin, int *device);
 QAMD_API qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *query, uint64_t qdim,
-                                                   qamd_mem query_mem, qamd_bin_sharded_query **query_io);
+                                                   qamd_mem query_mem, void *stream,
+                                             qamd_bin_sharded_query **query_io);
 QAMD_API void qamd_bin_sharded_query_free(qamd_bin_sharded_query *q);
 QAMD_API qamd_status qamd_bin_sharded_score_all(qamd_bin_sharded *h, const qamd_bin_sharded_query *q,
-                                                float *out, qamd_mem out_mem);
+                                                float *out, qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_bin_sharded_topk(qamd_bin_sharded *h, const qamd_bin_sharded_query *q, uint32_t k,
                                            int largest, uint32_t *out_ids, float *out_scores,
-                                           qamd_mem out_mem);
+                                           qamd_mem out_mem, void *stream);
 typedef struct qamd_bin_sharded_query_batch qamd_bin_sharded_query_batch;
 QAMD_API qamd_status qamd_bin_sharded_encode_query_batch(qamd_bin_sharded *h, const float *queries,
                                                          uint64_t n_queries, uint64_t qdim,
-                                                         qamd_mem queries_mem,
-                                                         qamd_bin_sharded_query_batch **batch_io);
+                                                         qamd_mem queries_mem, void *stream,
+                                             qamd_bin_sharded_query_batch **batch_io);
 QAMD_API void qamd_bin_sharded_query_batch_free(qamd_bin_sharded_query_batch *b);
 QAMD_API qamd_status qamd_bin_sharded_topk_batch(qamd_bin_sharded *h, const qamd_bin_sharded_query_batch *b,
                                                  uint32_t k, int largest, uint32_t *out_ids,
-                                                 float *out_scores, qamd_mem out_mem);
+                                                 float *out_scores, qamd_mem out_mem, void *stream);
 QAMD_API void qamd_bin_sharded_free(qamd_bin_sharded *h);
 
 typedef struct qamd_pq_sharded qamd_pq_sharded;
@@ -462,32 +479,35 @@ QAMD_API qamd_status qamd_pq_sharded_encode(const float *data, qamd_mem data_mem
                                             const qamd_vector_parameters *vp, uint64_t chunk_size,
                                             const float *centroids, uint32_t max_kmeans_threads,
                                             qamd_stop_fn stop, void *stop_user, const int *devices,
-                                            uint32_t n_shards, qamd_pq_sharded **out);
+                                            uint32_t n_shards, void *stream,
+                                             qamd_pq_sharded **out);
 QAMD_API qamd_status qamd_pq_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                                const qamd_vector_parameters *vp, uint64_t chunk_size,
                                                const float *centroids, const int *devices,
-                                               uint32_t n_shards, qamd_pq_sharded **out);
+                                               uint32_t n_shards, void *stream,
+                                             qamd_pq_sharded **out);
 QAMD_API uint32_t qamd_pq_sharded_shard_count(const qamd_pq_sharded *h);
 QAMD_API qamd_status qamd_pq_sharded_shard(const qamd_pq_sharded *h, uint32_t g, const qamd_pq **shard,
                                            uint64_t *row_begin, int *device);
 QAMD_API qamd_status qamd_pq_sharded_get_centroids(const qamd_pq_sharded *h, float *centroids);
 QAMD_API qamd_status qamd_pq_sharded_encode_query(qamd_pq_sharded *h, const float *query, uint64_t qdim,
-                                                  qamd_mem query_mem, qamd_pq_sharded_query **query_io);
+                                                  qamd_mem query_mem, void *stream,
+                                             qamd_pq_sharded_query **query_io);
 QAMD_API void qamd_pq_sharded_query_free(qamd_pq_sharded_query *q);
 QAMD_API qamd_status qamd_pq_sharded_score_all(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, float *out,
-                                               qamd_mem out_mem);
+                                               qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_pq_sharded_topk(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, uint32_t k,
                                           int largest, uint32_t *out_ids, float *out_scores,
-                                          qamd_mem out_mem);
+                                          qamd_mem out_mem, void *stream);
 typedef struct qamd_pq_sharded_query_batch qamd_pq_sharded_query_batch;
 QAMD_API qamd_status qamd_pq_sharded_encode_query_batch(qamd_pq_sharded *h, const float *queries,
                                                         uint64_t n_queries, uint64_t qdim,
-                                                        qamd_mem queries_mem,
-                                                        qamd_pq_sharded_query_batch **batch_io);
+                                                        qamd_mem queries_mem, void *stream,
+                                             qamd_pq_sharded_query_batch **batch_io);
 QAMD_API void qamd_pq_sharded_query_batch_free(qamd_pq_sharded_query_batch *b);
 QAMD_API qamd_status qamd_pq_sharded_topk_batch(qamd_pq_sharded *h, const qamd_pq_sharded_query_batch *b,
                                                 uint32_t k, int largest, uint32_t *out_ids,
-                                                float *out_scores, qamd_mem out_mem);
+                                                float *out_scores, qamd_mem out_mem, void *stream);
 QAMD_API void qamd_pq_sharded_free(qamd_pq_sharded *h);
 
 /* ===================================================================================

@@ -157,43 +157,43 @@ def lib() -> C.CDLL:
         "qamd_pq_encoder_finish": (i32, [vp, pp]),
         "qamd_pq_encoder_abort": (None, [vp]),
         # row-sharded stores (one process, several GPUs)
-        "qamd_u8_sharded_encode": (i32, [vp, i32, VP, f32p, f32p, STOP_FN, vp, C.POINTER(i32), u32, pp]),
-        "qamd_u8_sharded_from_rows": (i32, [vp, i32, C.POINTER(U8MetadataC), C.POINTER(i32), u32, pp]),
+        "qamd_u8_sharded_encode": (i32, [vp, i32, VP, f32p, f32p, STOP_FN, vp, C.POINTER(i32), u32, vp, pp]),
+        "qamd_u8_sharded_from_rows": (i32, [vp, i32, C.POINTER(U8MetadataC), C.POINTER(i32), u32, vp, pp]),
         "qamd_u8_sharded_shard_count": (u32, [vp]),
         "qamd_u8_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
         "qamd_u8_sharded_get_metadata": (i32, [vp, C.POINTER(U8MetadataC)]),
-        "qamd_u8_sharded_encode_query": (i32, [vp, vp, u64, i32, pp]),
+        "qamd_u8_sharded_encode_query": (i32, [vp, vp, u64, i32, vp, pp]),
         "qamd_u8_sharded_query_free": (None, [vp]),
-        "qamd_u8_sharded_score_all": (i32, [vp, vp, vp, i32]),
-        "qamd_u8_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
-        "qamd_u8_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, pp]),
+        "qamd_u8_sharded_score_all": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_u8_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
+        "qamd_u8_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, vp, pp]),
         "qamd_u8_sharded_query_batch_free": (None, [vp]),
-        "qamd_u8_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_u8_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_u8_sharded_free": (None, [vp]),
-        "qamd_bin_sharded_encode": (i32, [vp, i32, VP, i32, STOP_FN, vp, C.POINTER(i32), u32, pp]),
-        "qamd_bin_sharded_from_rows": (i32, [vp, i32, VP, i32, C.POINTER(i32), u32, pp]),
+        "qamd_bin_sharded_encode": (i32, [vp, i32, VP, i32, STOP_FN, vp, C.POINTER(i32), u32, vp, pp]),
+        "qamd_bin_sharded_from_rows": (i32, [vp, i32, VP, i32, C.POINTER(i32), u32, vp, pp]),
         "qamd_bin_sharded_shard_count": (u32, [vp]),
         "qamd_bin_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
-        "qamd_bin_sharded_encode_query": (i32, [vp, vp, u64, i32, pp]),
+        "qamd_bin_sharded_encode_query": (i32, [vp, vp, u64, i32, vp, pp]),
         "qamd_bin_sharded_query_free": (None, [vp]),
-        "qamd_bin_sharded_score_all": (i32, [vp, vp, vp, i32]),
-        "qamd_bin_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
-        "qamd_bin_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, pp]),
+        "qamd_bin_sharded_score_all": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_bin_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
+        "qamd_bin_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, vp, pp]),
         "qamd_bin_sharded_query_batch_free": (None, [vp]),
-        "qamd_bin_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_bin_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_bin_sharded_free": (None, [vp]),
-        "qamd_pq_sharded_encode": (i32, [vp, i32, VP, u64, vp, u32, STOP_FN, vp, C.POINTER(i32), u32, pp]),
-        "qamd_pq_sharded_from_rows": (i32, [vp, i32, VP, u64, vp, C.POINTER(i32), u32, pp]),
+        "qamd_pq_sharded_encode": (i32, [vp, i32, VP, u64, vp, u32, STOP_FN, vp, C.POINTER(i32), u32, vp, pp]),
+        "qamd_pq_sharded_from_rows": (i32, [vp, i32, VP, u64, vp, C.POINTER(i32), u32, vp, pp]),
         "qamd_pq_sharded_shard_count": (u32, [vp]),
         "qamd_pq_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
         "qamd_pq_sharded_get_centroids": (i32, [vp, vp]),
-        "qamd_pq_sharded_encode_query": (i32, [vp, vp, u64, i32, pp]),
+        "qamd_pq_sharded_encode_query": (i32, [vp, vp, u64, i32, vp, pp]),
         "qamd_pq_sharded_query_free": (None, [vp]),
-        "qamd_pq_sharded_score_all": (i32, [vp, vp, vp, i32]),
-        "qamd_pq_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32]),
-        "qamd_pq_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, pp]),
+        "qamd_pq_sharded_score_all": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_pq_sharded_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
+        "qamd_pq_sharded_encode_query_batch": (i32, [vp, vp, u64, u64, i32, vp, pp]),
         "qamd_pq_sharded_query_batch_free": (None, [vp]),
-        "qamd_pq_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32]),
+        "qamd_pq_sharded_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_pq_sharded_free": (None, [vp]),
         "qamd_topk_scores": (i32, [vp, u64, u32, i32, vp, vp, i32, vp]),
         "qamd_topk_merge": (i32, [vp, vp, u64, vp, u32, u32, u32, i32, vp, vp, i32, vp]),

@@ -257,8 +257,8 @@ constexpr int kMaxDevices = 64;
 struct ThreadWs {
     void *ptr = nullptr;
     size_t bytes = 0;
-    hipStream_t last_stream = nullptr;  // stream of the last call that used the buffer
-    bool in_flight = false;             // that call only enqueued (no synchronisation since)
+    hipEvent_t done = nullptr;  // recorded behind the last call that only enqueued work on the buffer
+    bool in_flight = false;     // `done` may not have completed yet
     uint64_t tags[3] = {0, 0, 0};
 };
 
@@ -289,6 +289,7 @@ struct ThreadState {
             if (hipSetDevice(dev) == hipSuccess) {
                 moved = true;
                 (void)hipFree(w.ptr);  // waits for the device: nothing of ours can still be using it
+                if (w.done) (void)hipEventDestroy(w.done);
             }
             w = ThreadWs{};
         }
@@ -353,10 +354,15 @@ void host_query_release(hipStream_t s) {
     if (ts.query_read && hipEventRecord(ts.query_read, s) == hipSuccess) ts.query_pending = true;
 }
 
-// Hand-off between consecutive calls of one thread: work on ONE stream is ordered by the stream
-// itself (the common case: nothing to do, which also keeps these calls capturable into a hipGraph);
-// a thread that moves to another stream while its previous call may still be running waits for
-// the device once.  No events: nothing is ever recorded on a stream the caller might have destroyed.
+// Hand-off between consecutive calls of one thread.  A call that synchronised its stream before it
+// released the workspace (host outputs) leaves nothing behind.  A call that only ENQUEUED records the
+// workspace's own event behind its work; the next acquire -- on whatever stream -- makes that stream
+// wait for the event unless it has completed already.  Events outlive streams, so nothing is ever
+// asked of a stream the caller may have destroyed since, no stream handle is compared, and there is
+// no device-wide synchronisation (which would stall other threads' scans and is illegal inside a
+// stream capture).  While a stream is being captured nothing is recorded: the captured work runs
+// when the graph is launched, and a graph that uses a thread's workspace must not be replayed
+// concurrently with other calls of that thread (include/quantization_amd.h, conventions).
 qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out, uint64_t **tags) {
     int dev = 0;
     QAMD_HIP(hipGetDevice(&dev));
@@ -375,21 +381,39 @@ qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, vo
         QAMD_HIP(hipMalloc(&w.ptr, want));
         w.bytes = want;
     }
-    if (w.in_flight && w.last_stream != s) {
-        QAMD_HIP(hipDeviceSynchronize());
-        w.in_flight = false;
+    if (w.in_flight) {
+        const hipError_t q = hipEventQuery(w.done);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            QAMD_HIP(hipStreamWaitEvent(s, w.done, 0));
+        } else if (q != hipSuccess) {
+            return fail(QAMD_ERR_DEVICE, "workspace hand-off: hipEventQuery failed: %s", hipGetErrorString(q));
+        } else {
+            w.in_flight = false;
+        }
     }
     *out = w.ptr;
     if (tags) *tags = w.tags;
     return QAMD_OK;
 }
 
-void thread_ws_release(ThreadWsSlot slot, hipStream_t s) {
+void thread_ws_release(ThreadWsSlot slot, hipStream_t s, bool synced) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return;
     ThreadWs &w = thread_state().at(dev, slot);
-    w.last_stream = s;
-    w.in_flight = true;
+    w.in_flight = false;
+    if (synced) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) return;
+    if (!w.done && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) {
+        w.done = nullptr;
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);  // no event to hand over: finish the work instead
+        return;
+    }
+    if (hipEventRecord(w.done, s) == hipSuccess) w.in_flight = true;
+    else (void)hipStreamSynchronize(s);
 }
 
 void thread_release_all() { thread_state().release(); }

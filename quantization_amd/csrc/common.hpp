@@ -164,9 +164,9 @@ HostScratch host_scratch();
 float *host_query_acquire(size_t n_floats, const float **dev_view);
 void host_query_release(hipStream_t s);
 
-// Grow-only device workspaces per calling thread AND device, handed from call to call: calls on
-// one stream are ordered by the stream; acquire() on ANOTHER stream than the last release() waits
-// for the device once (rare).  For the whole-store calls' scratch (score vector of a top-k, radix-select
+// Grow-only device workspaces per calling thread AND device, handed from call to call: a call that
+// only enqueued records the workspace's event at release(), the next acquire() makes its stream wait
+// for it (no device-wide synchronisation, no stream handle kept).  For the whole-store calls' scratch (score vector of a top-k, radix-select
 // state, PQ partial sums): hipMallocAsync + hipFreeAsync cost ~70 us per buffer and call on this
 // runtime, which is most of a top-k on a small store.  A thread that alternates between stores
 // on several GPUs keeps one workspace per (slot, device).  Freed by qamd_thread_release() or when
@@ -176,7 +176,8 @@ enum ThreadWsSlot { WS_SCORES = 0, WS_SELECT = 1, WS_PARTIAL = 2, WS_FUSED = 3, 
 // whenever it is (re)allocated: what the caller has cached inside it.
 qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, void **out,
                               uint64_t **tags = nullptr);
-void thread_ws_release(ThreadWsSlot slot, hipStream_t s);
+// synced: the caller synchronised `s` after its last use of the buffer (nothing to hand over).
+void thread_ws_release(ThreadWsSlot slot, hipStream_t s, bool synced = false);
 // Frees every workspace and the mapped host scratch of the calling thread (all devices).
 void thread_release_all();
 

@@ -1243,7 +1243,7 @@ qamd_status qamd_pq_score_all(const qamd_pq *h, const qamd_pq_query *q, float *o
     QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * 4, s, reinterpret_cast<void **>(&tmp)));
     qamd_status st = scan_launch(h, q->lut.as<float>(), nullptr, h->count, tmp, s);
     if (st == QAMD_OK) st = copy_out(out, QAMD_MEM_HOST, tmp, h->count * 4, s);
-    thread_ws_release(WS_SCORES, s);
+    thread_ws_release(WS_SCORES, s, st == QAMD_OK);  // the download synchronised the stream
     return st;
 }
 

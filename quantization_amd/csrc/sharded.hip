@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -42,7 +44,16 @@ qamd_status pq_train_centroids(const float *data, qamd_mem data_mem, const qamd_
 namespace {
 
 // ------------------------------------------------------------------------------------ workers
-// A worker sleeps on a condition variable between calls, but both sides first poll for ~50 us:
+// Execution model.  Every shard has a job queue served by kLanes worker threads ("lanes"), each bound
+// to the shard's device with its own stream and its own per-thread workspaces.  A call from ANY caller
+// thread posts one job per shard and waits for its own jobs only, so K threads searching one sharded
+// handle (the reference's `&self` methods are called from many search threads at once,
+// quantization/src/encoded_vectors.rs:21-35) interleave on the shards' queues instead of taking turns
+// on the handle: there is no per-handle lock on the query path.  What a call needs beyond the shard
+// handles -- the gather / result buffers on devices[0], the per-shard staging buffers, a root stream
+// -- lives in a CallSlot leased for the duration of the call (as many slots as there are concurrent
+// callers, created on demand).
+// A lane sleeps on the queue's condition variable between jobs, but both sides first poll for ~50 us:
 // searches arrive back to back, and a futex wake-up (10-20 us) per shard and call would otherwise be
 // a fifth of a 1.25M-row shard scan.
 inline void cpu_relax() {
@@ -51,72 +62,134 @@ inline void cpu_relax() {
 #endif
 }
 constexpr int kSpinIterations = 4000;
+constexpr uint32_t kMaxLanes = 8;
+
+uint32_t lanes_per_shard() {  // QAMD_SHARD_LANES=1..8 (default 2: one job runs while the next is being enqueued)
+    static const uint32_t lanes = [] {
+        const char *e = getenv("QAMD_SHARD_LANES");
+        const long v = e ? strtol(e, nullptr, 10) : 2;
+        return (uint32_t)(v < 1 ? 1 : v > (long)kMaxLanes ? kMaxLanes : v);
+    }();
+    return lanes;
+}
+
+struct Worker;  // a lane
+
+// One fan-out: completed when every job posted for it has run.  Lives on the caller's stack; the
+// lane that finishes the last job sets `done` and notifies UNDER the mutex, and the caller leaves
+// wait() only after taking that mutex, so no lane touches a Call its owner has already destroyed.
+struct Call {
+    std::atomic<uint32_t> pending{0};
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    qamd_status status = QAMD_OK;  // first failure
+    std::string error;
+
+    void finish_one(qamd_status st, const std::string &err) {
+        if (st != QAMD_OK) {
+            std::lock_guard<std::mutex> lk(m);
+            if (status == QAMD_OK) {
+                status = st;
+                error = err;
+            }
+        }
+        if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk(m);
+            done = true;
+            cv.notify_all();
+        }
+    }
+
+    qamd_status wait() {
+        for (int i = 0; i < kSpinIterations * 8 && pending.load(std::memory_order_acquire) != 0; i++) cpu_relax();
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        if (status != QAMD_OK) last_error() = error;
+        return status;
+    }
+};
+
+struct Job {
+    const std::function<qamd_status(uint32_t, Worker &)> *fn = nullptr;
+    uint32_t shard = 0;
+    Call *call = nullptr;
+};
+
+struct ShardQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    std::atomic<uint32_t> queued{0};  // == jobs.size(), readable without the lock (the lanes' poll)
+    bool quit = false;
+
+    void push(const Job &j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            jobs.push_back(j);
+            queued.store((uint32_t)jobs.size(), std::memory_order_release);
+        }
+        cv.notify_one();
+    }
+};
 
 struct Worker {
     int device = 0;
     hipStream_t stream = nullptr;
+    ShardQueue *queue = nullptr;
     std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::function<qamd_status()> job;
-    std::atomic<bool> has_job{false}, finished{false};
-    bool quit = false;
-    qamd_status result = QAMD_OK;
-    std::string error;
+    // set-up hand-shake with Pool::start (a lane that cannot select its device or create its stream
+    // must not silently run shard jobs on the null stream of whatever device is current)
+    std::mutex ready_m;
+    std::condition_variable ready_cv;
+    bool ready = false;
+    qamd_status setup = QAMD_OK;
+    std::string setup_error;
 
     void loop() {
-        (void)hipSetDevice(device);
-        (void)qamd_set_device(device);  // handles this thread creates live on the shard's device
-        (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-        for (;;) {
-            for (int i = 0; i < kSpinIterations && !has_job.load(std::memory_order_acquire); i++) cpu_relax();
-            std::function<qamd_status()> fn;
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return has_job.load(std::memory_order_acquire) || quit; });
-                if (quit) break;
-                fn = std::move(job);
-                has_job.store(false, std::memory_order_relaxed);
-            }
-            qamd_status st = fn();
-            std::string err = st == QAMD_OK ? std::string() : last_error();
-            {
-                std::lock_guard<std::mutex> lk(m);
-                result = st;
-                error = std::move(err);
-                finished.store(true, std::memory_order_release);
-            }
-            cv.notify_all();
+        qamd_status st = QAMD_OK;
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) st = fail(QAMD_ERR_DEVICE, "shard worker: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+        if (st == QAMD_OK) st = qamd_set_device(device);  // handles this thread creates live on the shard's device
+        if (st == QAMD_OK && (e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) {
+            stream = nullptr;
+            st = fail(QAMD_ERR_DEVICE, "shard worker: cannot create a stream on device %d: %s", device, hipGetErrorString(e));
         }
-        if (stream) {
-            (void)hipStreamSynchronize(stream);
-            (void)hipStreamDestroy(stream);
-        }
-        thread_release_all();  // this thread's workspaces go with it
-    }
-
-    void post(std::function<qamd_status()> fn) {
         {
-            std::lock_guard<std::mutex> lk(m);
-            job = std::move(fn);
-            finished.store(false, std::memory_order_relaxed);
-            has_job.store(true, std::memory_order_release);
+            std::lock_guard<std::mutex> lk(ready_m);
+            setup = st;
+            if (st != QAMD_OK) setup_error = last_error();
+            ready = true;
+            ready_cv.notify_all();
         }
-        cv.notify_all();
-    }
-
-    qamd_status wait() {
-        for (int i = 0; i < kSpinIterations * 8 && !finished.load(std::memory_order_acquire); i++) cpu_relax();
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return finished.load(std::memory_order_acquire); });
-        if (result != QAMD_OK) last_error() = error;
-        return result;
+        if (st != QAMD_OK) {
+            if (stream) (void)hipStreamDestroy(stream);
+            return;
+        }
+        ShardQueue &q = *queue;
+        for (;;) {
+            for (int i = 0; i < kSpinIterations && q.queued.load(std::memory_order_acquire) == 0; i++) cpu_relax();
+            Job job;
+            {
+                std::unique_lock<std::mutex> lk(q.m);
+                q.cv.wait(lk, [&] { return !q.jobs.empty() || q.quit; });
+                if (q.jobs.empty()) break;  // quit, nothing left
+                job = q.jobs.front();
+                q.jobs.pop_front();
+                q.queued.store((uint32_t)q.jobs.size(), std::memory_order_release);
+            }
+            const qamd_status r = (*job.fn)(job.shard, *this);
+            job.call->finish_one(r, r == QAMD_OK ? std::string() : last_error());
+        }
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamDestroy(stream);
+        thread_release_all();  // this thread's workspaces go with it
     }
 };
 
 struct Pool {
-    std::vector<std::unique_ptr<Worker>> workers;
-    std::mutex call;  // one sharded call at a time per handle
+    std::vector<std::unique_ptr<ShardQueue>> queues;  // one per shard
+    std::vector<std::unique_ptr<Worker>> workers;     // kLanes per shard
 
     qamd_status start(const int *devices, uint32_t n) {
         const int have = device_count();
@@ -124,42 +197,45 @@ struct Pool {
         for (uint32_t g = 0; g < n; g++)
             if (devices[g] < 0 || devices[g] >= have)
                 return fail(QAMD_ERR_ARGUMENTS, "shard %u: device %d out of range (have %d)", g, devices[g], have);
+        const uint32_t lanes = lanes_per_shard();
         for (uint32_t g = 0; g < n; g++) {
-            std::unique_ptr<Worker> w(new Worker);
-            w->device = devices[g];
-            Worker *raw = w.get();
-            w->th = std::thread([raw] { raw->loop(); });
-            workers.push_back(std::move(w));
+            queues.emplace_back(new ShardQueue);
+            for (uint32_t l = 0; l < lanes; l++) {
+                std::unique_ptr<Worker> w(new Worker);
+                w->device = devices[g];
+                w->queue = queues.back().get();
+                Worker *raw = w.get();
+                w->th = std::thread([raw] { raw->loop(); });
+                workers.push_back(std::move(w));
+            }
+        }
+        for (auto &w : workers) {
+            std::unique_lock<std::mutex> lk(w->ready_m);
+            w->ready_cv.wait(lk, [&] { return w->ready; });
+            if (w->setup != QAMD_OK) {
+                last_error() = w->setup_error;
+                return w->setup;  // ~Pool joins what was started
+            }
         }
         return QAMD_OK;
     }
 
-    // fn(g, worker) on every shard's worker concurrently; first failure wins.
+    // fn(g, lane) for every shard, concurrently with other callers' jobs; first failure wins.
     qamd_status run(const std::function<qamd_status(uint32_t, Worker &)> &fn) {
-        for (uint32_t g = 0; g < workers.size(); g++) {
-            Worker *w = workers[g].get();
-            w->post([&fn, g, w] { return fn(g, *w); });
-        }
-        qamd_status st = QAMD_OK;
-        std::string err;
-        for (auto &w : workers) {
-            const qamd_status r = w->wait();
-            if (r != QAMD_OK && st == QAMD_OK) {
-                st = r;
-                err = last_error();
-            }
-        }
-        if (st != QAMD_OK) last_error() = err;
-        return st;
+        Call call;
+        const uint32_t G = (uint32_t)queues.size();
+        call.pending.store(G, std::memory_order_relaxed);
+        for (uint32_t g = 0; g < G; g++) queues[g]->push(Job{&fn, g, &call});
+        return call.wait();
     }
 
     ~Pool() {
-        for (auto &w : workers) {
+        for (auto &q : queues) {
             {
-                std::lock_guard<std::mutex> lk(w->m);
-                w->quit = true;
+                std::lock_guard<std::mutex> lk(q->m);
+                q->quit = true;
             }
-            w->cv.notify_all();
+            q->cv.notify_all();
         }
         for (auto &w : workers)
             if (w->th.joinable()) w->th.join();
@@ -257,6 +333,34 @@ template <class H, class Qy> struct ShardedQuery {
     }
 };
 
+// What one in-flight call owns besides the shard handles (leased, see the execution model above).
+struct CallSlot {
+    hipStream_t root_stream = nullptr;  // on devices[0]: the merge kernel and the result download
+    DevBuf gather, result;              // [G][Q][k] ids | [G][Q][k] scores ; [Q][k] ids | scores (devices[0])
+    size_t gather_cap = 0, result_cap = 0;
+    // per shard, on the shard's device: its k pairs / its scores before the peer copy, a staged query
+    std::vector<DevBuf> local_pairs, local_scores, query_stage;
+    bool busy = false;
+};
+
+// The caller's stream and the buffers it hands over.  Sharded calls run on the lanes' own streams,
+// which nothing orders against the stream that PRODUCED a caller's device buffer (or that still reads
+// the buffer a result will overwrite): when a buffer of the call is device memory, the caller's
+// stream is synchronised before the first lane touches it -- NULL meaning the null stream of the
+// device that owns the buffer (torch's default stream).  Every sharded call is synchronous, so at
+// return the outputs are complete and visible to any stream.
+qamd_status order_after_caller(qamd_mem mem, const void *buf, void *stream) {
+    if (mem != QAMD_MEM_DEVICE || !buf) return QAMD_OK;
+    if (stream) {
+        QAMD_HIP(hipStreamSynchronize(as_stream(stream)));
+        return QAMD_OK;
+    }
+    const int dev = device_of(buf);
+    QAMD_ON_DEVICE(dev < 0 ? current_device() : dev);
+    QAMD_HIP(hipStreamSynchronize(nullptr));
+    return QAMD_OK;
+}
+
 template <class H, class Qy> struct Sharded {
     const Ops<H, Qy> *ops = nullptr;
     uint64_t count = 0;
@@ -264,15 +368,53 @@ template <class H, class Qy> struct Sharded {
     std::vector<uint64_t> base;  // G + 1 row bounds
     std::vector<H *> shards;
     Pool pool;
-    // root (devices[0]) side of the top-k exchange
-    hipStream_t root_stream = nullptr;
-    DevBuf gather, bases_dev, result;  // [G][Q][k] ids | [G][Q][k] scores ; [G] u64 ; [Q][k] ids | scores
-    size_t gather_cap = 0, result_cap = 0;
-    // per shard, on the shard's device: its k pairs / its scores before the peer copy
-    std::vector<DevBuf> local_pairs, local_scores, query_stage;
+    DevBuf bases_dev;  // [G] u64 on devices[0], written once
+    std::mutex slots_m;
+    std::vector<std::unique_ptr<CallSlot>> slots;
 
     uint32_t G() const { return (uint32_t)shards.size(); }
     int root() const { return devices[0]; }
+
+    // RAII lease of a CallSlot: an idle one, or a new one (one per concurrent caller at most).
+    struct Lease {
+        Sharded *owner = nullptr;
+        CallSlot *slot = nullptr;
+        Lease() = default;
+        Lease(const Lease &) = delete;
+        Lease &operator=(const Lease &) = delete;
+        ~Lease() {
+            if (!slot) return;
+            std::lock_guard<std::mutex> lk(owner->slots_m);
+            slot->busy = false;
+        }
+        CallSlot *operator->() const { return slot; }
+    };
+    qamd_status lease(Lease &l) {
+        {
+            std::lock_guard<std::mutex> lk(slots_m);
+            for (auto &sl : slots)
+                if (!sl->busy) {
+                    sl->busy = true;
+                    l.owner = this;
+                    l.slot = sl.get();
+                    return QAMD_OK;
+                }
+        }
+        std::unique_ptr<CallSlot> fresh(new CallSlot);
+        fresh->local_pairs.resize(G());
+        fresh->local_scores.resize(G());
+        fresh->query_stage.resize(G());
+        {
+            QAMD_ON_DEVICE(root());
+            QAMD_HIP(hipStreamCreateWithFlags(&fresh->root_stream, hipStreamNonBlocking));
+        }
+        fresh->busy = true;
+        std::lock_guard<std::mutex> lk(slots_m);
+        l.owner = this;
+        l.slot = fresh.get();
+        slots.push_back(std::move(fresh));
+        return QAMD_OK;
+    }
 
     qamd_status init(const int *devs, uint32_t n, uint64_t total) {
         if (!devs || n == 0 || n > 64) return fail(QAMD_ERR_ARGUMENTS, "need 1..64 shards");
@@ -281,9 +423,6 @@ template <class H, class Qy> struct Sharded {
         devices.assign(devs, devs + n);
         shard_bounds(total, n, base);
         shards.assign(n, nullptr);
-        local_pairs.resize(n);
-        local_scores.resize(n);
-        query_stage.resize(n);
         QAMD_TRY(pool.start(devs, n));
         // direct xGMI copies between the shards' devices and devices[0] (the exchanges are peer copies);
         // where peer access cannot be enabled hipMemcpyAsync still works, staged by the runtime
@@ -299,23 +438,23 @@ template <class H, class Qy> struct Sharded {
             (void)hipGetLastError();  // "already enabled" is fine
         }
         QAMD_ON_DEVICE(root());
-        QAMD_HIP(hipStreamCreateWithFlags(&root_stream, hipStreamNonBlocking));
         QAMD_TRY(bases_dev.alloc(n * sizeof(uint64_t)));
-        QAMD_TRY(copy_in(bases_dev.ptr, base.data(), QAMD_MEM_HOST, n * sizeof(uint64_t), root_stream));
+        QAMD_TRY(copy_in(bases_dev.ptr, base.data(), QAMD_MEM_HOST, n * sizeof(uint64_t), nullptr));
         return QAMD_OK;
     }
 
     ~Sharded() {
         for (H *h : shards)
             if (h) ops->free_store(h);
-        if (root_stream) {
-            DeviceGuard g(root());
-            (void)hipStreamSynchronize(root_stream);
-            (void)hipStreamDestroy(root_stream);
-        }
+        for (auto &sl : slots)
+            if (sl->root_stream) {
+                DeviceGuard g(root());
+                (void)hipStreamSynchronize(sl->root_stream);
+                (void)hipStreamDestroy(sl->root_stream);
+            }
     }
 
-    qamd_status encode_query(const float *query, uint64_t qdim, qamd_mem mem, ShardedQuery<H, Qy> **io) {
+    qamd_status encode_query(const float *query, uint64_t qdim, qamd_mem mem, void *stream, ShardedQuery<H, Qy> **io) {
         std::unique_ptr<ShardedQuery<H, Qy>> fresh;
         ShardedQuery<H, Qy> *q = *io;
         if (!q) {
@@ -326,13 +465,16 @@ template <class H, class Qy> struct Sharded {
         }
         if (q->per_shard.size() != G()) return fail(QAMD_ERR_ARGUMENTS, "query belongs to another sharded store");
         const int src_dev = mem == QAMD_MEM_DEVICE ? device_of(query) : -1;
-        std::lock_guard<std::mutex> lk(pool.call);
+        QAMD_TRY(order_after_caller(mem, query, stream));
+        Lease slot;
+        QAMD_TRY(lease(slot));
         QAMD_TRY(pool.run([&](uint32_t g, Worker &w) -> qamd_status {
             const float *src = query;
             if (mem == QAMD_MEM_DEVICE && src_dev != w.device && qdim) {  // a device query lives on ONE GPU
-                if (query_stage[g].bytes < qdim * 4) QAMD_TRY(query_stage[g].alloc(qdim * 4));
-                QAMD_HIP(hipMemcpyAsync(query_stage[g].ptr, query, qdim * 4, hipMemcpyDefault, w.stream));
-                src = query_stage[g].template as<float>();
+                DevBuf &stage = slot->query_stage[g];
+                if (stage.bytes < qdim * 4) QAMD_TRY(stage.alloc(qdim * 4));
+                QAMD_HIP(hipMemcpyAsync(stage.ptr, query, qdim * 4, hipMemcpyDefault, w.stream));
+                src = stage.template as<float>();
             }
             QAMD_TRY(qamd_set_device(w.device));
             QAMD_TRY(ops->encode_query(shards[g], src, qdim, mem, w.stream, &q->per_shard[g]));
@@ -350,13 +492,15 @@ template <class H, class Qy> struct Sharded {
         return QAMD_OK;
     }
 
-    // out[base_g + i] = score_point(q, i of shard g).  Device output lives on devices[0].
-    qamd_status score_all(const ShardedQuery<H, Qy> *q, float *out, qamd_mem out_mem) {
+    // out[base_g + i] = score_point(q, i of shard g).  Device output: on any one GPU.
+    qamd_status score_all(const ShardedQuery<H, Qy> *q, float *out, qamd_mem out_mem, void *stream) {
         QAMD_TRY(check(q));
         if (count == 0) return QAMD_OK;
         if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
         const int out_dev = out_mem == QAMD_MEM_DEVICE ? device_of(out) : -1;
-        std::lock_guard<std::mutex> lk(pool.call);
+        QAMD_TRY(order_after_caller(out_mem, out, stream));
+        Lease slot;
+        QAMD_TRY(lease(slot));
         return pool.run([&](uint32_t g, Worker &w) -> qamd_status {
             const uint64_t n = base[g + 1] - base[g];
             if (n == 0) return QAMD_OK;
@@ -364,49 +508,49 @@ template <class H, class Qy> struct Sharded {
             if (out_mem == QAMD_MEM_HOST || out_dev == w.device) {
                 QAMD_TRY(ops->score_all(shards[g], q->per_shard[g], dst, out_mem, w.stream));
             } else {  // the per-shard score gather over xGMI: scan locally, peer-copy 4 B/row
-                if (local_scores[g].bytes < n * 4) QAMD_TRY(local_scores[g].alloc(n * 4));
-                QAMD_TRY(ops->score_all(shards[g], q->per_shard[g], local_scores[g].template as<float>(), QAMD_MEM_DEVICE,
-                                        w.stream));
-                QAMD_HIP(hipMemcpyAsync(dst, local_scores[g].ptr, n * 4, hipMemcpyDefault, w.stream));
+                DevBuf &local = slot->local_scores[g];
+                if (local.bytes < n * 4) QAMD_TRY(local.alloc(n * 4));
+                QAMD_TRY(ops->score_all(shards[g], q->per_shard[g], local.template as<float>(), QAMD_MEM_DEVICE, w.stream));
+                QAMD_HIP(hipMemcpyAsync(dst, local.ptr, n * 4, hipMemcpyDefault, w.stream));
             }
             QAMD_HIP(hipStreamSynchronize(w.stream));
             return QAMD_OK;
         });
     }
 
-    qamd_status ensure_exchange(uint32_t Q, uint32_t k) {
+    qamd_status ensure_exchange(CallSlot &sl, uint32_t Q, uint32_t k) {
         const size_t need = (size_t)G() * Q * k * 8, res = (size_t)Q * k * 8;
-        if (gather_cap < need) {
-            QAMD_TRY(gather.alloc(need + need / 4));
-            gather_cap = need + need / 4;
+        if (sl.gather_cap < need) {
+            QAMD_TRY(sl.gather.alloc(need + need / 4));
+            sl.gather_cap = need + need / 4;
         }
-        if (result_cap < res) {
-            QAMD_TRY(result.alloc(res + res / 4));
-            result_cap = res + res / 4;
+        if (sl.result_cap < res) {
+            QAMD_TRY(sl.result.alloc(res + res / 4));
+            sl.result_cap = res + res / 4;
         }
         return QAMD_OK;
     }
 
     // Runs the merge of [G][Q][k] gathered pairs on devices[0] and delivers [Q][k] ids / scores.
-    qamd_status merge_and_deliver(uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
+    qamd_status merge_and_deliver(CallSlot &sl, uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
                                   qamd_mem out_mem) {
         const uint32_t N = pow2_at_least(G() * k);
         if ((size_t)N * 8 > 64 * 1024) return fail(QAMD_ERR_ARGUMENTS, "shards x k = %u exceeds 8192 merge slots", G() * k);
-        const uint32_t *g_ids = gather.as<uint32_t>();
+        const uint32_t *g_ids = sl.gather.as<uint32_t>();
         const float *g_sc = reinterpret_cast<const float *>(g_ids + (size_t)G() * Q * k);
         const HostScratch hs = (out_mem == QAMD_MEM_HOST && Q == 1) ? host_scratch() : HostScratch{};
-        uint32_t *ids_dev = out_mem == QAMD_MEM_DEVICE ? out_ids : hs.host ? hs.dev : result.as<uint32_t>();
+        uint32_t *ids_dev = out_mem == QAMD_MEM_DEVICE ? out_ids : hs.host ? hs.dev : sl.result.as<uint32_t>();
         float *sc_dev = out_mem == QAMD_MEM_DEVICE ? out_scores
                         : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
-                                                : reinterpret_cast<float *>(result.as<uint32_t>() + (size_t)Q * k);
-        hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(1024), (size_t)N * 8, root_stream, g_ids, g_sc,
+                                                : reinterpret_cast<float *>(sl.result.as<uint32_t>() + (size_t)Q * k);
+        hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(1024), (size_t)N * 8, sl.root_stream, g_ids, g_sc,
                            (uint64_t)Q * k, bases_dev.as<uint64_t>(), G(), Q, k, largest, N, ids_dev, sc_dev);
         QAMD_HIP(hipGetLastError());
         if (out_mem == QAMD_MEM_HOST && !hs.host) {
-            QAMD_HIP(hipMemcpyAsync(out_ids, ids_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, root_stream));
-            QAMD_HIP(hipMemcpyAsync(out_scores, sc_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, root_stream));
+            QAMD_HIP(hipMemcpyAsync(out_ids, ids_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, sl.root_stream));
+            QAMD_HIP(hipMemcpyAsync(out_scores, sc_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, sl.root_stream));
         }
-        QAMD_HIP(hipStreamSynchronize(root_stream));
+        QAMD_HIP(hipStreamSynchronize(sl.root_stream));
         if (hs.host) {
             memcpy(out_ids, hs.host, (size_t)k * 4);
             memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
@@ -415,18 +559,21 @@ template <class H, class Qy> struct Sharded {
     }
 
     // Shard g's [Q][k] pairs -> slot g of the gather buffer on devices[0] (after the shard's top-k).
-    // `fn` runs the shard's own top-k with device outputs (ids, scores) on the worker's stream.
+    // `fn` runs the shard's own top-k with device outputs (ids, scores) on the lane's stream.
     qamd_status topk_common(uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem,
+                            void *stream,
                             const std::function<qamd_status(uint32_t, Worker &, uint32_t *, float *)> &fn) {
         if (k == 0 || Q == 0) return QAMD_OK;
         if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
         if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
         if (out_mem == QAMD_MEM_DEVICE && device_of(out_ids) != root())
             return fail(QAMD_ERR_ARGUMENTS, "device outputs of a sharded top-k must live on devices[0] (%d)", root());
-        std::lock_guard<std::mutex> lk(pool.call);
+        QAMD_TRY(order_after_caller(out_mem, out_ids, stream));
+        Lease slot;
+        QAMD_TRY(lease(slot));
         QAMD_ON_DEVICE(root());
-        QAMD_TRY(ensure_exchange(Q, k));
-        uint32_t *g_ids = gather.as<uint32_t>();
+        QAMD_TRY(ensure_exchange(*slot.slot, Q, k));
+        uint32_t *g_ids = slot->gather.template as<uint32_t>();
         float *g_sc = reinterpret_cast<float *>(g_ids + (size_t)G() * Q * k);
         const size_t per = (size_t)Q * k;
         QAMD_TRY(pool.run([&](uint32_t g, Worker &w) -> qamd_status {
@@ -435,8 +582,9 @@ template <class H, class Qy> struct Sharded {
             if (w.device == root()) {  // same GPU: the shard's top-k writes its slot directly
                 QAMD_TRY(fn(g, w, slot_ids, slot_sc));
             } else {  // k pairs per query over xGMI
-                if (local_pairs[g].bytes < per * 8) QAMD_TRY(local_pairs[g].alloc(per * 8));
-                uint32_t *l_ids = local_pairs[g].template as<uint32_t>();
+                DevBuf &local = slot->local_pairs[g];
+                if (local.bytes < per * 8) QAMD_TRY(local.alloc(per * 8));
+                uint32_t *l_ids = local.template as<uint32_t>();
                 float *l_sc = reinterpret_cast<float *>(l_ids + per);
                 QAMD_TRY(fn(g, w, l_ids, l_sc));
                 QAMD_HIP(hipMemcpyAsync(slot_ids, l_ids, per * 4, hipMemcpyDefault, w.stream));
@@ -445,13 +593,13 @@ template <class H, class Qy> struct Sharded {
             QAMD_HIP(hipStreamSynchronize(w.stream));
             return QAMD_OK;
         }));
-        return merge_and_deliver(Q, k, largest, out_ids, out_scores, out_mem);
+        return merge_and_deliver(*slot.slot, Q, k, largest, out_ids, out_scores, out_mem);
     }
 
     qamd_status topk(const ShardedQuery<H, Qy> *q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
-                     qamd_mem out_mem) {
+                     qamd_mem out_mem, void *stream) {
         QAMD_TRY(check(q));
-        return topk_common(1, k, largest, out_ids, out_scores, out_mem,
+        return topk_common(1, k, largest, out_ids, out_scores, out_mem, stream,
                            [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
                                return ops->topk(shards[g], q->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE, w.stream);
                            });
@@ -518,17 +666,20 @@ template <class B> struct ShardedBatch {
 
 template <class S, class B, class EncodeFn>
 qamd_status sharded_encode_query_batch(S *h, const float *queries, uint64_t n_queries, uint64_t qdim, qamd_mem queries_mem,
-                                       ShardedBatch<B> *b, EncodeFn encode) {
+                                       void *stream, ShardedBatch<B> *b, EncodeFn encode) {
     if (b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "batch belongs to another sharded store");
     const int src_dev = queries_mem == QAMD_MEM_DEVICE ? device_of(queries) : -1;
     const size_t bytes = (size_t)n_queries * qdim * 4;
-    std::lock_guard<std::mutex> lk(h->pool.call);
+    QAMD_TRY(order_after_caller(queries_mem, queries, stream));
+    typename S::Lease slot;
+    QAMD_TRY(h->lease(slot));
     QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
         const float *src = queries;
         if (queries_mem == QAMD_MEM_DEVICE && src_dev != w.device && bytes) {  // device queries live on ONE GPU
-            if (h->query_stage[g].bytes < bytes) QAMD_TRY(h->query_stage[g].alloc(bytes));
-            QAMD_HIP(hipMemcpyAsync(h->query_stage[g].ptr, queries, bytes, hipMemcpyDefault, w.stream));
-            src = h->query_stage[g].template as<float>();
+            DevBuf &stage = slot->query_stage[g];
+            if (stage.bytes < bytes) QAMD_TRY(stage.alloc(bytes));
+            QAMD_HIP(hipMemcpyAsync(stage.ptr, queries, bytes, hipMemcpyDefault, w.stream));
+            src = stage.template as<float>();
         }
         QAMD_TRY(encode(h->shards[g], src, n_queries, qdim, queries_mem, w.stream, &b->per_shard[g]));
         QAMD_HIP(hipStreamSynchronize(w.stream));
@@ -581,12 +732,14 @@ qamd_status qamd_topk_merge(const uint32_t *ids_dev, const float *scores_dev, ui
 // ===================================================================================== u8
 qamd_status qamd_u8_sharded_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
                                    const float *quantile, const float *alpha_offset, qamd_stop_fn stop, void *stop_user,
-                                   const int *devices, uint32_t n_shards, qamd_u8_sharded **out) {
+                                   const int *devices, uint32_t n_shards, void *stream,
+                                   qamd_u8_sharded **out) {
     if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
     std::unique_ptr<qamd_u8_sharded> h(new qamd_u8_sharded);
     h->ops = &kU8Ops;
     QAMD_TRY(h->init(devices, n_shards, vp->count));
+    QAMD_TRY(order_after_caller(data_mem, data, stream));
     const uint64_t dim = vp->dim;
     float ao[2] = {0.0f, 0.0f};
     if (alpha_offset) {
@@ -649,12 +802,14 @@ qamd_status qamd_u8_sharded_encode(const float *data, qamd_mem data_mem, const q
 }
 
 qamd_status qamd_u8_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_u8_metadata *meta,
-                                      const int *devices, uint32_t n_shards, qamd_u8_sharded **out) {
+                                      const int *devices, uint32_t n_shards, void *stream,
+                                   qamd_u8_sharded **out) {
     if (!meta || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     std::unique_ptr<qamd_u8_sharded> h(new qamd_u8_sharded);
     h->ops = &kU8Ops;
     h->meta = *meta;
     QAMD_TRY(h->init(devices, n_shards, meta->vector_parameters.count));
+    QAMD_TRY(order_after_caller(rows_mem, rows, stream));
     const uint64_t stride = meta->actual_dim + 4;
     QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
         qamd_u8_metadata sm = *meta;
@@ -687,8 +842,8 @@ qamd_status qamd_u8_sharded_get_metadata(const qamd_u8_sharded *h, qamd_u8_metad
     return QAMD_OK;
 }
 
-qamd_status qamd_u8_sharded_encode_query(qamd_u8_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem,
-                                         qamd_u8_sharded_query **query_io) {
+qamd_status qamd_u8_sharded_encode_query(qamd_u8_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem, void *stream,
+                                   qamd_u8_sharded_query **query_io) {
     if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     ShardedQuery<qamd_u8, qamd_u8_query> *q = *query_io;
     const bool fresh = q == nullptr;
@@ -698,7 +853,7 @@ qamd_status qamd_u8_sharded_encode_query(qamd_u8_sharded *h, const float *query,
         nq->per_shard.assign(h->G(), nullptr);
         q = nq;
     }
-    qamd_status st = h->encode_query(query, qdim, query_mem, &q);
+    qamd_status st = h->encode_query(query, qdim, query_mem, stream, &q);
     if (st != QAMD_OK) {
         if (fresh) delete static_cast<qamd_u8_sharded_query *>(q);
         return st;
@@ -709,19 +864,20 @@ qamd_status qamd_u8_sharded_encode_query(qamd_u8_sharded *h, const float *query,
 
 void qamd_u8_sharded_query_free(qamd_u8_sharded_query *q) { delete q; }
 
-qamd_status qamd_u8_sharded_score_all(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, float *out, qamd_mem out_mem) {
+qamd_status qamd_u8_sharded_score_all(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, float *out, qamd_mem out_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    return h->score_all(q, out, out_mem);
+    return h->score_all(q, out, out_mem, stream);
 }
 
 qamd_status qamd_u8_sharded_topk(qamd_u8_sharded *h, const qamd_u8_sharded_query *q, uint32_t k, int largest,
-                                 uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+                                 uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+    return h->topk(q, k, largest, out_ids, out_scores, out_mem, stream);
 }
 
 qamd_status qamd_u8_sharded_encode_query_batch(qamd_u8_sharded *h, const float *queries, uint64_t n_queries, uint64_t qdim,
-                                               qamd_mem queries_mem, qamd_u8_sharded_query_batch **batch_io) {
+                                               qamd_mem queries_mem, void *stream,
+                                   qamd_u8_sharded_query_batch **batch_io) {
     if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     std::unique_ptr<qamd_u8_sharded_query_batch> fresh;
     qamd_u8_sharded_query_batch *b = *batch_io;
@@ -731,7 +887,7 @@ qamd_status qamd_u8_sharded_encode_query_batch(qamd_u8_sharded *h, const float *
         b->per_shard.assign(h->G(), nullptr);
         b->free_fn = qamd_u8_query_batch_free;
     }
-    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, b, qamd_u8_encode_query_batch));
+    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, stream, b, qamd_u8_encode_query_batch));
     if (fresh) *batch_io = fresh.release();
     return QAMD_OK;
 }
@@ -739,9 +895,9 @@ qamd_status qamd_u8_sharded_encode_query_batch(qamd_u8_sharded *h, const float *
 void qamd_u8_sharded_query_batch_free(qamd_u8_sharded_query_batch *b) { delete b; }
 
 qamd_status qamd_u8_sharded_topk_batch(qamd_u8_sharded *h, const qamd_u8_sharded_query_batch *b, uint32_t k, int largest,
-                                       uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+                                       uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
     if (!h || !b || b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "null or foreign argument");
-    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem,
+    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, stream,
                           [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
                               return qamd_u8_topk_batch(h->shards[g], b->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE,
                                                         w.stream);
@@ -753,7 +909,8 @@ void qamd_u8_sharded_free(qamd_u8_sharded *h) { delete h; }
 // ===================================================================================== binary
 qamd_status qamd_bin_sharded_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
                                     qamd_bits_store store, qamd_stop_fn stop, void *stop_user, const int *devices,
-                                    uint32_t n_shards, qamd_bin_sharded **out) {
+                                    uint32_t n_shards, void *stream,
+                                   qamd_bin_sharded **out) {
     if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
     std::unique_ptr<qamd_bin_sharded> h(new qamd_bin_sharded);
@@ -761,6 +918,7 @@ qamd_status qamd_bin_sharded_encode(const float *data, qamd_mem data_mem, const 
     h->vp = *vp;
     h->store = store;
     QAMD_TRY(h->init(devices, n_shards, vp->count));
+    QAMD_TRY(order_after_caller(data_mem, data, stream));
     QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
         qamd_vector_parameters svp = *vp;
         svp.count = h->base[g + 1] - h->base[g];
@@ -779,14 +937,15 @@ qamd_status qamd_bin_sharded_encode(const float *data, qamd_mem data_mem, const 
 }
 
 qamd_status qamd_bin_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_vector_parameters *vp,
-                                       qamd_bits_store store, const int *devices, uint32_t n_shards,
-                                       qamd_bin_sharded **out) {
+                                       qamd_bits_store store, const int *devices, uint32_t n_shards, void *stream,
+                                   qamd_bin_sharded **out) {
     if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     std::unique_ptr<qamd_bin_sharded> h(new qamd_bin_sharded);
     h->ops = &kBinOps;
     h->vp = *vp;
     h->store = store;
     QAMD_TRY(h->init(devices, n_shards, vp->count));
+    QAMD_TRY(order_after_caller(rows_mem, rows, stream));
     const uint64_t stride = qamd_bin_quantized_vector_size(vp, store);
     QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
         qamd_vector_parameters svp = *vp;
@@ -813,8 +972,8 @@ qamd_status qamd_bin_sharded_shard(const qamd_bin_sharded *h, uint32_t g, const 
     return QAMD_OK;
 }
 
-qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem,
-                                          qamd_bin_sharded_query **query_io) {
+qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem, void *stream,
+                                   qamd_bin_sharded_query **query_io) {
     if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     ShardedQuery<qamd_bin, qamd_bin_query> *q = *query_io;
     const bool fresh = q == nullptr;
@@ -824,7 +983,7 @@ qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *quer
         nq->per_shard.assign(h->G(), nullptr);
         q = nq;
     }
-    qamd_status st = h->encode_query(query, qdim, query_mem, &q);
+    qamd_status st = h->encode_query(query, qdim, query_mem, stream, &q);
     if (st != QAMD_OK) {
         if (fresh) delete static_cast<qamd_bin_sharded_query *>(q);
         return st;
@@ -836,20 +995,20 @@ qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *quer
 void qamd_bin_sharded_query_free(qamd_bin_sharded_query *q) { delete q; }
 
 qamd_status qamd_bin_sharded_score_all(qamd_bin_sharded *h, const qamd_bin_sharded_query *q, float *out,
-                                       qamd_mem out_mem) {
+                                       qamd_mem out_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    return h->score_all(q, out, out_mem);
+    return h->score_all(q, out, out_mem, stream);
 }
 
 qamd_status qamd_bin_sharded_topk(qamd_bin_sharded *h, const qamd_bin_sharded_query *q, uint32_t k, int largest,
-                                  uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+                                  uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+    return h->topk(q, k, largest, out_ids, out_scores, out_mem, stream);
 }
 
 qamd_status qamd_bin_sharded_encode_query_batch(qamd_bin_sharded *h, const float *queries, uint64_t n_queries,
-                                                uint64_t qdim, qamd_mem queries_mem,
-                                                qamd_bin_sharded_query_batch **batch_io) {
+                                                uint64_t qdim, qamd_mem queries_mem, void *stream,
+                                   qamd_bin_sharded_query_batch **batch_io) {
     if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     std::unique_ptr<qamd_bin_sharded_query_batch> fresh;
     qamd_bin_sharded_query_batch *b = *batch_io;
@@ -859,7 +1018,7 @@ qamd_status qamd_bin_sharded_encode_query_batch(qamd_bin_sharded *h, const float
         b->per_shard.assign(h->G(), nullptr);
         b->free_fn = qamd_bin_query_batch_free;
     }
-    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, b, qamd_bin_encode_query_batch));
+    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, stream, b, qamd_bin_encode_query_batch));
     if (fresh) *batch_io = fresh.release();
     return QAMD_OK;
 }
@@ -867,9 +1026,9 @@ qamd_status qamd_bin_sharded_encode_query_batch(qamd_bin_sharded *h, const float
 void qamd_bin_sharded_query_batch_free(qamd_bin_sharded_query_batch *b) { delete b; }
 
 qamd_status qamd_bin_sharded_topk_batch(qamd_bin_sharded *h, const qamd_bin_sharded_query_batch *b, uint32_t k, int largest,
-                                        uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+                                        uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
     if (!h || !b || b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "null or foreign argument");
-    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem,
+    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, stream,
                           [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
                               return qamd_bin_topk_batch(h->shards[g], b->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE,
                                                          w.stream);
@@ -881,7 +1040,7 @@ void qamd_bin_sharded_free(qamd_bin_sharded *h) { delete h; }
 // ===================================================================================== PQ
 qamd_status qamd_pq_sharded_encode(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
                                    uint64_t chunk_size, const float *centroids, uint32_t max_kmeans_threads,
-                                   qamd_stop_fn stop, void *stop_user, const int *devices, uint32_t n_shards,
+                                   qamd_stop_fn stop, void *stop_user, const int *devices, uint32_t n_shards, void *stream,
                                    qamd_pq_sharded **out) {
     if (!vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
@@ -891,6 +1050,7 @@ qamd_status qamd_pq_sharded_encode(const float *data, qamd_mem data_mem, const q
     h->vp = *vp;
     h->chunk_size = chunk_size;
     QAMD_TRY(h->init(devices, n_shards, vp->count));
+    QAMD_TRY(order_after_caller(data_mem, data, stream));
     if (centroids) {
         h->centroids.assign(centroids, centroids + (size_t)QAMD_PQ_CENTROIDS * vp->dim);
     } else {  // find_centroids (:278-342) once, on the device that holds the data (or devices[0])
@@ -918,8 +1078,8 @@ qamd_status qamd_pq_sharded_encode(const float *data, qamd_mem data_mem, const q
 }
 
 qamd_status qamd_pq_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd_vector_parameters *vp,
-                                      uint64_t chunk_size, const float *centroids, const int *devices, uint32_t n_shards,
-                                      qamd_pq_sharded **out) {
+                                      uint64_t chunk_size, const float *centroids, const int *devices, uint32_t n_shards, void *stream,
+                                   qamd_pq_sharded **out) {
     if (!vp || !out || !centroids) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
     std::unique_ptr<qamd_pq_sharded> h(new qamd_pq_sharded);
@@ -928,6 +1088,7 @@ qamd_status qamd_pq_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, co
     h->chunk_size = chunk_size;
     h->centroids.assign(centroids, centroids + (size_t)QAMD_PQ_CENTROIDS * vp->dim);
     QAMD_TRY(h->init(devices, n_shards, vp->count));
+    QAMD_TRY(order_after_caller(rows_mem, rows, stream));
     const uint64_t stride = qamd_pq_quantized_vector_size(vp, chunk_size);
     QAMD_TRY(h->pool.run([&](uint32_t g, Worker &w) -> qamd_status {
         qamd_vector_parameters svp = *vp;
@@ -961,8 +1122,8 @@ qamd_status qamd_pq_sharded_get_centroids(const qamd_pq_sharded *h, float *centr
     return QAMD_OK;
 }
 
-qamd_status qamd_pq_sharded_encode_query(qamd_pq_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem,
-                                         qamd_pq_sharded_query **query_io) {
+qamd_status qamd_pq_sharded_encode_query(qamd_pq_sharded *h, const float *query, uint64_t qdim, qamd_mem query_mem, void *stream,
+                                   qamd_pq_sharded_query **query_io) {
     if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     ShardedQuery<qamd_pq, qamd_pq_query> *q = *query_io;
     const bool fresh = q == nullptr;
@@ -972,7 +1133,7 @@ qamd_status qamd_pq_sharded_encode_query(qamd_pq_sharded *h, const float *query,
         nq->per_shard.assign(h->G(), nullptr);
         q = nq;
     }
-    qamd_status st = h->encode_query(query, qdim, query_mem, &q);
+    qamd_status st = h->encode_query(query, qdim, query_mem, stream, &q);
     if (st != QAMD_OK) {
         if (fresh) delete static_cast<qamd_pq_sharded_query *>(q);
         return st;
@@ -983,19 +1144,20 @@ qamd_status qamd_pq_sharded_encode_query(qamd_pq_sharded *h, const float *query,
 
 void qamd_pq_sharded_query_free(qamd_pq_sharded_query *q) { delete q; }
 
-qamd_status qamd_pq_sharded_score_all(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, float *out, qamd_mem out_mem) {
+qamd_status qamd_pq_sharded_score_all(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, float *out, qamd_mem out_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    return h->score_all(q, out, out_mem);
+    return h->score_all(q, out, out_mem, stream);
 }
 
 qamd_status qamd_pq_sharded_topk(qamd_pq_sharded *h, const qamd_pq_sharded_query *q, uint32_t k, int largest,
-                                 uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+                                 uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    return h->topk(q, k, largest, out_ids, out_scores, out_mem);
+    return h->topk(q, k, largest, out_ids, out_scores, out_mem, stream);
 }
 
 qamd_status qamd_pq_sharded_encode_query_batch(qamd_pq_sharded *h, const float *queries, uint64_t n_queries, uint64_t qdim,
-                                               qamd_mem queries_mem, qamd_pq_sharded_query_batch **batch_io) {
+                                               qamd_mem queries_mem, void *stream,
+                                   qamd_pq_sharded_query_batch **batch_io) {
     if (!h || !batch_io || (!queries && n_queries && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     std::unique_ptr<qamd_pq_sharded_query_batch> fresh;
     qamd_pq_sharded_query_batch *b = *batch_io;
@@ -1005,7 +1167,7 @@ qamd_status qamd_pq_sharded_encode_query_batch(qamd_pq_sharded *h, const float *
         b->per_shard.assign(h->G(), nullptr);
         b->free_fn = qamd_pq_query_batch_free;
     }
-    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, b, qamd_pq_encode_query_batch));
+    QAMD_TRY(sharded_encode_query_batch(h, queries, n_queries, qdim, queries_mem, stream, b, qamd_pq_encode_query_batch));
     if (fresh) *batch_io = fresh.release();
     return QAMD_OK;
 }
@@ -1013,9 +1175,9 @@ qamd_status qamd_pq_sharded_encode_query_batch(qamd_pq_sharded *h, const float *
 void qamd_pq_sharded_query_batch_free(qamd_pq_sharded_query_batch *b) { delete b; }
 
 qamd_status qamd_pq_sharded_topk_batch(qamd_pq_sharded *h, const qamd_pq_sharded_query_batch *b, uint32_t k, int largest,
-                                       uint32_t *out_ids, float *out_scores, qamd_mem out_mem) {
+                                       uint32_t *out_ids, float *out_scores, qamd_mem out_mem, void *stream) {
     if (!h || !b || b->per_shard.size() != h->G()) return fail(QAMD_ERR_ARGUMENTS, "null or foreign argument");
-    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem,
+    return h->topk_common((uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, stream,
                           [&](uint32_t g, Worker &w, uint32_t *ids, float *sc) {
                               return qamd_pq_topk_batch(h->shards[g], b->per_shard[g], k, largest, ids, sc, QAMD_MEM_DEVICE,
                                                         w.stream);

@@ -196,7 +196,7 @@ qamd_status select_kth_f32(const float *vals_dev, uint64_t n, uint64_t k, bool l
     unsigned long long prefix = 0;
     qamd_status r = hipGetLastError() == hipSuccess ? QAMD_OK : fail(QAMD_ERR_DEVICE, "select_kth launch failed");
     if (r == QAMD_OK) r = copy_out(&prefix, QAMD_MEM_HOST, &st->prefix, 8, stream);
-    thread_ws_release(WS_SELECT, stream);
+    thread_ws_release(WS_SELECT, stream, r == QAMD_OK);
     if (r != QAMD_OK) return r;
     uint32_t u = (uint32_t)(prefix >> 32);  // invert ordered_bits()
     if (largest) u = ~u;
@@ -655,7 +655,7 @@ qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint3
     qamd_status st = QAMD_OK;
     if (tags[0] != 0x5154u) {  // fresh (re)allocation: the ticket starts at zero, the last arriver keeps it there
         if (hipMemsetAsync(ws, 0, 256, stream) != hipSuccess) st = fail(QAMD_ERR_DEVICE, "top-k: ticket reset failed");
-        tags[0] = 0x5154u;
+        else tags[0] = 0x5154u;
     }
     const HostScratch hs = out_mem == QAMD_MEM_HOST ? host_scratch() : HostScratch{};
     SmallTopk p;
@@ -677,6 +677,7 @@ qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint3
                    : hs.host               ? reinterpret_cast<float *>(hs.dev + 1024)
                                            : reinterpret_cast<float *>(ws + off_out) + k;
     if (st == QAMD_OK) st = launch(p, stream);
+    if (st != QAMD_OK) tags[0] = 0;  // a launch that may not have run leaves the ticket unknown: reset it next time
     if (st == QAMD_OK && out_mem == QAMD_MEM_HOST) {
         if (hs.host) {
             // A stream synchronisation costs a 20-30 us wake-up on this runtime -- as much as the whole
@@ -692,16 +693,20 @@ qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint3
                     break;
             }
             std::atomic_thread_fence(std::memory_order_acquire);
-            if (!seen && hipStreamSynchronize(stream) != hipSuccess)
+            if (!seen && hipStreamSynchronize(stream) != hipSuccess) {
                 st = fail(QAMD_ERR_DEVICE, "top-k: stream synchronisation failed");
-            memcpy(out_ids, hs.host, (size_t)k * 4);
-            memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
+                tags[0] = 0;
+            }
+            if (st == QAMD_OK) {  // never hand back what an earlier query left in the scratch
+                memcpy(out_ids, hs.host, (size_t)k * 4);
+                memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
+            }
         } else {
             st = copy_out(out_ids, QAMD_MEM_HOST, p.out_ids, (size_t)k * 4, stream);
             if (st == QAMD_OK) st = copy_out(out_scores, QAMD_MEM_HOST, p.out_scores, (size_t)k * 4, stream);
         }
     }
-    thread_ws_release(WS_SMALL, stream);
+    thread_ws_release(WS_SMALL, stream, st == QAMD_OK && out_mem == QAMD_MEM_HOST);  // host results: the kernel has finished
     return st;
 }
 

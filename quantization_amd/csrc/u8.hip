@@ -1591,7 +1591,7 @@ qamd_status qamd_u8_score_all(const qamd_u8 *h, const qamd_u8_query *q, float *o
     QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * sizeof(float), s, reinterpret_cast<void **>(&tmp)));
     qamd_status st = scan_into(h, q, tmp, s);
     if (st == QAMD_OK) st = copy_out(out, QAMD_MEM_HOST, tmp, h->count * sizeof(float), s);
-    thread_ws_release(WS_SCORES, s);
+    thread_ws_release(WS_SCORES, s, st == QAMD_OK);  // the download synchronised the stream
     return st;
 }
 

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from .encoded_vectors import (VectorParameters, check, device_of, flatten_rows, in_buf, make_stop, out_buf,
-                              validate)
+                              stream_ptr, validate)
 from .encoded_vectors_binary import BitsStoreType, EncodedVectorsBin
 from .encoded_vectors_pq import CENTROIDS_COUNT, EncodedVectorsPQ
 from .encoded_vectors_u8 import EncodedVectorsU8
@@ -26,6 +26,21 @@ def _devices(devices):
     if not devs:
         raise ValueError("devices must name at least one GPU")
     return (C.c_int32 * len(devs))(*devs), devs
+
+
+def _caller_stream(stream, *buffers) -> C.c_void_p:
+    """The stream argument of the sharded entry points: the stream that produced the call's device
+    inputs / still uses the buffers its device outputs overwrite.  Given explicitly, or torch's current
+    stream on the device of the first CUDA tensor among `buffers` (a sharded call's tensors may live
+    on any GPU, not only the current one); the null stream otherwise."""
+    if stream is not None:
+        return stream_ptr(stream)
+    for b in buffers:
+        d = device_of(b) if b is not None else None
+        if d is not None:
+            import torch
+            return C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+    return C.c_void_p(0)
 
 
 class _ShardedQuery:
@@ -80,34 +95,36 @@ class _ShardedBase:
             if d is not None and d != self.devices[0]:
                 raise ValueError(f"device outputs of a sharded store must live on devices[0] (cuda:{self.devices[0]})")
 
-    def encode_query(self, query, reuse=None):
+    def encode_query(self, query, reuse=None, stream=None):
         buf = in_buf(query, np.float32)
         n = int(np.prod(tuple(query.shape))) if hasattr(query, "shape") else len(query)
         h = reuse._h if reuse is not None else C.c_void_p()
-        check(self._fn("encode_query")(self._h, buf.ptr, n, buf.mem, C.byref(h)))
+        check(self._fn("encode_query")(self._h, buf.ptr, n, buf.mem, _caller_stream(stream, query), C.byref(h)))
         return reuse if reuse is not None else _ShardedQuery(h, self._fn("query_free"), self)
 
-    def score_all(self, query, out=None):
+    def score_all(self, query, out=None, stream=None):
         """scores[i] = score_point(query, i) over the GLOBAL row ids — each shard writes its slice."""
         buf, ret = out_buf(out, self.count, np.float32)
-        check(self._fn("score_all")(self._h, query._h, buf.ptr, buf.mem))
+        check(self._fn("score_all")(self._h, query._h, buf.ptr, buf.mem, _caller_stream(stream, out)))
         return ret
 
-    def topk(self, query, k: int, largest: bool = True, out_ids=None, out_scores=None):
+    def topk(self, query, k: int, largest: bool = True, out_ids=None, out_scores=None, stream=None):
         """Global best-k (ids are global row ids), merged on devices[0]; same order as one handle."""
         self._check_root(out_ids, out_scores)
         ib, ids = out_buf(out_ids, k, np.uint32)
         sb, sc = out_buf(out_scores, k, np.float32)
         if ib.mem != sb.mem:
             raise ValueError("out_ids and out_scores must both be host or both be device buffers")
-        check(self._fn("topk")(self._h, query._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem))
+        check(self._fn("topk")(self._h, query._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem,
+                               _caller_stream(stream, out_ids, out_scores)))
         return ids, sc
 
-    def encode_query_batch(self, queries, reuse=None):
+    def encode_query_batch(self, queries, reuse=None, stream=None):
         nq, qdim = int(queries.shape[0]), int(queries.shape[1])
         buf = in_buf(queries, np.float32)
         h = reuse._h if reuse is not None else C.c_void_p()
-        check(self._fn("encode_query_batch")(self._h, buf.ptr, nq, qdim, buf.mem, C.byref(h)))
+        check(self._fn("encode_query_batch")(self._h, buf.ptr, nq, qdim, buf.mem, _caller_stream(stream, queries),
+                                             C.byref(h)))
         if reuse is not None:
             reuse.n_queries = nq
             return reuse
@@ -115,14 +132,15 @@ class _ShardedBase:
         b.n_queries = nq
         return b
 
-    def topk_batch(self, batch, k: int, largest: bool = True, out_ids=None, out_scores=None):
+    def topk_batch(self, batch, k: int, largest: bool = True, out_ids=None, out_scores=None, stream=None):
         nq = batch.n_queries
         self._check_root(out_ids, out_scores)
         ib, ids = out_buf(out_ids, nq * k, np.uint32)
         sb, sc = out_buf(out_scores, nq * k, np.float32)
         if ib.mem != sb.mem:
             raise ValueError("out_ids and out_scores must both be host or both be device buffers")
-        check(self._fn("topk_batch")(self._h, batch._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem))
+        check(self._fn("topk_batch")(self._h, batch._h, int(k), int(bool(largest)), ib.ptr, sb.ptr, sb.mem,
+                                     _caller_stream(stream, out_ids, out_scores)))
         if isinstance(ids, np.ndarray):
             return ids.reshape(nq, k), sc.reshape(nq, k)
         return ids, sc
@@ -141,7 +159,7 @@ class ShardedVectorsU8(_ShardedBase):
 
     @classmethod
     def encode(cls, orig_data, vector_parameters: VectorParameters, devices, quantile: float | None = None,
-               stop_condition=None, *, alpha_offset=None) -> "ShardedVectorsU8":
+               stop_condition=None, *, alpha_offset=None, stream=None) -> "ShardedVectorsU8":
         data = flatten_rows(orig_data, vector_parameters.dim)
         validate(data, vector_parameters)
         vp = vector_parameters.to_c()
@@ -152,18 +170,20 @@ class ShardedVectorsU8(_ShardedBase):
         out = C.c_void_p()
         check(_lib.lib().qamd_u8_sharded_encode(buf.ptr, buf.mem, C.byref(vp), C.byref(q) if q is not None else None,
                                                 C.cast(ao, C.POINTER(C.c_float)) if ao is not None else None,
-                                                make_stop(stop_condition), None, arr, len(devs), C.byref(out)))
+                                                make_stop(stop_condition), None, arr, len(devs),
+                                                _caller_stream(stream, data), C.byref(out)))
         return cls(out, devs, vector_parameters)
 
     @classmethod
-    def from_storage(cls, rows, metadata: dict, devices) -> "ShardedVectorsU8":
+    def from_storage(cls, rows, metadata: dict, devices, stream=None) -> "ShardedVectorsU8":
         vp = metadata["vector_parameters"]
         meta = _lib.U8MetadataC(int(metadata["actual_dim"]), float(metadata["alpha"]), float(metadata["offset"]),
                                 float(metadata["multiplier"]), vp.to_c())
         buf = in_buf(rows, np.uint8)
         arr, devs = _devices(devices)
         out = C.c_void_p()
-        check(_lib.lib().qamd_u8_sharded_from_rows(buf.ptr, buf.mem, C.byref(meta), arr, len(devs), C.byref(out)))
+        check(_lib.lib().qamd_u8_sharded_from_rows(buf.ptr, buf.mem, C.byref(meta), arr, len(devs),
+                                                   _caller_stream(stream, rows), C.byref(out)))
         return cls(out, devs, vp)
 
     @property
@@ -177,7 +197,9 @@ class ShardedVectorsU8(_ShardedBase):
     def shard(self, g: int) -> tuple[EncodedVectorsU8, int]:
         """(borrowed single-device view of shard g, its first global row).  Valid while `self` lives."""
         h, base, dev = self._shard_raw(g)
-        return EncodedVectorsU8(h, dev, owned=False), base
+        view = EncodedVectorsU8(h, dev, owned=False)
+        view._owner = self  # the shard's handle is freed with the sharded store: keep that alive
+        return view, base
 
 
 
@@ -190,7 +212,7 @@ class ShardedVectorsBin(_ShardedBase):
 
     @classmethod
     def encode(cls, orig_data, vector_parameters: VectorParameters, devices, stop_condition=None, *,
-               store: BitsStoreType = BitsStoreType.U8) -> "ShardedVectorsBin":
+               store: BitsStoreType = BitsStoreType.U8, stream=None) -> "ShardedVectorsBin":
         data = flatten_rows(orig_data, vector_parameters.dim)
         validate(data, vector_parameters)
         vp = vector_parameters.to_c()
@@ -198,25 +220,27 @@ class ShardedVectorsBin(_ShardedBase):
         arr, devs = _devices(devices)
         out = C.c_void_p()
         check(_lib.lib().qamd_bin_sharded_encode(buf.ptr, buf.mem, C.byref(vp), int(store), make_stop(stop_condition),
-                                                 None, arr, len(devs), C.byref(out)))
+                                                 None, arr, len(devs), _caller_stream(stream, data), C.byref(out)))
         return cls(out, devs, vector_parameters, store)
 
     @classmethod
     def from_storage(cls, rows, vector_parameters: VectorParameters, devices,
-                     store: BitsStoreType = BitsStoreType.U8) -> "ShardedVectorsBin":
+                     store: BitsStoreType = BitsStoreType.U8, stream=None) -> "ShardedVectorsBin":
         vp = vector_parameters.to_c()
         buf = in_buf(rows, np.uint8)
         arr, devs = _devices(devices)
         out = C.c_void_p()
         check(_lib.lib().qamd_bin_sharded_from_rows(buf.ptr, buf.mem, C.byref(vp), int(store), arr, len(devs),
-                                                    C.byref(out)))
+                                                    _caller_stream(stream, rows), C.byref(out)))
         return cls(out, devs, vector_parameters, store)
 
     def shard(self, g: int) -> tuple[EncodedVectorsBin, int]:
         h, base, dev = self._shard_raw(g)
         b, e = self.shard_range(g)
         vp = VectorParameters(self._vp.dim, e - b, self._vp.distance_type, self._vp.invert)
-        return EncodedVectorsBin(h, vp, self._store, dev, owned=False), base
+        view = EncodedVectorsBin(h, vp, self._store, dev, owned=False)
+        view._owner = self
+        return view, base
 
 
 class ShardedVectorsPQ(_ShardedBase):
@@ -228,7 +252,7 @@ class ShardedVectorsPQ(_ShardedBase):
 
     @classmethod
     def encode(cls, data, vector_parameters: VectorParameters, chunk_size: int, devices, max_kmeans_threads: int = 1,
-               stop_condition=None, *, centroids=None) -> "ShardedVectorsPQ":
+               stop_condition=None, *, centroids=None, stream=None) -> "ShardedVectorsPQ":
         data = flatten_rows(data, vector_parameters.dim)
         validate(data, vector_parameters)
         vp = vector_parameters.to_c()
@@ -243,19 +267,20 @@ class ShardedVectorsPQ(_ShardedBase):
         check(_lib.lib().qamd_pq_sharded_encode(buf.ptr, buf.mem, C.byref(vp), int(chunk_size),
                                                 C.c_void_p(cen.ctypes.data) if cen is not None else None,
                                                 int(max_kmeans_threads), make_stop(stop_condition), None, arr, len(devs),
-                                                C.byref(out)))
+                                                _caller_stream(stream, data), C.byref(out)))
         return cls(out, devs, vector_parameters, chunk_size)
 
     @classmethod
     def from_storage(cls, rows, vector_parameters: VectorParameters, chunk_size: int, centroids,
-                     devices) -> "ShardedVectorsPQ":
+                     devices, stream=None) -> "ShardedVectorsPQ":
         vp = vector_parameters.to_c()
         buf = in_buf(rows, np.uint8)
         cen = np.ascontiguousarray(centroids, dtype=np.float32)
         arr, devs = _devices(devices)
         out = C.c_void_p()
         check(_lib.lib().qamd_pq_sharded_from_rows(buf.ptr, buf.mem, C.byref(vp), int(chunk_size),
-                                                   C.c_void_p(cen.ctypes.data), arr, len(devs), C.byref(out)))
+                                                   C.c_void_p(cen.ctypes.data), arr, len(devs),
+                                                   _caller_stream(stream, rows), C.byref(out)))
         return cls(out, devs, vector_parameters, chunk_size)
 
     @property
@@ -268,4 +293,6 @@ class ShardedVectorsPQ(_ShardedBase):
         h, base, dev = self._shard_raw(g)
         b, e = self.shard_range(g)
         vp = VectorParameters(self._vp.dim, e - b, self._vp.distance_type, self._vp.invert)
-        return EncodedVectorsPQ(h, vp, self._chunk_size, dev, owned=False), base
+        view = EncodedVectorsPQ(h, vp, self._chunk_size, dev, owned=False)
+        view._owner = self
+        return view, base

@@ -112,10 +112,10 @@ int main(int argc, char **argv) {
     CHECK(qamd_u8_topk(h, q, K, 1, ids, top, QAMD_MEM_HOST, NULL));
 
     /* the same store behind a sharded handle (two logical shards on device 0) */
-    CHECK(qamd_u8_sharded_from_rows(rows, QAMD_MEM_HOST, &meta, devices, 2, &sh));
-    CHECK(qamd_u8_sharded_encode_query(sh, query, DIM, QAMD_MEM_HOST, &sq));
-    CHECK(qamd_u8_sharded_score_all(sh, sq, scores2, QAMD_MEM_HOST));
-    CHECK(qamd_u8_sharded_topk(sh, sq, K, 1, ids2, top2, QAMD_MEM_HOST));
+    CHECK(qamd_u8_sharded_from_rows(rows, QAMD_MEM_HOST, &meta, devices, 2, NULL, &sh));
+    CHECK(qamd_u8_sharded_encode_query(sh, query, DIM, QAMD_MEM_HOST, NULL, &sq));
+    CHECK(qamd_u8_sharded_score_all(sh, sq, scores2, QAMD_MEM_HOST, NULL));
+    CHECK(qamd_u8_sharded_topk(sh, sq, K, 1, ids2, top2, QAMD_MEM_HOST, NULL));
     if (memcmp(scores, scores2, sizeof(float) * COUNT) != 0 || memcmp(ids, ids2, sizeof ids) != 0 ||
         memcmp(top, top2, sizeof top) != 0) {
         fprintf(stderr, "sharded result differs from the single-handle result\n");

@@ -16,11 +16,11 @@ SRC = os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke.c")
 COUNT, DIM, K = 3000, 72, 30
 
 
-def build_program(tmp_path) -> str:
-    exe = str(tmp_path / "c_abi_smoke")
+def build_program(tmp_path, src=SRC, std="c99", extra=()) -> str:
+    exe = str(tmp_path / os.path.splitext(os.path.basename(src))[0])
     libdir = os.path.dirname(_lib.LIB_PATH)
-    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                    SRC, "-L", libdir, "-lquantization_amd", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    subprocess.run(["gcc", f"-std={std}", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    src, "-L", libdir, "-lquantization_amd", f"-Wl,-rpath,{libdir}", *extra, "-o", exe], check=True)
     return exe
 
 
@@ -68,3 +68,25 @@ def test_c_program_matches_oracle(tmp_path, qo):
     order = np.lexsort((np.arange(COUNT), -want.astype(np.float64)))[:K]
     assert [t[0] for t in top] == order.tolist()
     assert [t[1] for t in top] == want[order].view(np.uint32).tolist()
+
+
+THREADS_SRC = os.path.join(ROOT, "tests", "c_abi", "sharded_threads.c")
+
+
+def test_threaded_c_program_compiles_and_links(tmp_path):
+    build_program(tmp_path, THREADS_SRC, std="gnu99", extra=("-lpthread",))
+
+
+@pytest.mark.gpu
+def test_sharded_handle_lets_search_threads_overlap(tmp_path):
+    """Six pthreads searching one 8-shard handle (tests/c_abi/sharded_threads.c): every answer equals
+    the plain handle's, and the calls INTERLEAVE -- there is no per-handle lock: the wall time of the
+    concurrent run is under half the serial one (logical shards on one GPU, latency-bound searches)."""
+    exe = build_program(tmp_path, THREADS_SRC, std="gnu99", extra=("-lpthread",))
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    f = res.stdout.split()
+    got = {f[i]: float(f[i + 1]) for i in range(0, len(f) - 1, 2)}
+    assert got["mismatches"] == 0 and got["failures"] == 0, res.stdout
+    print(res.stdout)
+    assert got["concurrent_us"] < 0.5 * got["serial_us"], res.stdout

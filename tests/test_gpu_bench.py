@@ -102,3 +102,46 @@ def test_bench_batched_topk_mode(ranks):
     assert j["n_gpus"] == ranks and j["unit"] == "pairs/s" and j["value"] > 0
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     assert j["config"]["total_rows"] == 1200000  # strong scaling: the store is fixed, the ranks split it
+
+
+def test_bench_starts_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no rank environment: the parent (which never touches the GPU) starts the
+    two ranks as a child torch.distributed.run, relays rank 0's line and exits with the child's code.  The line
+    says what the process group was: backend, the world size torch.distributed saw, one device entry per rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--rows",
+           "200001", "--backend", "gloo", "--all-ranks-on-device", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    cfg = j["config"]
+    assert cfg["dist_backend"] == "gloo" and cfg["world_size_seen"] == 2 and len(cfg["rank_devices"]) == 2
+    assert cfg["exchange"] == "scores" and "auto" in cfg["exchange_reason"]
+    # a failing rank must fail the launcher too
+    bad = subprocess.run(cmd + ["--quantizer", "pq", "--batch-queries", "8"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=env)
+    assert bad.returncode != 0
+
+
+def test_bench_binary_multi_rank_defaults_to_the_topk_exchange():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows",
+           "400000", "--quantizer", "binary", "--dim", "1024", "--backend", "gloo", "--all-ranks-on-device", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["config"]["exchange"] == "topk" and "score gather" in j["config"]["exchange_reason"]
+
+
+@pytest.mark.parametrize("exchange", ["scores", "topk"])
+def test_bench_single_process_sharded_handle(exchange):
+    """--single-process: one process drives the shards through qamd_u8_sharded_* (two logical shards here)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "2", "--devices", "0,0",
+           "--steps", "5", "--warmup", "2", "--rows", "300001", "--exchange", exchange]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["config"]["launch"] == "single-process" and j["config"]["devices"] == [0, 0]
+    assert j["config"]["rows_per_gpu"] == 150000 and j["config"]["exchange"] == exchange
+    assert 0 < j["roofline"]["frac"] < 1.2

@@ -240,9 +240,10 @@ def test_u8_sharded_on_two_real_devices():
     _same_topk(sh.topk(qs, 30), one.topk(q1, 30))
 
 
-def test_sharded_handle_serialises_concurrent_callers():
-    """A sharded handle fans one call out at a time; callers on several threads must still each get
-    their own exact answer (the per-call exchange buffers are guarded)."""
+def test_sharded_handle_concurrent_callers_get_their_own_answers():
+    """Callers on several threads share one sharded handle with no per-handle lock (their jobs
+    interleave on the shards' queues, each call leases its own exchange buffers): every caller must
+    still get its own exact answer.  The timing side of this is tests/c_abi/sharded_threads.c."""
     import threading
 
     rng = np.random.default_rng(12)
@@ -274,3 +275,59 @@ def test_sharded_handle_serialises_concurrent_callers():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_sharded_calls_are_ordered_after_the_callers_stream(qo):
+    """The lanes run on private streams: a query (or a store) that a kernel on the caller's stream is
+    still producing must not be read early.  The producer here is a long chain of
+    element-wise kernels ending in the copy that makes the real values."""
+    rng = np.random.default_rng(21)
+    n, dim = 50_000, 128
+    data = rng.random((n, dim), dtype=np.float32)
+    vp = qa.VectorParameters(dim, n, D.Dot, False)
+    one = qa.EncodedVectorsU8.encode(data, vp)
+    sh = qa.ShardedVectorsU8.encode(data, vp, [0] * 3)
+    filler = torch.zeros(96 << 20, dtype=torch.float32, device="cuda:0")
+    side = torch.cuda.Stream()
+    for trial in range(6):
+        query = rng.random(dim, dtype=np.float32)
+        staged = torch.from_numpy(query).cuda()
+        dq = torch.full((dim,), float("nan"), device="cuda:0")
+        torch.cuda.synchronize()
+        stream = side if trial % 2 else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            for _ in range(6):
+                filler.add_(1.0)  # ~ms of queued work in front of the real values
+            dq.copy_(staged)
+            qs = sh.encode_query(dq)  # stream=None -> torch's current stream on the tensor's device
+        ids, sc = sh.topk(qs, 20)
+        wi, ws = one.topk(one.encode_query(query), 20)
+        assert np.array_equal(ids, wi), trial
+        assert_bits_equal(sc, ws, f"trial {trial}")
+    # a store encoded from a tensor that is still being written
+    src = torch.from_numpy(data).cuda()
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            filler.add_(1.0)
+        dst.copy_(src)
+        sh2 = qa.ShardedVectorsU8.encode(dst, vp, [0, 0])
+    got = np.concatenate([sh2.shard(g)[0].storage_bytes() for g in range(2)])
+    assert np.array_equal(got, one.storage_bytes())
+    torch.cuda.synchronize()
+
+
+def test_shard_view_keeps_its_sharded_store_alive():
+    import gc
+
+    rng = np.random.default_rng(22)
+    data = rng.random((4000, 32), dtype=np.float32)
+    vp = qa.VectorParameters(32, 4000, D.Dot, False)
+    view, base = qa.ShardedVectorsU8.encode(data, vp, [0, 0]).shard(1)  # the parent is dropped right here
+    gc.collect()
+    one = qa.EncodedVectorsU8.encode(data, vp)
+    assert base == 2000
+    assert np.array_equal(view.storage_bytes(), one.storage_bytes()[2000:])
+    q = rng.random(32, dtype=np.float32)
+    assert_bits_equal(view.score_all(view.encode_query(q)), one.score_all(one.encode_query(q))[2000:], "view after parent drop")
