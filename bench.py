@@ -372,7 +372,7 @@ def run_single_process(args):
                    "launch": "single-process", "devices": devices, "device_names": names, "quantizer": "u8",
                    "rows_per_gpu": n0, "dim": dim, "distance": args.distance, "exchange": exchange,
                    "exchange_reason": why, "total_rows": n_total, "queries": args.queries,
-                   "shard_lanes": int(os.environ.get("QAMD_SHARD_LANES", "2"))},
+                   "shard_lanes": int(os.environ.get("QAMD_SHARD_LANES", "3"))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "u8_scan_kernel", "kernel_ms": kern_ms,
                      "kernel_ms_min": float(np.min(kern_all)), "kernel_ms_median": float(np.median(kern_all)),

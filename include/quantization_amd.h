@@ -150,6 +150,13 @@ QAMD_API qamd_status qamd_u8_from_rows(const uint8_t *rows, qamd_mem rows_mem,
 /* The inverse: write the reference-format row bytes (count * quantized_vector_size). */
 QAMD_API qamd_status qamd_u8_export_rows(const qamd_u8 *h, uint8_t *rows, qamd_mem rows_mem,
                                          void *stream);
+/* Rows [first_row, first_row + n_rows) only: the caller-owned-storage half of encode.  The reference's
+ * encode pushes every row into the CALLER's store (storage_builder.push_vector_data,
+ * encoded_vectors_u8.rs:34-40,117; encoded_storage.rs:17-25); a binding feeds its EncodedStorageBuilder
+ * from bounded ranges (e.g. 64k rows) after encode / encoder_finish, so the store never has to exist
+ * as one host buffer.  QAMD_ERR_OUT_OF_RANGE when the range leaves [0, count]. */
+QAMD_API qamd_status qamd_u8_export_rows_range(const qamd_u8 *h, uint64_t first_row, uint64_t n_rows,
+                                               uint8_t *rows, qamd_mem rows_mem, void *stream);
 QAMD_API qamd_status qamd_u8_get_metadata(const qamd_u8 *h, qamd_u8_metadata *out);
 
 /* EncodedVectors::save / load (:263-288): raw row file + serde_json metadata file. */
@@ -170,6 +177,23 @@ QAMD_API void qamd_u8_query_free(qamd_u8_query *q);
 QAMD_API qamd_status qamd_u8_score_point(const qamd_u8 *h, const qamd_u8_query *q, uint32_t i,
                                          float *out);
 QAMD_API qamd_status qamd_u8_score_internal(const qamd_u8 *h, uint32_t i, uint32_t j, float *out);
+
+/* score_internal (:386-453) for ONE stored row against many: out[k] = score_internal(i, ids[k]) -- what
+ * graph construction asks (a new node against its candidate list), one launch instead of one per pair.
+ * Host or device ids / outputs; with device ids and outputs the call only enqueues. */
+QAMD_API qamd_status qamd_u8_score_internal_ids(const qamd_u8 *h, uint32_t i, const uint32_t *ids, uint64_t n_ids,
+                                                qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream);
+/* ... and for MANY stored rows, each against its own id list, in one launch: list l is
+ * ids[list_offsets[l] .. list_offsets[l + 1]) (list_offsets: n_lists + 1 entries from 0, n_ids =
+ * list_offsets[n_lists]); out[p] = score_internal(rows[l], ids[p]) for every p of list l.
+ * `lists_mem` says where rows, list_offsets and ids live (one kind for the three).  Host lists are
+ * validated (QAMD_ERR_OUT_OF_RANGE as score_internal) and bursts of up to ~1000 ids travel through the
+ * calling thread's mapped scratch (one launch + one synchronisation, no allocation, no copy call);
+ * device lists need a device output and only enqueue: an id or row out of range scores NaN. */
+QAMD_API qamd_status qamd_u8_score_internal_ids_batch(const qamd_u8 *h, const uint32_t *rows,
+                                                      const uint32_t *list_offsets, uint32_t n_lists,
+                                                      const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem,
+                                                      float *out, qamd_mem out_mem, void *stream);
 
 /* NEW (batched caller loop, demos/src/ann_benchmark.rs:247-252):
  * out[i] = score_point(q, i) for i in [0, count). */
@@ -202,6 +226,14 @@ QAMD_API void qamd_u8_query_batch_free(qamd_u8_query_batch *b);
 /* out[q * count + i] = score_point(query q, i): n_queries * count f32 (mind the size). */
 QAMD_API qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, float *out,
                                          qamd_mem out_mem, void *stream);
+/* score_point (:331-384) for many (query, id list) pairs in ONE launch -- one hop of every in-flight
+ * HNSW search: list l (ids[list_offsets[l] .. list_offsets[l + 1])) is scored against query l of the
+ * batch; out[p] = score_point(query l, ids[p]).  n_lists <= n_queries.  Buffers as
+ * qamd_u8_score_internal_ids_batch. */
+QAMD_API qamd_status qamd_u8_score_ids_batch(const qamd_u8 *h, const qamd_u8_query_batch *b,
+                                             const uint32_t *list_offsets, uint32_t n_lists, const uint32_t *ids,
+                                             uint64_t n_ids, qamd_mem lists_mem, float *out, qamd_mem out_mem,
+                                             void *stream);
 /* out_ids / out_scores: n_queries x k, per query as qamd_u8_topk.  Synchronises the stream. */
 QAMD_API qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, uint32_t k,
                                         int largest, uint32_t *out_ids, float *out_scores,
@@ -244,6 +276,10 @@ QAMD_API qamd_status qamd_bin_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                         void *stream, qamd_bin **out);
 QAMD_API qamd_status qamd_bin_export_rows(const qamd_bin *h, uint8_t *rows, qamd_mem rows_mem,
                                           void *stream);
+/* Ranged form (storage_builder.push_vector_data, encoded_vectors_binary.rs:165-191 via
+ * encoded_storage.rs:17-25); see qamd_u8_export_rows_range. */
+QAMD_API qamd_status qamd_bin_export_rows_range(const qamd_bin *h, uint64_t first_row, uint64_t n_rows,
+                                                uint8_t *rows, qamd_mem rows_mem, void *stream);
 QAMD_API qamd_status qamd_bin_save(const qamd_bin *h, const char *data_path, const char *meta_path);
 QAMD_API qamd_status qamd_bin_load(const char *data_path, const char *meta_path,
                                    const qamd_vector_parameters *vp, qamd_bits_store store,
@@ -259,6 +295,14 @@ QAMD_API void qamd_bin_query_free(qamd_bin_query *q);
 QAMD_API qamd_status qamd_bin_score_point(const qamd_bin *h, const qamd_bin_query *q, uint32_t i,
                                           float *out);
 QAMD_API qamd_status qamd_bin_score_internal(const qamd_bin *h, uint32_t i, uint32_t j, float *out);
+/* Bursts of pairs in one launch (score_internal :302-314 is the metric of score_point on two stored
+ * rows); arguments as qamd_u8_score_internal_ids / _ids_batch. */
+QAMD_API qamd_status qamd_bin_score_internal_ids(const qamd_bin *h, uint32_t i, const uint32_t *ids, uint64_t n_ids,
+                                                 qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_bin_score_internal_ids_batch(const qamd_bin *h, const uint32_t *rows,
+                                                       const uint32_t *list_offsets, uint32_t n_lists,
+                                                       const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem,
+                                                       float *out, qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_bin_score_all(const qamd_bin *h, const qamd_bin_query *q, float *out,
                                         qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_bin_score_ids(const qamd_bin *h, const qamd_bin_query *q,
@@ -281,6 +325,11 @@ QAMD_API void qamd_bin_query_batch_free(qamd_bin_query_batch *b);
 /* out[q * count + i] = score_point(query q, i). */
 QAMD_API qamd_status qamd_bin_score_batch(const qamd_bin *h, const qamd_bin_query_batch *b, float *out,
                                           qamd_mem out_mem, void *stream);
+/* score_point for many (query, id list) pairs in one launch; as qamd_u8_score_ids_batch. */
+QAMD_API qamd_status qamd_bin_score_ids_batch(const qamd_bin *h, const qamd_bin_query_batch *b,
+                                              const uint32_t *list_offsets, uint32_t n_lists, const uint32_t *ids,
+                                              uint64_t n_ids, qamd_mem lists_mem, float *out, qamd_mem out_mem,
+                                              void *stream);
 QAMD_API qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b, uint32_t k,
                                          int largest, uint32_t *out_ids, float *out_scores,
                                          qamd_mem out_mem, void *stream);
@@ -333,6 +382,10 @@ QAMD_API qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                        const float *centroids, void *stream, qamd_pq **out);
 QAMD_API qamd_status qamd_pq_export_rows(const qamd_pq *h, uint8_t *rows, qamd_mem rows_mem,
                                          void *stream);
+/* Ranged form (storage_builder.push_vector_data, encoded_vectors_pq.rs:136-226 via
+ * encoded_storage.rs:17-25); see qamd_u8_export_rows_range. */
+QAMD_API qamd_status qamd_pq_export_rows_range(const qamd_pq *h, uint64_t first_row, uint64_t n_rows,
+                                               uint8_t *rows, qamd_mem rows_mem, void *stream);
 /* Metadata.centroids (256 x dim f32, host). */
 QAMD_API qamd_status qamd_pq_get_centroids(const qamd_pq *h, float *centroids);
 QAMD_API qamd_status qamd_pq_save(const qamd_pq *h, const char *data_path, const char *meta_path);
@@ -349,6 +402,14 @@ QAMD_API void qamd_pq_query_free(qamd_pq_query *q);
 QAMD_API qamd_status qamd_pq_score_point(const qamd_pq *h, const qamd_pq_query *q, uint32_t i,
                                          float *out);
 QAMD_API qamd_status qamd_pq_score_internal(const qamd_pq *h, uint32_t i, uint32_t j, float *out);
+/* Bursts of pairs in one launch (score_internal :566-593: both rows decoded to centroid sub-vectors, the
+ * chunk metrics summed in chunk order); arguments as qamd_u8_score_internal_ids / _ids_batch. */
+QAMD_API qamd_status qamd_pq_score_internal_ids(const qamd_pq *h, uint32_t i, const uint32_t *ids, uint64_t n_ids,
+                                                qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream);
+QAMD_API qamd_status qamd_pq_score_internal_ids_batch(const qamd_pq *h, const uint32_t *rows,
+                                                      const uint32_t *list_offsets, uint32_t n_lists,
+                                                      const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem,
+                                                      float *out, qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_pq_score_all(const qamd_pq *h, const qamd_pq_query *q, float *out,
                                        qamd_mem out_mem, void *stream);
 QAMD_API qamd_status qamd_pq_score_ids(const qamd_pq *h, const qamd_pq_query *q,
@@ -370,6 +431,11 @@ QAMD_API qamd_status qamd_pq_encode_query_batch(const qamd_pq *h, const float *q
 QAMD_API void qamd_pq_query_batch_free(qamd_pq_query_batch *b);
 QAMD_API qamd_status qamd_pq_score_batch(const qamd_pq *h, const qamd_pq_query_batch *b, float *out,
                                          qamd_mem out_mem, void *stream);
+/* score_point for many (query, id list) pairs in one launch (LUT l for list l); as qamd_u8_score_ids_batch. */
+QAMD_API qamd_status qamd_pq_score_ids_batch(const qamd_pq *h, const qamd_pq_query_batch *b,
+                                             const uint32_t *list_offsets, uint32_t n_lists, const uint32_t *ids,
+                                             uint64_t n_ids, qamd_mem lists_mem, float *out, qamd_mem out_mem,
+                                             void *stream);
 QAMD_API qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_batch *b, uint32_t k,
                                         int largest, uint32_t *out_ids, float *out_scores,
                                         qamd_mem out_mem, void *stream);

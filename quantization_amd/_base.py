@@ -111,6 +111,47 @@ class EncodedVectorsBase:
                                     stream_ptr(stream)))
         return ret
 
+    # ------------------------------------------------------------------ bursts of pairs (the HNSW caller)
+    def score_internal_ids(self, i: int, ids, out=None, stream=None):
+        """scores[k] = score_internal(i, ids[k]): one stored row against many, one launch."""
+        check_same_device(self._device, ids, out)
+        ib = in_buf(ids, np.uint32)
+        n = int(ids.numel()) if hasattr(ids, "numel") else len(ids)
+        buf, ret = out_buf(out, n, np.float32)
+        check(self._fn("score_internal_ids")(self._h, int(i), ib.ptr, n, ib.mem, buf.ptr, buf.mem, stream_ptr(stream)))
+        return ret
+
+    def _lists(self, list_offsets, ids, rows=None):
+        bufs = [in_buf(list_offsets, np.uint32), in_buf(ids, np.uint32)] + ([in_buf(rows, np.uint32)] if rows is not None else [])
+        if len({b.mem for b in bufs}) != 1:
+            raise ValueError("list_offsets, ids and rows must all be host or all be device buffers")
+        count = lambda x: int(x.numel()) if hasattr(x, "numel") else len(x)
+        n_lists, n_ids = count(list_offsets) - 1, count(ids)
+        if rows is not None and count(rows) != n_lists:
+            raise ValueError("one row per list")
+        return bufs, n_lists, n_ids
+
+    def score_ids_batch(self, batch, list_offsets, ids, out=None, stream=None):
+        """One launch for many (query, id list) pairs - one hop of every in-flight HNSW search: list l =
+        ids[list_offsets[l]:list_offsets[l + 1]] is scored against query l of `batch`;
+        scores[p] = score_point(query l, ids[p])."""
+        check_same_device(self._device, list_offsets, ids, out)
+        (ob, ib), n_lists, n_ids = self._lists(list_offsets, ids)
+        buf, ret = out_buf(out, n_ids, np.float32)
+        check(self._fn("score_ids_batch")(self._h, batch._h, ob.ptr, n_lists, ib.ptr, n_ids, ib.mem, buf.ptr, buf.mem,
+                                          stream_ptr(stream)))
+        return ret
+
+    def score_internal_ids_batch(self, rows, list_offsets, ids, out=None, stream=None):
+        """One launch for many (stored row, id list) pairs - graph construction:
+        scores[p] = score_internal(rows[l], ids[p]) for the ids p of list l."""
+        check_same_device(self._device, rows, list_offsets, ids, out)
+        (ob, ib, rb), n_lists, n_ids = self._lists(list_offsets, ids, rows)
+        buf, ret = out_buf(out, n_ids, np.float32)
+        check(self._fn("score_internal_ids_batch")(self._h, rb.ptr, ob.ptr, n_lists, ib.ptr, n_ids, ib.mem, buf.ptr,
+                                                   buf.mem, stream_ptr(stream)))
+        return ret
+
     def topk(self, query, k: int, largest: bool = True, out_ids=None, out_scores=None, stream=None):
         """Best-k rows of the scan (demos/src/ann_benchmark_data.rs:151-167 keeps 30 in a heap),
         sorted best-first; ties go to the lower row id.  Returns (ids, scores)."""

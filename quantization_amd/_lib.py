@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         "qamd_u8_encode": (i32, [vp, i32, VP, f32p, f32p, STOP_FN, vp, vp, pp]),
         "qamd_u8_from_rows": (i32, [vp, i32, C.POINTER(U8MetadataC), vp, pp]),
         "qamd_u8_export_rows": (i32, [vp, vp, i32, vp]),
+        "qamd_u8_export_rows_range": (i32, [vp, u64, u64, vp, i32, vp]),
         "qamd_u8_get_metadata": (i32, [vp, C.POINTER(U8MetadataC)]),
         "qamd_u8_save": (i32, [vp, C.c_char_p, C.c_char_p]),
         "qamd_u8_load": (i32, [C.c_char_p, C.c_char_p, VP, pp]),
@@ -91,6 +92,9 @@ def lib() -> C.CDLL:
         "qamd_u8_score_point": (i32, [vp, vp, u32, f32p]),
         "qamd_u8_score_internal": (i32, [vp, u32, u32, f32p]),
         "qamd_u8_score_all": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_u8_score_internal_ids": (i32, [vp, u32, vp, u64, i32, vp, i32, vp]),
+        "qamd_u8_score_internal_ids_batch": (i32, [vp, vp, vp, u32, vp, u64, i32, vp, i32, vp]),
+        "qamd_u8_score_ids_batch": (i32, [vp, vp, vp, u32, vp, u64, i32, vp, i32, vp]),
         "qamd_u8_score_ids": (i32, [vp, vp, vp, u64, i32, vp, i32, vp]),
         "qamd_u8_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_u8_free": (None, [vp]),
@@ -110,6 +114,7 @@ def lib() -> C.CDLL:
         "qamd_bin_encode": (i32, [vp, i32, VP, i32, STOP_FN, vp, vp, pp]),
         "qamd_bin_from_rows": (i32, [vp, i32, VP, i32, vp, pp]),
         "qamd_bin_export_rows": (i32, [vp, vp, i32, vp]),
+        "qamd_bin_export_rows_range": (i32, [vp, u64, u64, vp, i32, vp]),
         "qamd_bin_save": (i32, [vp, C.c_char_p, C.c_char_p]),
         "qamd_bin_load": (i32, [C.c_char_p, C.c_char_p, VP, i32, pp]),
         "qamd_bin_encode_query": (i32, [vp, vp, u64, i32, vp, pp]),
@@ -118,6 +123,9 @@ def lib() -> C.CDLL:
         "qamd_bin_score_point": (i32, [vp, vp, u32, f32p]),
         "qamd_bin_score_internal": (i32, [vp, u32, u32, f32p]),
         "qamd_bin_score_all": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_bin_score_internal_ids": (i32, [vp, u32, vp, u64, i32, vp, i32, vp]),
+        "qamd_bin_score_internal_ids_batch": (i32, [vp, vp, vp, u32, vp, u64, i32, vp, i32, vp]),
+        "qamd_bin_score_ids_batch": (i32, [vp, vp, vp, u32, vp, u64, i32, vp, i32, vp]),
         "qamd_bin_score_ids": (i32, [vp, vp, vp, u64, i32, vp, i32, vp]),
         "qamd_bin_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_bin_free": (None, [vp]),
@@ -134,6 +142,7 @@ def lib() -> C.CDLL:
         "qamd_pq_encode": (i32, [vp, i32, VP, u64, vp, u32, STOP_FN, vp, vp, pp]),
         "qamd_pq_from_rows": (i32, [vp, i32, VP, u64, vp, vp, pp]),
         "qamd_pq_export_rows": (i32, [vp, vp, i32, vp]),
+        "qamd_pq_export_rows_range": (i32, [vp, u64, u64, vp, i32, vp]),
         "qamd_pq_get_centroids": (i32, [vp, vp]),
         "qamd_pq_save": (i32, [vp, C.c_char_p, C.c_char_p]),
         "qamd_pq_load": (i32, [C.c_char_p, C.c_char_p, VP, pp]),
@@ -143,6 +152,9 @@ def lib() -> C.CDLL:
         "qamd_pq_score_point": (i32, [vp, vp, u32, f32p]),
         "qamd_pq_score_internal": (i32, [vp, u32, u32, f32p]),
         "qamd_pq_score_all": (i32, [vp, vp, vp, i32, vp]),
+        "qamd_pq_score_internal_ids": (i32, [vp, u32, vp, u64, i32, vp, i32, vp]),
+        "qamd_pq_score_internal_ids_batch": (i32, [vp, vp, vp, u32, vp, u64, i32, vp, i32, vp]),
+        "qamd_pq_score_ids_batch": (i32, [vp, vp, vp, u32, vp, u64, i32, vp, i32, vp]),
         "qamd_pq_score_ids": (i32, [vp, vp, vp, u64, i32, vp, i32, vp]),
         "qamd_pq_topk": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_pq_free": (None, [vp]),

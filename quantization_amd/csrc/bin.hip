@@ -21,6 +21,7 @@
 
 #include "batch_common.hpp"
 #include "common.hpp"
+#include "lists.hpp"
 #include "multi_reduce.hpp"
 #include "topk.hpp"
 #include "topk_device.hpp"
@@ -300,6 +301,64 @@ __global__ __launch_bounds__(kBlock) void bin_words_kernel(const uint32_t *__res
     }
 }
 
+// Random access for bursts of pairs (lists.hpp): out[k] = metric(row ids[k] xor the query of pair k).
+// Which query: `lists` == nullptr -> q_single for every pair (it may be a stored row: score_internal is
+// the same metric on two stored rows, encoded_vectors_binary.rs:302-314); lists, list_rows == nullptr ->
+// bit row l of a query batch for the pairs of list l; lists and list_rows -> stored row list_rows[l].
+// VEC16 (ds % 16 == 0): 8 lanes per pair, 16-byte pieces, up to four in flight per lane; else 16 lanes
+// per pair at dword granularity (rows of 4 and 8 bytes).
+template <bool VEC16>
+__global__ __launch_bounds__(kBlock) void bin_pairs_kernel(const uint32_t *__restrict__ rows, const uint32_t *q_single,
+                                                          const uint8_t *__restrict__ q_batch, uint32_t q_stride,
+                                                          const uint32_t *__restrict__ lists, uint32_t n_lists,
+                                                          const uint32_t *__restrict__ list_rows, float dim_f, int is_dot,
+                                                          int invert, const uint32_t *__restrict__ ids, uint64_t n,
+                                                          uint32_t n_rows, uint32_t row_words, float *__restrict__ out) {
+    constexpr int G = VEC16 ? 8 : 16, RW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    for (uint64_t base = wave * RW; base < n; base += n_waves * RW) {
+        const uint64_t k = base + rslot;
+        const uint32_t row = k < n ? ids[k] : 0xFFFFFFFFu;
+        bool ok = row < n_rows;
+        const uint32_t *qp = q_single;
+        if (lists) {
+            const uint32_t l = k < n ? list_of_pair(lists, n_lists, (uint32_t)k) : 0u;
+            if (list_rows) {
+                const uint32_t qr = list_rows[l];
+                ok = ok && qr < n_rows;
+                qp = rows + (uint64_t)(qr < n_rows ? qr : 0u) * row_words;
+            } else {
+                qp = reinterpret_cast<const uint32_t *>(q_batch + (size_t)l * q_stride);
+            }
+        }
+        const uint32_t *p = rows + (uint64_t)(ok ? row : 0u) * row_words;
+        uint32_t acc = 0;
+        if (VEC16) {
+            const uint32_t chunks = row_words / 4;
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(p), *q4 = reinterpret_cast<const uint4 *>(qp);
+            for (uint32_t c0 = sub; c0 < chunks; c0 += 4 * G) {
+                uint4 v[4], qv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t c = c0 + j * G, cc = c < chunks ? c : chunks - 1;
+                    v[j] = p4[cc];
+                    qv[j] = q4[cc];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c0 + j * G < chunks) acc = xpop16(v[j], qv[j], acc);
+            }
+        } else {
+            for (uint32_t w = sub; w < row_words; w += G) acc += __popc(p[w] ^ qp[w]);
+        }
+        acc = group_sum<G>(acc);
+        if (sub == 0 && k < n) out[k] = ok ? metric(acc, dim_f, is_dot, invert) : __builtin_nanf("");
+    }
+}
+
 // encode_vector (:193-208): one wave per row, 64 elements per ballot; lane (step % 64) keeps
 // the ballot of `step`, so after <= 64 steps every lane owns 8 output bytes (coalesced store).
 __global__ __launch_bounds__(kBlock) void bin_encode_kernel(const float *__restrict__ data, uint64_t n_rows,
@@ -446,6 +505,67 @@ qamd_status words_launch(const qamd_bin *h, const uint32_t *qbits, const uint32_
     return QAMD_OK;
 }
 
+// One launch of bin_pairs_kernel (lists == nullptr: the single query bit row for every id).
+qamd_status pairs_launch(const qamd_bin *h, const uint32_t *q_single, const uint8_t *q_batch, uint64_t q_stride,
+                         const uint32_t *lists, uint32_t n_lists, const uint32_t *list_rows, const uint32_t *ids_dev,
+                         uint64_t n, float *out_dev, hipStream_t s) {
+    if (n == 0) return QAMD_OK;
+    const bool vec16 = h->ds % 16 == 0;
+    const int grid = grid_for((n + (vec16 ? 7 : 3)) / (vec16 ? 8 : 4), kBlock / 64, 8);
+#define QAMD_BIN_PAIRS(V)                                                                                          \
+    hipLaunchKernelGGL(bin_pairs_kernel<V>, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint32_t>(), q_single, q_batch, \
+                       (uint32_t)q_stride, lists, n_lists, list_rows, (float)h->vp.dim,                            \
+                       (int)(h->vp.distance_type == QAMD_DOT), h->vp.invert, ids_dev, n, (uint32_t)h->count,        \
+                       (uint32_t)(h->ds / 4), out_dev)
+    if (vec16) QAMD_BIN_PAIRS(true);
+    else QAMD_BIN_PAIRS(false);
+#undef QAMD_BIN_PAIRS
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+// out[k] = metric(query bit row `qbits`, row ids[k]) for host or device ids / outputs: the body of
+// score_ids and, with qbits = stored row i, of score_internal_ids.
+qamd_status score_ids_any(const qamd_bin *h, const uint32_t *qbits, const uint32_t *ids, uint64_t n_ids, qamd_mem ids_mem,
+                          float *out, qamd_mem out_mem, hipStream_t s) {
+    DevBuf ids_tmp, out_tmp;
+    const uint32_t *ids_dev = ids;
+    // per-pair granularity (score_point and friends): ids and results through the calling
+    // thread's mapped host scratch -- no allocation, no copy calls
+    const HostScratch hs = (ids_mem == QAMD_MEM_HOST && out_mem == QAMD_MEM_HOST && n_ids <= 1024) ? host_scratch()
+                                                                                                  : HostScratch{};
+    if (hs.host) {
+        for (uint64_t k = 0; k < n_ids; k++) {
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+            hs.host[k] = ids[k];
+        }
+        QAMD_TRY(pairs_launch(h, qbits, nullptr, 0, nullptr, 0, nullptr, hs.dev, n_ids, reinterpret_cast<float *>(hs.dev + 1024), s));
+        QAMD_HIP(hipStreamSynchronize(s));
+        memcpy(out, hs.host + 1024, n_ids * 4);
+        return QAMD_OK;
+    }
+    if (ids_mem == QAMD_MEM_HOST) {
+        for (uint64_t k = 0; k < n_ids; k++)
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+        QAMD_TRY(ids_tmp.alloc(n_ids * 4));
+        QAMD_TRY(copy_in(ids_tmp.ptr, ids, QAMD_MEM_HOST, n_ids * 4, s));
+        ids_dev = ids_tmp.as<uint32_t>();
+    }
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(out_tmp.alloc(n_ids * 4));
+        out_dev = out_tmp.as<float>();
+    }
+    QAMD_TRY(pairs_launch(h, qbits, nullptr, 0, nullptr, 0, nullptr, ids_dev, n_ids, out_dev, s));
+    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, n_ids * 4, s));
+    else if (ids_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
+    return QAMD_OK;
+}
+
 bool fused_capable(const qamd_bin *h) { return h->ds % 16 == 0 && h->ds / 16 <= 64; }
 
 qamd_status scan_bits(const qamd_bin *h, const void *qbits_dev, float *out_dev, hipStream_t s,
@@ -505,7 +625,9 @@ bool bin_topk_small(const qamd_bin *h, const void *qbits_dev, uint32_t k, int la
                     qamd_mem out_mem, hipStream_t s, qamd_status &st) {
     const int g = bin_small_group((uint32_t)(h->ds / 16));
     SmallTopkPlan plan;
-    if (!g || !fused_capable(h) || !small_topk_plan(h->count, k, 2 * (64 / g), plan)) return false;
+    if (!g || !fused_capable(h)) return false;
+    const uint32_t tile = 2 * (64 / g), least = (uint32_t)std::max<uint64_t>(16 * tile, (128 * 1024) / h->ds);
+    if (!small_topk_plan(h->count, k, tile, least, plan)) return false;
     st = small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t stt) {
         return launch_small(h, static_cast<const uint4 *>(qbits_dev), plan, p, stt);
     });
@@ -616,19 +738,32 @@ qamd_status qamd_bin_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qam
     return QAMD_OK;
 }
 
-qamd_status qamd_bin_export_rows(const qamd_bin *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+// Rows [first_row, first_row + n_rows) as the reference's storage holds them (push_vector_data,
+// encoded_storage.rs:17-25), in bounded pieces.
+qamd_status qamd_bin_export_rows_range(const qamd_bin *h, uint64_t first_row, uint64_t n_rows, uint8_t *rows,
+                                       qamd_mem rows_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    if (h->count == 0 || h->nb == 0) return QAMD_OK;
+    if (first_row > h->count || n_rows > h->count - first_row)
+        return fail(QAMD_ERR_OUT_OF_RANGE, "rows [%llu, +%llu) out of range (count %llu)", (unsigned long long)first_row,
+                    (unsigned long long)n_rows, (unsigned long long)h->count);
+    if (n_rows == 0 || h->nb == 0) return QAMD_OK;
     if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
-    if (h->nb == h->ds) return copy_out(rows, rows_mem, h->rows.ptr, h->count * h->nb, s);
-    std::vector<uint8_t> wide(h->count * h->ds), host(h->count * h->nb);
-    QAMD_TRY(copy_out(wide.data(), QAMD_MEM_HOST, h->rows.ptr, wide.size(), s));
-    for (uint64_t r = 0; r < h->count; r++) memcpy(&host[r * h->nb], &wide[r * h->ds], h->nb);
+    const uint8_t *src = h->rows.as<uint8_t>() + first_row * h->ds;
+    if (h->nb == h->ds) return copy_out(rows, rows_mem, src, n_rows * h->nb, s);
+    // rows of <= 32 dims are held at a 4-byte stride on the device: re-stride on the way out
+    std::vector<uint8_t> wide(n_rows * h->ds), host(n_rows * h->nb);
+    QAMD_TRY(copy_out(wide.data(), QAMD_MEM_HOST, src, wide.size(), s));
+    for (uint64_t r = 0; r < n_rows; r++) memcpy(&host[r * h->nb], &wide[r * h->ds], h->nb);
     if (rows_mem == QAMD_MEM_HOST) memcpy(rows, host.data(), host.size());
     else QAMD_TRY(copy_in(rows, host.data(), QAMD_MEM_HOST, host.size(), s));
     return QAMD_OK;
+}
+
+qamd_status qamd_bin_export_rows(const qamd_bin *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return qamd_bin_export_rows_range(h, 0, h->count, rows, rows_mem, stream);
 }
 
 // save/load (:260-286): Metadata{vector_parameters} as serde_json + raw row bytes.
@@ -739,67 +874,42 @@ qamd_status qamd_bin_score_ids(const qamd_bin *h, const qamd_bin_query *q, const
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
-    DevBuf ids_tmp, out_tmp;
-    const uint32_t *ids_dev = ids;
-    // per-pair granularity (score_point and friends): ids and results through the calling
-    // thread's mapped host scratch -- no allocation, no copy calls
-    const HostScratch hs = (ids_mem == QAMD_MEM_HOST && out_mem == QAMD_MEM_HOST && n_ids <= 1024) ? host_scratch()
-                                                                                                  : HostScratch{};
-    if (hs.host) {
-        for (uint64_t k = 0; k < n_ids; k++) {
-            if (ids[k] >= h->count)
-                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
-                            (unsigned long long)h->count);
-            hs.host[k] = ids[k];
-        }
-        QAMD_TRY(words_launch(h, q->buf.as<uint32_t>(), hs.dev, n_ids, reinterpret_cast<float *>(hs.dev + 1024), s));
-        QAMD_HIP(hipStreamSynchronize(s));
-        memcpy(out, hs.host + 1024, n_ids * 4);
-        return QAMD_OK;
-    }
-    if (ids_mem == QAMD_MEM_HOST) {
-        for (uint64_t k = 0; k < n_ids; k++)
-            if (ids[k] >= h->count)
-                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
-                            (unsigned long long)h->count);
-        QAMD_TRY(ids_tmp.alloc(n_ids * 4));
-        QAMD_TRY(copy_in(ids_tmp.ptr, ids, QAMD_MEM_HOST, n_ids * 4, s));
-        ids_dev = ids_tmp.as<uint32_t>();
-    }
-    float *out_dev = out;
-    if (out_mem == QAMD_MEM_HOST) {
-        QAMD_TRY(out_tmp.alloc(n_ids * 4));
-        out_dev = out_tmp.as<float>();
-    }
-    QAMD_TRY(words_launch(h, q->buf.as<uint32_t>(), ids_dev, n_ids, out_dev, s));
-    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, n_ids * 4, s));
-    else if (ids_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
-    return QAMD_OK;
+    return score_ids_any(h, q->buf.as<uint32_t>(), ids, n_ids, ids_mem, out, out_mem, s);
 }
 
 qamd_status qamd_bin_score_point(const qamd_bin *h, const qamd_bin_query *q, uint32_t i, float *out) {
     return qamd_bin_score_ids(h, q, &i, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
 }
 
+// score_internal (:302-314) for one stored row against many: out[k] = score_internal(i, ids[k]).
+qamd_status qamd_bin_score_internal_ids(const qamd_bin *h, uint32_t i, const uint32_t *ids, uint64_t n_ids,
+                                        qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (n_ids == 0) return QAMD_OK;
+    if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (i >= h->count) return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", i, (unsigned long long)h->count);
+    QAMD_ON_DEVICE(h->device);
+    return score_ids_any(h, h->rows.as<uint32_t>() + (uint64_t)i * (h->ds / 4), ids, n_ids, ids_mem, out, out_mem,
+                         as_stream(stream));
+}
+
 qamd_status qamd_bin_score_internal(const qamd_bin *h, uint32_t i, uint32_t j, float *out) {
     if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    if (i >= h->count || j >= h->count)
-        return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
+    if (j >= h->count) return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
+    return qamd_bin_score_internal_ids(h, i, &j, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
+}
+
+// Many stored rows, each against its own id list, in one launch (lists.hpp).
+qamd_status qamd_bin_score_internal_ids_batch(const qamd_bin *h, const uint32_t *rows, const uint32_t *list_offsets,
+                                              uint32_t n_lists, const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem,
+                                              float *out, qamd_mem out_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (n_lists && !rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
     QAMD_ON_DEVICE(h->device);
-    const uint32_t *qrow = h->rows.as<uint32_t>() + (uint64_t)i * (h->ds / 4);
-    const HostScratch hs = host_scratch();
-    if (hs.host) {
-        hs.host[0] = j;
-        QAMD_TRY(words_launch(h, qrow, hs.dev, 1, reinterpret_cast<float *>(hs.dev + 1024), nullptr));
-        QAMD_HIP(hipStreamSynchronize(nullptr));
-        memcpy(out, hs.host + 1024, 4);
-        return QAMD_OK;
-    }
-    DevBuf tmp;
-    QAMD_TRY(tmp.alloc(16));
-    QAMD_TRY(copy_in(tmp.ptr, &j, QAMD_MEM_HOST, 4, nullptr));
-    QAMD_TRY(words_launch(h, qrow, tmp.as<uint32_t>(), 1, tmp.as<float>() + 1, nullptr));
-    return copy_out(out, QAMD_MEM_HOST, tmp.as<float>() + 1, 4, nullptr);
+    hipStream_t s = as_stream(stream);
+    return run_lists(list_offsets, n_lists, ids, n_ids, rows, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
+        return pairs_launch(h, nullptr, nullptr, 0, a.offsets, a.n_lists, a.rows, a.ids, a.n_pairs, a.out, s);
+    });
 }
 
 qamd_status qamd_bin_topk(const qamd_bin *h, const qamd_bin_query *q, uint32_t k, int largest, uint32_t *out_ids,
@@ -1287,6 +1397,21 @@ static qamd_status bin_check_batch(const qamd_bin *h, const qamd_bin_query_batch
         return fail(QAMD_ERR_ARGUMENTS, "queries have %llu bytes, rows have %llu", (unsigned long long)b->nb,
                     (unsigned long long)h->nb);
     return QAMD_OK;
+}
+
+// Many (query, id list) pairs in one launch (lists.hpp): out[p] = score_point(query l, ids[p]).
+qamd_status qamd_bin_score_ids_batch(const qamd_bin *h, const qamd_bin_query_batch *b, const uint32_t *list_offsets,
+                                     uint32_t n_lists, const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem, float *out,
+                                     qamd_mem out_mem, void *stream) {
+    QAMD_TRY(bin_check_batch(h, b));
+    if (n_lists > b->n_queries)
+        return fail(QAMD_ERR_ARGUMENTS, "%u lists, but the batch holds %llu queries", n_lists, (unsigned long long)b->n_queries);
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    return run_lists(list_offsets, n_lists, ids, n_ids, nullptr, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
+        return pairs_launch(h, nullptr, b->bits.as<uint8_t>(), b->q_stride, a.offsets, a.n_lists, nullptr, a.ids, a.n_pairs,
+                            a.out, s);
+    });
 }
 
 qamd_status qamd_bin_score_batch(const qamd_bin *h, const qamd_bin_query_batch *b, float *out, qamd_mem out_mem,

@@ -201,7 +201,17 @@ bool ReadyEvent::complete() const {
 }
 
 qamd_status ReadyEvent::wait(hipStream_t consumer) const {
-    if (set && consumer != stream) QAMD_HIP(hipStreamWaitEvent(consumer, ev, 0));
+    if (!set || consumer == stream) return QAMD_OK;
+    // usually the encode finished long ago: a query of the event (~1 us) instead of a wait command on
+    // the consumer's stream (~5 us of host time on this runtime).  Not while the consumer's stream is
+    // being captured: hipEventQuery is not a capturable call (it would invalidate the capture).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(consumer, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap == hipStreamCaptureStatusNone) {
+        if (hipEventQuery(ev) == hipSuccess) return QAMD_OK;
+        (void)hipGetLastError();
+    }
+    QAMD_HIP(hipStreamWaitEvent(consumer, ev, 0));
     return QAMD_OK;
 }
 
@@ -381,7 +391,9 @@ qamd_status thread_ws_acquire(ThreadWsSlot slot, size_t bytes, hipStream_t s, vo
         QAMD_HIP(hipMalloc(&w.ptr, want));
         w.bytes = want;
     }
-    if (w.in_flight) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (w.in_flight && hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+    if (w.in_flight && cap == hipStreamCaptureStatusNone) {  // (a capture records, it does not run: see above)
         const hipError_t q = hipEventQuery(w.done);
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "lists.hpp"
 #include "topk.hpp"
 #include "topk_device.hpp"
 
@@ -483,6 +484,111 @@ __global__ void pq_internal_kernel(const uint8_t *__restrict__ rows, uint32_t ro
     *out = invert ? -total : total;
 }
 
+// score_point for bursts of (query, id) pairs (lists.hpp): the pairs of list l are scored with LUT l of
+// a query batch, gathered through L1/L2 (a burst touches each LUT a few dozen times: staging 96 KiB
+// per workgroup would cost more than the gathers).  Four lanes per pair, lane k = the reference's SSE
+// lane k, exactly as pq_scan_kernel => the same score bits.
+template <bool VEC16>
+__global__ __launch_bounds__(kBlock) void pq_lists_kernel(const uint32_t *__restrict__ rows32,
+                                                         const float *__restrict__ luts, uint64_t lut_stride,
+                                                         const uint32_t *__restrict__ lists, uint32_t n_lists,
+                                                         const uint32_t *__restrict__ ids, uint64_t n, uint32_t n_rows,
+                                                         uint32_t m, uint32_t row_words, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int k = lane & 3, rslot = lane >> 2;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const uint32_t groups = m / 4, shift = 8 * k;
+    for (uint64_t base = wave * 16; base < n; base += n_waves * 16) {
+        const uint64_t idx = base + rslot;
+        const uint32_t row = idx < n ? ids[idx] : 0xFFFFFFFFu;
+        const bool ok = row < n_rows;
+        const uint32_t l = idx < n ? list_of_pair(lists, n_lists, (uint32_t)idx) : 0u;
+        const float *lut = luts + (size_t)l * lut_stride;
+        const float *lut_k = lut + k * kCentroids;
+        const uint32_t *p = rows32 + (uint64_t)(ok ? row : 0) * row_words;
+        float acc = 0.0f;
+        uint32_t t = 0;
+        if (VEC16) {
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
+            for (; t + 4 <= groups; t += 4) {
+                const uint4 w = p4[t >> 2];
+                const float *q = lut_k + (size_t)t * 4 * kCentroids;
+                acc += q[(w.x >> shift) & 255u];
+                acc += q[4 * kCentroids + ((w.y >> shift) & 255u)];
+                acc += q[8 * kCentroids + ((w.z >> shift) & 255u)];
+                acc += q[12 * kCentroids + ((w.w >> shift) & 255u)];
+            }
+        }
+        for (; t < groups; t++) {
+            const uint32_t w = p[t];
+            acc += lut_k[(size_t)t * 4 * kCentroids + ((w >> shift) & 255u)];
+        }
+        float a = acc + __shfl_xor(acc, 2, 64);  // (l0 + l2) + (l1 + l3)  (:430-432)
+        float sc = a + __shfl_xor(a, 1, 64);
+        if (k == 0 && idx < n) {
+            if (ok) {
+                for (uint32_t c = groups * 4; c < m; c++) {  // tail (:434-438)
+                    const uint32_t code = (p[c >> 2] >> (8 * (c & 3))) & 255u;
+                    sc += lut[(size_t)c * kCentroids + code];
+                }
+                out[idx] = sc;
+            } else {
+                out[idx] = __builtin_nanf("");
+            }
+        }
+    }
+}
+
+// score_internal (:566-593) for bursts of pairs: 16 lanes per pair.  Lane `sub` decodes chunks
+// sub, sub + 16, ... of both rows to their centroid sub-vectors and forms the chunk's metric with the
+// reference's sequential f32 loop; the chunk results are then added IN CHUNK ORDER (the reference's
+// `.sum()` over the chunk iterator), 16 at a time through the group's lanes.  Which row is the "query":
+// lists == nullptr -> single_row for every pair; else stored row list_rows[l] for the pairs of list l.
+__global__ __launch_bounds__(kBlock) void pq_internal_pairs_kernel(const uint8_t *__restrict__ rows, uint32_t row_stride,
+                                                                  uint32_t dim, uint32_t chunk_size, uint32_t m,
+                                                                  const float *__restrict__ centroids, int distance,
+                                                                  int invert, uint32_t single_row,
+                                                                  const uint32_t *__restrict__ lists, uint32_t n_lists,
+                                                                  const uint32_t *__restrict__ list_rows,
+                                                                  const uint32_t *__restrict__ ids, uint64_t n,
+                                                                  uint32_t n_rows, float *__restrict__ out) {
+    constexpr int G = 16, RW = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, rslot = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    for (uint64_t base = wave * RW; base < n; base += n_waves * RW) {
+        const uint64_t k = base + rslot;
+        const uint32_t rj = k < n ? ids[k] : 0xFFFFFFFFu;
+        uint32_t ri = single_row;
+        if (lists) ri = list_rows[k < n ? list_of_pair(lists, n_lists, (uint32_t)k) : 0u];
+        const bool ok = rj < n_rows && ri < n_rows;
+        const uint8_t *ci = rows + (size_t)(ok ? ri : 0u) * row_stride, *cj = rows + (size_t)(ok ? rj : 0u) * row_stride;
+        float total = 0.0f;
+        for (uint32_t c0 = 0; c0 < m; c0 += G) {  // wave-uniform trip count: the shuffles below are executed by all lanes
+            const uint32_t c = c0 + sub;
+            float sc = 0.0f;
+            if (c < m) {
+                const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
+                const float *a = centroids + (size_t)ci[c] * dim + lo, *b = centroids + (size_t)cj[c] * dim + lo;
+                if (distance == QAMD_DOT)
+                    for (uint32_t t = 0; t < len; t++) sc += a[t] * b[t];
+                else if (distance == QAMD_L1)
+                    for (uint32_t t = 0; t < len; t++) sc += fabsf(a[t] - b[t]);
+                else
+                    for (uint32_t t = 0; t < len; t++) sc += (a[t] - b[t]) * (a[t] - b[t]);
+            }
+#pragma unroll
+            for (int l = 0; l < G; l++) {
+                const float v = __shfl(sc, l, G);
+                if (c0 + l < m) total += v;
+            }
+        }
+        if (sub == 0 && k < n) out[k] = ok ? (invert ? -total : total) : __builtin_nanf("");
+    }
+}
+
 // Reference rows (stride m) <-> device rows (stride round_up(m,4)).
 __global__ __launch_bounds__(kBlock) void pq_restride_kernel(const uint8_t *__restrict__ src, uint32_t src_stride,
                                                             uint8_t *__restrict__ dst, uint32_t dst_stride,
@@ -781,7 +887,8 @@ bool pq_topk_small(const qamd_pq *h, const float *lut, uint32_t k, int largest, 
                    qamd_mem out_mem, hipStream_t s, qamd_status &status) {
     SmallTopkPlan plan;
     const size_t lut_bytes = (size_t)h->m * kCentroids * sizeof(float);
-    if (h->m < 1 || lut_bytes > 128 * 1024 || !small_topk_plan(h->count, k, 16, plan)) return false;
+    // every workgroup stages the whole LUT (m KiB) before its first row: worth it from ~512 rows on
+    if (h->m < 1 || lut_bytes > 128 * 1024 || !small_topk_plan(h->count, k, 16, 512, plan)) return false;
     static std::atomic<uint64_t> set_on{0};
     if (first_use_on_device(set_on)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<true>),
@@ -1069,24 +1176,36 @@ qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd
     return QAMD_OK;
 }
 
-qamd_status qamd_pq_export_rows(const qamd_pq *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+// Rows [first_row, first_row + n_rows) as the reference's storage holds them (m code bytes per row;
+// push_vector_data, encoded_storage.rs:17-25), in bounded pieces.
+qamd_status qamd_pq_export_rows_range(const qamd_pq *h, uint64_t first_row, uint64_t n_rows, uint8_t *rows,
+                                      qamd_mem rows_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    if (h->count == 0 || h->m == 0) return QAMD_OK;
+    if (first_row > h->count || n_rows > h->count - first_row)
+        return fail(QAMD_ERR_OUT_OF_RANGE, "rows [%llu, +%llu) out of range (count %llu)", (unsigned long long)first_row,
+                    (unsigned long long)n_rows, (unsigned long long)h->count);
+    if (n_rows == 0 || h->m == 0) return QAMD_OK;
     if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
-    if (h->m == h->ds) return copy_out(rows, rows_mem, h->rows.ptr, h->count * h->m, s);
+    const uint8_t *src = h->rows.as<uint8_t>() + first_row * h->ds;
+    if (h->m == h->ds) return copy_out(rows, rows_mem, src, n_rows * h->m, s);
     DevBuf stage;
     uint8_t *dst = rows;
     if (rows_mem == QAMD_MEM_HOST) {
-        QAMD_TRY(stage.alloc(h->count * h->m));
+        QAMD_TRY(stage.alloc(n_rows * h->m));
         dst = stage.as<uint8_t>();
     }
-    hipLaunchKernelGGL(pq_restride_kernel, dim3(grid_for(h->count * h->m, kBlock * 4, 8)), dim3(kBlock), 0, s,
-                       h->rows.as<uint8_t>(), (uint32_t)h->ds, dst, (uint32_t)h->m, h->count, (uint32_t)h->m);
+    hipLaunchKernelGGL(pq_restride_kernel, dim3(grid_for(n_rows * h->m, kBlock * 4, 8)), dim3(kBlock), 0, s, src,
+                       (uint32_t)h->ds, dst, (uint32_t)h->m, n_rows, (uint32_t)h->m);
     QAMD_HIP(hipGetLastError());
-    if (rows_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(rows, QAMD_MEM_HOST, dst, h->count * h->m, s));
+    if (rows_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(rows, QAMD_MEM_HOST, dst, n_rows * h->m, s));
     return QAMD_OK;
+}
+
+qamd_status qamd_pq_export_rows(const qamd_pq *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return qamd_pq_export_rows_range(h, 0, h->count, rows, rows_mem, stream);
 }
 
 qamd_status qamd_pq_get_centroids(const qamd_pq *h, float *centroids) {
@@ -1297,28 +1416,64 @@ qamd_status qamd_pq_score_point(const qamd_pq *h, const qamd_pq_query *q, uint32
     return qamd_pq_score_ids(h, q, &i, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
 }
 
+namespace {
+qamd_status internal_pairs_launch(const qamd_pq *h, uint32_t single_row, const uint32_t *lists, uint32_t n_lists,
+                                  const uint32_t *list_rows, const uint32_t *ids_dev, uint64_t n, float *out_dev,
+                                  hipStream_t s) {
+    if (n == 0) return QAMD_OK;
+    const int grid = grid_for((n + 3) / 4, kBlock / 64, 8);
+    hipLaunchKernelGGL(pq_internal_pairs_kernel, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint8_t>(), (uint32_t)h->ds,
+                       (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
+                       h->vp.distance_type, h->vp.invert, single_row, lists, n_lists, list_rows, ids_dev, n,
+                       (uint32_t)h->count, out_dev);
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+}  // namespace
+
+// score_internal (:566-593) for one stored row against many: out[k] = score_internal(i, ids[k]).
+qamd_status qamd_pq_score_internal_ids(const qamd_pq *h, uint32_t i, const uint32_t *ids, uint64_t n_ids,
+                                       qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (n_ids == 0) return QAMD_OK;
+    if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (i >= h->count) return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", i, (unsigned long long)h->count);
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    // one list of n_ids ids: the list machinery with the row passed by value (no offsets needed)
+    if (ids_mem == QAMD_MEM_DEVICE) {
+        if (out_mem == QAMD_MEM_HOST) {
+            StreamBuf res;
+            QAMD_TRY(res.alloc(n_ids * 4, s));
+            QAMD_TRY(internal_pairs_launch(h, i, nullptr, 0, nullptr, ids, n_ids, res.as<float>(), s));
+            return copy_out(out, QAMD_MEM_HOST, res.ptr, n_ids * 4, s);
+        }
+        return internal_pairs_launch(h, i, nullptr, 0, nullptr, ids, n_ids, out, s);
+    }
+    const uint32_t offs[2] = {0u, (uint32_t)n_ids};
+    if (n_ids > 0xFFFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "too many ids");
+    return run_lists(offs, 1, ids, n_ids, nullptr, QAMD_MEM_HOST, out, out_mem, h->count, s, [&](const ListArgs &a) {
+        return internal_pairs_launch(h, i, nullptr, 0, nullptr, a.ids, a.n_pairs, a.out, s);
+    });
+}
+
 qamd_status qamd_pq_score_internal(const qamd_pq *h, uint32_t i, uint32_t j, float *out) {
     if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    if (i >= h->count || j >= h->count)
-        return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
+    if (j >= h->count) return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
+    return qamd_pq_score_internal_ids(h, i, &j, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
+}
+
+// Many stored rows, each against its own id list, in one launch (lists.hpp).
+qamd_status qamd_pq_score_internal_ids_batch(const qamd_pq *h, const uint32_t *rows, const uint32_t *list_offsets,
+                                             uint32_t n_lists, const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem,
+                                             float *out, qamd_mem out_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (n_lists && !rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
     QAMD_ON_DEVICE(h->device);
-    const HostScratch hs = host_scratch();
-    DevBuf tmp;
-    float *res = hs.host ? reinterpret_cast<float *>(hs.dev + 1024) : nullptr;
-    if (!res) {
-        QAMD_TRY(tmp.alloc(16));
-        res = tmp.as<float>();
-    }
-    hipLaunchKernelGGL(pq_internal_kernel, dim3(1), dim3(64), 0, nullptr, h->rows.as<uint8_t>(), (uint32_t)h->ds,
-                       (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
-                       h->vp.distance_type, h->vp.invert, i, j, res);
-    QAMD_HIP(hipGetLastError());
-    if (hs.host) {
-        QAMD_HIP(hipStreamSynchronize(nullptr));
-        memcpy(out, hs.host + 1024, 4);
-        return QAMD_OK;
-    }
-    return copy_out(out, QAMD_MEM_HOST, tmp.ptr, 4, nullptr);
+    hipStream_t s = as_stream(stream);
+    return run_lists(list_offsets, n_lists, ids, n_ids, rows, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
+        return internal_pairs_launch(h, 0, a.offsets, a.n_lists, a.rows, a.ids, a.n_pairs, a.out, s);
+    });
 }
 
 qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, int largest, uint32_t *out_ids,
@@ -1577,6 +1732,32 @@ static qamd_status pq_check_batch(const qamd_pq *h, const qamd_pq_query_batch *b
     if (b->m != h->m) return fail(QAMD_ERR_ARGUMENTS, "query LUTs have %llu chunks, store has %llu",
                                   (unsigned long long)b->m, (unsigned long long)h->m);
     return QAMD_OK;
+}
+
+// Many (query, id list) pairs in one launch (lists.hpp): out[p] = score_point(query l, ids[p]).
+qamd_status qamd_pq_score_ids_batch(const qamd_pq *h, const qamd_pq_query_batch *b, const uint32_t *list_offsets,
+                                    uint32_t n_lists, const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem, float *out,
+                                    qamd_mem out_mem, void *stream) {
+    QAMD_TRY(pq_check_batch(h, b));
+    if (n_lists > b->n_queries)
+        return fail(QAMD_ERR_ARGUMENTS, "%u lists, but the batch holds %llu queries", n_lists, (unsigned long long)b->n_queries);
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    const size_t per = (size_t)h->m * kCentroids;
+    return run_lists(list_offsets, n_lists, ids, n_ids, nullptr, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
+        const uint32_t row_words = (uint32_t)(h->ds / 4);
+        const int grid = grid_for((a.n_pairs + 15) / 16, kBlock / 64, 8);
+        if (row_words % 4 == 0)
+            hipLaunchKernelGGL(pq_lists_kernel<true>, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint32_t>(), b->luts.as<float>(),
+                               (uint64_t)per, a.offsets, a.n_lists, a.ids, a.n_pairs, (uint32_t)h->count, (uint32_t)h->m,
+                               row_words, a.out);
+        else
+            hipLaunchKernelGGL(pq_lists_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint32_t>(), b->luts.as<float>(),
+                               (uint64_t)per, a.offsets, a.n_lists, a.ids, a.n_pairs, (uint32_t)h->count, (uint32_t)h->m,
+                               row_words, a.out);
+        QAMD_HIP(hipGetLastError());
+        return QAMD_OK;
+    });
 }
 
 qamd_status qamd_pq_score_batch(const qamd_pq *h, const qamd_pq_query_batch *b, float *out, qamd_mem out_mem,

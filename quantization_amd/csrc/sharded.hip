@@ -64,10 +64,10 @@ inline void cpu_relax() {
 constexpr int kSpinIterations = 4000;
 constexpr uint32_t kMaxLanes = 8;
 
-uint32_t lanes_per_shard() {  // QAMD_SHARD_LANES=1..8 (default 2: one job runs while the next is being enqueued)
+uint32_t lanes_per_shard() {  // QAMD_SHARD_LANES=1..8 (default 3: while one lane waits for its kernel, others enqueue)
     static const uint32_t lanes = [] {
         const char *e = getenv("QAMD_SHARD_LANES");
-        const long v = e ? strtol(e, nullptr, 10) : 2;
+        const long v = e ? strtol(e, nullptr, 10) : 3;
         return (uint32_t)(v < 1 ? 1 : v > (long)kMaxLanes ? kMaxLanes : v);
     }();
     return lanes;
@@ -322,6 +322,9 @@ template <class H, class Qy> struct Ops {
     qamd_status (*score_all)(const H *, const Qy *, float *, qamd_mem, void *);
     qamd_status (*topk)(const H *, const Qy *, uint32_t, int, uint32_t *, float *, qamd_mem, void *);
     void (*free_store)(H *);
+    // encode_query of a HOST query of this many values launches nothing (the values are kept in the query
+    // object until its first consumer, u8.hip): the sharded call then needs no fan-out either
+    bool (*host_encode_is_lazy)(uint64_t qdim);
 };
 
 template <class H, class Qy> struct ShardedQuery {
@@ -342,6 +345,23 @@ struct CallSlot {
     std::vector<DevBuf> local_pairs, local_scores, query_stage;
     bool busy = false;
 };
+
+// Waits for `s` by polling first: searches on small shards finish within tens of microseconds, less
+// than the 20-30 us wake-up latency of a blocking synchronisation on this runtime.  Every lane waits
+// for its own stream (in parallel), then the caller for the root stream.  (Tried instead: lanes only
+// record an event and the root stream waits for the G events -- hipStreamWaitEvent costs ~5 us of
+// host time per event, serially on the caller: slower from 4 shards on.)
+qamd_status wait_stream(hipStream_t s) {
+    for (int i = 0; i < 5000; i++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return QAMD_OK;
+        if (e != hipErrorNotReady) return fail(QAMD_ERR_DEVICE, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        for (int j = 0; j < 64; j++) cpu_relax();  // ~1-2 us between polls: the query takes runtime locks other threads need
+    }
+    QAMD_HIP(hipStreamSynchronize(s));
+    return QAMD_OK;
+}
 
 // The caller's stream and the buffers it hands over.  Sharded calls run on the lanes' own streams,
 // which nothing orders against the stream that PRODUCED a caller's device buffer (or that still reads
@@ -446,12 +466,13 @@ template <class H, class Qy> struct Sharded {
     ~Sharded() {
         for (H *h : shards)
             if (h) ops->free_store(h);
-        for (auto &sl : slots)
+        for (auto &sl : slots) {
             if (sl->root_stream) {
                 DeviceGuard g(root());
                 (void)hipStreamSynchronize(sl->root_stream);
                 (void)hipStreamDestroy(sl->root_stream);
             }
+        }
     }
 
     qamd_status encode_query(const float *query, uint64_t qdim, qamd_mem mem, void *stream, ShardedQuery<H, Qy> **io) {
@@ -465,6 +486,12 @@ template <class H, class Qy> struct Sharded {
         }
         if (q->per_shard.size() != G()) return fail(QAMD_ERR_ARGUMENTS, "query belongs to another sharded store");
         const int src_dev = mem == QAMD_MEM_DEVICE ? device_of(query) : -1;
+        if (mem == QAMD_MEM_HOST && ops->host_encode_is_lazy(qdim)) {  // G host-side copies, no GPU work, no lanes
+            for (uint32_t g = 0; g < G(); g++)
+                QAMD_TRY(ops->encode_query(shards[g], query, qdim, mem, nullptr, &q->per_shard[g]));
+            if (fresh) *io = fresh.release();
+            return QAMD_OK;
+        }
         QAMD_TRY(order_after_caller(mem, query, stream));
         Lease slot;
         QAMD_TRY(lease(slot));
@@ -477,8 +504,11 @@ template <class H, class Qy> struct Sharded {
                 src = stage.template as<float>();
             }
             QAMD_TRY(qamd_set_device(w.device));
+            // a host query has been copied out of the caller's buffer when encode_query returns, and the
+            // query object orders its consumers after the encode kernel (ReadyEvent): nothing to wait for
             QAMD_TRY(ops->encode_query(shards[g], src, qdim, mem, w.stream, &q->per_shard[g]));
-            QAMD_HIP(hipStreamSynchronize(w.stream));
+            // a device query: the caller's buffer and the slot's staging copy are in use until the kernel has run
+            if (mem == QAMD_MEM_DEVICE) QAMD_TRY(wait_stream(w.stream));
             return QAMD_OK;
         }));
         if (fresh) *io = fresh.release();
@@ -513,8 +543,7 @@ template <class H, class Qy> struct Sharded {
                 QAMD_TRY(ops->score_all(shards[g], q->per_shard[g], local.template as<float>(), QAMD_MEM_DEVICE, w.stream));
                 QAMD_HIP(hipMemcpyAsync(dst, local.ptr, n * 4, hipMemcpyDefault, w.stream));
             }
-            QAMD_HIP(hipStreamSynchronize(w.stream));
-            return QAMD_OK;
+            return wait_stream(w.stream);
         });
     }
 
@@ -550,7 +579,7 @@ template <class H, class Qy> struct Sharded {
             QAMD_HIP(hipMemcpyAsync(out_ids, ids_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, sl.root_stream));
             QAMD_HIP(hipMemcpyAsync(out_scores, sc_dev, (size_t)Q * k * 4, hipMemcpyDeviceToHost, sl.root_stream));
         }
-        QAMD_HIP(hipStreamSynchronize(sl.root_stream));
+        QAMD_TRY(wait_stream(sl.root_stream));
         if (hs.host) {
             memcpy(out_ids, hs.host, (size_t)k * 4);
             memcpy(out_scores, hs.host + 1024, (size_t)k * 4);
@@ -560,9 +589,27 @@ template <class H, class Qy> struct Sharded {
 
     // Shard g's [Q][k] pairs -> slot g of the gather buffer on devices[0] (after the shard's top-k).
     // `fn` runs the shard's own top-k with device outputs (ids, scores) on the lane's stream.
+#ifdef QAMD_DEV
+    static double now_us() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+    }
+#define QAMD_T(i) { const double t_ = now_us(); g_t[i] += t_ - t_last; t_last = t_; }
+#else
+#define QAMD_T(i)
+#endif
     qamd_status topk_common(uint32_t Q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem,
                             void *stream,
                             const std::function<qamd_status(uint32_t, Worker &, uint32_t *, float *)> &fn) {
+#ifdef QAMD_DEV
+        static thread_local double g_t[8] = {0};
+        static thread_local int g_n = 0;
+        double t_last = now_us();
+        if (++g_n % 300 == 0) {
+            fprintf(stderr, "topk_common phases us: lease %.1f run %.1f waits %.1f merge+sync %.1f\n", g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_t[3] / g_n);
+        }
+#endif
         if (k == 0 || Q == 0) return QAMD_OK;
         if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
         if (k > 1024) return fail(QAMD_ERR_ARGUMENTS, "topk: k=%u exceeds 1024", k);
@@ -573,6 +620,7 @@ template <class H, class Qy> struct Sharded {
         QAMD_TRY(lease(slot));
         QAMD_ON_DEVICE(root());
         QAMD_TRY(ensure_exchange(*slot.slot, Q, k));
+        QAMD_T(0)
         uint32_t *g_ids = slot->gather.template as<uint32_t>();
         float *g_sc = reinterpret_cast<float *>(g_ids + (size_t)G() * Q * k);
         const size_t per = (size_t)Q * k;
@@ -590,10 +638,13 @@ template <class H, class Qy> struct Sharded {
                 QAMD_HIP(hipMemcpyAsync(slot_ids, l_ids, per * 4, hipMemcpyDefault, w.stream));
                 QAMD_HIP(hipMemcpyAsync(slot_sc, l_sc, per * 4, hipMemcpyDefault, w.stream));
             }
-            QAMD_HIP(hipStreamSynchronize(w.stream));
-            return QAMD_OK;
+            return wait_stream(w.stream);
         }));
-        return merge_and_deliver(*slot.slot, Q, k, largest, out_ids, out_scores, out_mem);
+        QAMD_T(1)
+        QAMD_T(2)
+        const qamd_status mst = merge_and_deliver(*slot.slot, Q, k, largest, out_ids, out_scores, out_mem);
+        QAMD_T(3)
+        return mst;
     }
 
     qamd_status topk(const ShardedQuery<H, Qy> *q, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
@@ -682,19 +733,19 @@ qamd_status sharded_encode_query_batch(S *h, const float *queries, uint64_t n_qu
             src = stage.template as<float>();
         }
         QAMD_TRY(encode(h->shards[g], src, n_queries, qdim, queries_mem, w.stream, &b->per_shard[g]));
-        QAMD_HIP(hipStreamSynchronize(w.stream));
-        return QAMD_OK;
+        return wait_stream(w.stream);  // batch objects carry no ready event: finished before anyone scores with them
     }));
     b->n_queries = n_queries;
     return QAMD_OK;
 }
 
+bool never_lazy(uint64_t) { return false; }
 const Ops<qamd_u8, qamd_u8_query> kU8Ops = {qamd_u8_encode_query, qamd_u8_query_free, qamd_u8_score_all, qamd_u8_topk,
-                                            qamd_u8_free};
+                                            qamd_u8_free, u8_host_encode_is_lazy};
 const Ops<qamd_bin, qamd_bin_query> kBinOps = {qamd_bin_encode_query, qamd_bin_query_free, qamd_bin_score_all,
-                                               qamd_bin_topk, qamd_bin_free};
+                                               qamd_bin_topk, qamd_bin_free, never_lazy};
 const Ops<qamd_pq, qamd_pq_query> kPqOps = {qamd_pq_encode_query, qamd_pq_query_free, qamd_pq_score_all, qamd_pq_topk,
-                                            qamd_pq_free};
+                                            qamd_pq_free, never_lazy};
 
 }  // namespace
 

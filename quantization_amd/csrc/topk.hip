@@ -631,11 +631,16 @@ qamd_status topk_finish(const float *scores_dev, uint64_t n, uint32_t k, int lar
 }
 
 // ------------------------------------------------------------------------ single-launch top-k
-bool small_topk_plan(uint64_t n, uint32_t k, uint32_t rows_per_tile, SmallTopkPlan &plan) {
+bool small_topk_plan(uint64_t n, uint32_t k, uint32_t rows_per_tile, uint32_t min_rows_per_wg, SmallTopkPlan &plan) {
     if (n == 0 || n > (2u << 20) || k == 0 || k > kSmallTopkMaxK) return false;
     uint32_t wgs = std::min<uint32_t>((uint32_t)device_info().cu_count, 256u);  // one 16-wave workgroup per CU;
                                                                                 // <= 256: the last workgroup folds 16 lists per wave
-    wgs = (uint32_t)std::min<uint64_t>(wgs, (n + rows_per_tile - 1) / rows_per_tile);  // at least one tile each
+    // A workgroup is worth starting only for a share of the rows that keeps its 16 waves busy for a few
+    // passes (and, per caller, that outweighs what a workgroup loads before its first row): on a 10k-row
+    // store 256 workgroups of 40 rows each spend their time in the cross-workgroup fold of 256 lists, and
+    // under concurrent searches every such launch occupies every CU.
+    const uint64_t least = round_up(std::max<uint64_t>(min_rows_per_wg, rows_per_tile), rows_per_tile);
+    wgs = (uint32_t)std::min<uint64_t>(wgs, (n + least - 1) / least);
     const uint32_t per = (uint32_t)round_up((n + wgs - 1) / wgs, rows_per_tile);
     wgs = (uint32_t)((n + per - 1) / per);  // drop workgroups that would own no row
     plan.workgroups = wgs;

@@ -73,7 +73,9 @@ struct SmallTopk;
 struct SmallTopkPlan {
     uint32_t workgroups = 0, rows_per_wg = 0;
 };
-bool small_topk_plan(uint64_t n, uint32_t k, uint32_t rows_per_tile, SmallTopkPlan &plan);
+// rows_per_tile: rows one wave takes per pass; min_rows_per_wg: below this share a further workgroup is not worth its
+// start-up and its list in the final fold (callers: a few passes of the 16 waves, >= 128 KiB of row bytes).
+bool small_topk_plan(uint64_t n, uint32_t k, uint32_t rows_per_tile, uint32_t min_rows_per_wg, SmallTopkPlan &plan);
 qamd_status small_topk(const SmallTopkPlan &plan, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
                        qamd_mem out_mem, hipStream_t stream,
                        const std::function<qamd_status(const SmallTopk &, hipStream_t)> &launch);

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "lists.hpp"
 #include "multi_reduce.hpp"
 #include "topk.hpp"
 #include "topk_device.hpp"
@@ -284,27 +285,18 @@ __global__ __launch_bounds__(kScanBlock) void u8_scan_multi_kernel(
 // 64-bit key (order-preserving score bits << 32 | row) in the wave's LDS staging row, and the wave /
 // workgroup / last-arriver merges of topk_device.hpp keep the best k.  100k x 768: one launch
 // replaces the sample / pivot / filtering-scan / sort chain (66 us).
+// The body, given the query's pieces in registers (q) and its offset:
 template <int G, int ITERS, bool IS_L1, bool EXACT>
-__global__ __launch_bounds__(1024) void u8_topk_small_kernel(
-    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint4 *__restrict__ qcodes,
-    const float *__restrict__ q_off_p, float multiplier, uint32_t n_rows, uint32_t row_chunks, uint32_t rows_per_wg,
-    SmallTopk p) {
-    __shared__ unsigned long long lds[2 * kSmallTopkWaves][64];  // [0, 16): tournament lists, [16, 32): staging rows
+__device__ __forceinline__ void u8_topk_small_body(const uint4 *__restrict__ codes, const float *__restrict__ offsets,
+                                                   const uint4 (&q)[ITERS], float q_off, float multiplier, uint32_t n_rows,
+                                                   uint32_t row_chunks, uint32_t rows_per_wg, const SmallTopk &p,
+                                                   unsigned long long (*lds)[64]) {
     unsigned long long(*lists)[64] = lds;
     constexpr int RW = 64 / G;
     constexpr int UNROLL = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % G, rslot = lane / G;
     unsigned long long *stage = lds[kSmallTopkWaves + wave];
-    uint4 q[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const uint32_t c = sub + it * G;
-        const uint4 t = qcodes[(EXACT || c < row_chunks) ? c : row_chunks - 1];
-        const bool in = EXACT || c < row_chunks;
-        q[it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
-    }
-    const float q_off = *q_off_p;
     const uint64_t wg_base = (uint64_t)blockIdx.x * rows_per_wg;
     SmallTopkWave acc_list;
     for (uint32_t tile = wave * UNROLL; tile * RW < rows_per_wg; tile += kSmallTopkWaves * UNROLL) {
@@ -345,6 +337,97 @@ __global__ __launch_bounds__(1024) void u8_topk_small_kernel(
     }
     if (acc_list.fill) small_topk_flush(acc_list, stage, lane);
     small_topk_finish(acc_list.best, lists, p);
+}
+
+template <int G, int ITERS, bool IS_L1, bool EXACT>
+__global__ __launch_bounds__(1024) void u8_topk_small_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint4 *__restrict__ qcodes,
+    const float *__restrict__ q_off_p, float multiplier, uint32_t n_rows, uint32_t row_chunks, uint32_t rows_per_wg,
+    SmallTopk p) {
+    __shared__ unsigned long long lds[2 * kSmallTopkWaves][64];  // [0, 16): tournament lists, [16, 32): staging rows
+    const int lane = threadIdx.x & 63, sub = lane % G;
+    uint4 q[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t c = sub + it * G;
+        const uint4 t = qcodes[(EXACT || c < row_chunks) ? c : row_chunks - 1];
+        const bool in = EXACT || c < row_chunks;
+        q[it] = make_uint4(in ? t.x : 0, in ? t.y : 0, in ? t.z : 0, in ? t.w : 0);
+    }
+    u8_topk_small_body<G, ITERS, IS_L1, EXACT>(codes, offsets, q, *q_off_p, multiplier, n_rows, row_chunks, rows_per_wg, p, lds);
+}
+
+// encode_query FOLDED INTO the single-launch top-k: one launch per search on a small store.  The f32
+// query arrives BY VALUE in the kernel arguments (<= 896 values: the argument block is 4 KiB), so no
+// copy call, no mapped-memory read over PCIe and no second, dependent launch stands in front of the
+// scan.  Every workgroup quantises the query itself -- thread t makes dword t of the codes with the
+// encoder's own f32_to_u8 and padding (encoded_vectors_u8.rs:290-329), the code sums are exact
+// integers (127^2 * 896 < 2^24), the offset is formed in the reference's order -- keeps the codes in
+// LDS, and goes on as u8_topk_small_kernel: same codes and offset => the same score bits.  Workgroup 0
+// also leaves offset + codes in the query object's buffer, so after this launch the object is an
+// ordinary encoded query for whoever uses it next.
+constexpr uint32_t kFusedQueryDims = 896;
+struct QueryByValue {
+    float v[kFusedQueryDims];
+};
+template <int G, int ITERS, bool IS_L1, bool EXACT>
+__global__ __launch_bounds__(1024) void u8_topk_small_fused_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const QueryByValue qv, uint32_t qdim,
+    uint32_t actual_dim, float alpha, float offset, int distance, int invert, uint8_t *__restrict__ qbuf, float multiplier,
+    uint32_t n_rows, uint32_t row_chunks, uint32_t rows_per_wg, SmallTopk p) {
+    __shared__ unsigned long long lds[2 * kSmallTopkWaves][64];
+    __shared__ __attribute__((aligned(16))) uint32_t qc_lds[kFusedQueryDims / 4];
+    __shared__ uint32_t qsum[2];
+    const uint32_t t = threadIdx.x;
+    const int lane = threadIdx.x & 63, sub = lane % G;
+    if (t < 2) qsum[t] = 0;
+    __syncthreads();
+    const float placeholder = (distance == QAMD_DOT) ? 0.0f : offset;
+    const uint32_t pad_code = f32_to_u8(placeholder, alpha, offset);
+    uint32_t s1 = 0, s2 = 0;
+    if (t < actual_dim / 4) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t j = 4 * t + b;
+            const uint32_t c = j < qdim ? f32_to_u8(qv.v[j], alpha, offset) : pad_code;
+            packed |= c << (8 * b);
+            s1 += c;
+            s2 += c * c;
+        }
+        qc_lds[t] = packed;
+    }
+    if (t < 256) {  // actual_dim / 4 <= 224: the first four waves hold everything
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&qsum[0], s1);
+            atomicAdd(&qsum[1], s2);
+        }
+    }
+    __syncthreads();
+    float q_off;
+    if (distance == QAMD_DOT) q_off = (float)qsum[0] * alpha * offset;
+    else if (distance == QAMD_L1) q_off = 0.0f;
+    else q_off = (float)qsum[1] * alpha * alpha;
+    if (invert) q_off = -q_off;
+    if (blockIdx.x == 0) {  // the query object becomes an encoded query (layout: encode_query_kernel)
+        if (t == 0) *reinterpret_cast<float *>(qbuf) = q_off;
+        if (t < actual_dim / 4) reinterpret_cast<uint32_t *>(qbuf + 16)[t] = qc_lds[t];
+    }
+    uint4 q[ITERS];
+    const uint4 *qc4 = reinterpret_cast<const uint4 *>(qc_lds);
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t c = sub + it * G;
+        const uint4 v = qc4[(EXACT || c < row_chunks) ? c : row_chunks - 1];
+        const bool in = EXACT || c < row_chunks;
+        q[it] = make_uint4(in ? v.x : 0, in ? v.y : 0, in ? v.z : 0, in ? v.w : 0);
+    }
+    u8_topk_small_body<G, ITERS, IS_L1, EXACT>(codes, offsets, q, q_off, multiplier, n_rows, row_chunks, rows_per_wg, p, lds);
 }
 
 // Generic dims (row_chunks > 16*8): runtime chunk loop, query re-read through L1/L2.
@@ -416,36 +499,65 @@ __global__ __launch_bounds__(kBlock) void u8_scan_avx2_lanes_kernel(
     }
 }
 
-// Random access: out[k] = score(q, ids[k]).  One 16-lane group per id.  qcodes/q_off_p may
-// point into the store itself (score_internal: "query" = row i).
+// Random access: out[k] = score(query of pair k, ids[k]).  One 16-lane group per pair, up to four
+// 16-byte pieces of the row (and of the query) in flight per lane.  Which query a pair is scored
+// against:
+//   lists == nullptr            one query for every pair (score_ids): q_single / q_off_single, which
+//                               may point into the store itself (score_internal: "query" = row i);
+//   lists, list_rows == nullptr query l of a batch for the pairs of list l (score_ids_batch);
+//   lists, list_rows            stored row list_rows[l] for the pairs of list l (score_internal_ids_batch).
+// Same integer sum and the same f32 epilogue as the scan => the same score bits.
 template <bool IS_L1>
-__global__ __launch_bounds__(kBlock) void u8_score_ids_kernel(
-    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint4 *qcodes,
-    const float *q_off_p, float multiplier, float diff, int mode, const uint32_t *__restrict__ ids,
-    uint64_t n_ids, uint32_t n_rows, uint32_t row_chunks, float *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void u8_score_pairs_kernel(
+    const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint4 *q_single, const float *q_off_single,
+    const uint8_t *__restrict__ q_batch, uint32_t q_pitch, const float *__restrict__ q_offs,
+    const uint32_t *__restrict__ lists, uint32_t n_lists, const uint32_t *__restrict__ list_rows, float multiplier,
+    float diff, int mode, const uint32_t *__restrict__ ids, uint64_t n_ids, uint32_t n_rows, uint32_t row_chunks,
+    float *__restrict__ out) {
     constexpr int G = 16, RW = 4;
     const int lane = threadIdx.x & 63;
     const int sub = lane % G, rslot = lane / G;
     const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
-    const float q_off = *q_off_p;
     for (uint64_t base = wave * RW; base < n_ids; base += n_waves * RW) {
         const uint64_t k = base + rslot;
         const uint32_t row = k < n_ids ? ids[k] : 0xFFFFFFFFu;
-        const bool ok = row < n_rows;
+        bool ok = row < n_rows;
+        const uint4 *qp = q_single;
+        float q_off = 0.0f;
+        if (lists) {
+            const uint32_t l = k < n_ids ? list_of_pair(lists, n_lists, (uint32_t)k) : 0u;
+            if (list_rows) {
+                const uint32_t qr = list_rows[l];
+                ok = ok && qr < n_rows;
+                const uint32_t qc = qr < n_rows ? qr : 0u;
+                qp = codes + (uint64_t)qc * row_chunks;
+                q_off = offsets[qc];
+            } else {
+                qp = reinterpret_cast<const uint4 *>(q_batch + (size_t)l * q_pitch);
+                q_off = q_offs[l];
+            }
+        } else {
+            q_off = *q_off_single;
+        }
+        const uint4 *p = codes + (uint64_t)(ok ? row : 0u) * row_chunks;
         uint32_t acc = 0;
-        if (ok) {
-            const uint4 *p = codes + (uint64_t)row * row_chunks;
-            for (uint32_t c = sub; c < row_chunks; c += G) {
-                uint4 v = p[c];
-                uint4 qv = qcodes[c];
-                acc = IS_L1 ? sad16(v, qv, acc) : dot16(v, qv, acc);
+        for (uint32_t c0 = sub; c0 < row_chunks; c0 += 4 * G) {
+            uint4 v[4], qv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {  // unconditional loads (clamped address): all four issue back to back
+                const uint32_t c = c0 + j * G, cc = c < row_chunks ? c : row_chunks - 1;
+                v[j] = p[cc];
+                qv[j] = qp[cc];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (c0 + j * G < row_chunks) acc = IS_L1 ? sad16(v[j], qv[j], acc) : dot16(v[j], qv[j], acc);
             }
         }
         acc = group_sum<G>(acc);
         if (sub == 0 && k < n_ids)
-            out[k] = ok ? epilogue(multiplier, acc, q_off, offsets[row], diff, mode)
-                        : __builtin_nanf("");
+            out[k] = ok ? epilogue(multiplier, acc, q_off, offsets[row], diff, mode) : __builtin_nanf("");
     }
 }
 
@@ -932,9 +1044,26 @@ void launch_scan_generic(const qamd_u8 *h, const uint4 *qc, const float *qo, flo
 
 template <bool IS_L1> struct SmallLaunch {
     template <int G, int ITERS>
-    static qamd_status go(const qamd_u8 *h, const uint4 *qc, const float *qo, const SmallTopkPlan &pl, const SmallTopk &p,
-                          hipStream_t s) {
+    static qamd_status go(const qamd_u8 *h, const uint4 *qc, const float *qo, const FusedQuery *fq, const SmallTopkPlan &pl,
+                          const SmallTopk &p, hipStream_t s) {
         const bool exact = h->row_chunks == (uint32_t)(G * ITERS);
+        if constexpr (G * ITERS * 16 > (int)kFusedQueryDims + 15 * 16) {
+            if (fq) return fail(QAMD_ERR_ARGUMENTS, "fused query does not fit the kernel arguments");
+        } else if (fq) {
+            QueryByValue qv;
+            memcpy(qv.v, fq->values, (size_t)fq->qdim * 4);
+            const qamd_vector_parameters &vp = h->meta.vector_parameters;
+#define QAMD_U8_SMALL_FUSED(EX)                                                                                        \
+    hipLaunchKernelGGL((u8_topk_small_fused_kernel<G, ITERS, IS_L1, EX>), dim3(pl.workgroups), dim3(1024), 0, s,          \
+                       h->codes.as<uint4>(), h->offsets.as<float>(), qv, fq->qdim, (uint32_t)h->meta.actual_dim,         \
+                       h->meta.alpha, h->meta.offset, vp.distance_type, vp.invert, fq->qbuf, h->meta.multiplier,           \
+                       (uint32_t)h->count, h->row_chunks, pl.rows_per_wg, p)
+            if (exact) QAMD_U8_SMALL_FUSED(true);
+            else QAMD_U8_SMALL_FUSED(false);
+#undef QAMD_U8_SMALL_FUSED
+            QAMD_HIP(hipGetLastError());
+            return QAMD_OK;
+        }
 #define QAMD_U8_SMALL(EX)                                                                                       \
     hipLaunchKernelGGL((u8_topk_small_kernel<G, ITERS, IS_L1, EX>), dim3(pl.workgroups), dim3(1024), 0, s,       \
                        h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier, (uint32_t)h->count, \
@@ -951,23 +1080,23 @@ template <bool IS_L1> struct SmallLaunch {
 int small_group(uint32_t rc) { return rc == 1 ? 1 : rc == 2 ? 2 : rc <= 4 ? 4 : rc <= 8 ? 8 : rc <= 128 ? 16 : 0; }
 
 template <bool IS_L1>
-qamd_status launch_small(const qamd_u8 *h, const uint4 *qc, const float *qo, const SmallTopkPlan &pl, const SmallTopk &p,
-                         hipStream_t s) {
+qamd_status launch_small(const qamd_u8 *h, const uint4 *qc, const float *qo, const FusedQuery *fq, const SmallTopkPlan &pl,
+                         const SmallTopk &p, hipStream_t s) {
     using L = SmallLaunch<IS_L1>;
     const uint32_t rc = h->row_chunks;
-    if (rc == 1) return L::template go<1, 1>(h, qc, qo, pl, p, s);
-    if (rc == 2) return L::template go<2, 1>(h, qc, qo, pl, p, s);
-    if (rc <= 4) return L::template go<4, 1>(h, qc, qo, pl, p, s);
-    if (rc <= 8) return L::template go<8, 1>(h, qc, qo, pl, p, s);
+    if (rc == 1) return L::template go<1, 1>(h, qc, qo, fq, pl, p, s);
+    if (rc == 2) return L::template go<2, 1>(h, qc, qo, fq, pl, p, s);
+    if (rc <= 4) return L::template go<4, 1>(h, qc, qo, fq, pl, p, s);
+    if (rc <= 8) return L::template go<8, 1>(h, qc, qo, fq, pl, p, s);
     switch ((rc + 15) / 16) {
-        case 1: return L::template go<16, 1>(h, qc, qo, pl, p, s);
-        case 2: return L::template go<16, 2>(h, qc, qo, pl, p, s);
-        case 3: return L::template go<16, 3>(h, qc, qo, pl, p, s);
-        case 4: return L::template go<16, 4>(h, qc, qo, pl, p, s);
-        case 5: return L::template go<16, 5>(h, qc, qo, pl, p, s);
-        case 6: return L::template go<16, 6>(h, qc, qo, pl, p, s);
-        case 7: return L::template go<16, 7>(h, qc, qo, pl, p, s);
-        case 8: return L::template go<16, 8>(h, qc, qo, pl, p, s);
+        case 1: return L::template go<16, 1>(h, qc, qo, fq, pl, p, s);
+        case 2: return L::template go<16, 2>(h, qc, qo, fq, pl, p, s);
+        case 3: return L::template go<16, 3>(h, qc, qo, fq, pl, p, s);
+        case 4: return L::template go<16, 4>(h, qc, qo, fq, pl, p, s);
+        case 5: return L::template go<16, 5>(h, qc, qo, fq, pl, p, s);
+        case 6: return L::template go<16, 6>(h, qc, qo, fq, pl, p, s);
+        case 7: return L::template go<16, 7>(h, qc, qo, fq, pl, p, s);
+        case 8: return L::template go<16, 8>(h, qc, qo, fq, pl, p, s);
         default: break;
     }
     return fail(QAMD_ERR_ARGUMENTS, "no small top-k kernel for %u chunks", rc);
@@ -1032,6 +1161,15 @@ bool fused_capable(const qamd_u8 *h) {
     return (is_l1 || h->lane_mode == 0) && h->row_chunks <= 128;
 }
 
+// The single-launch top-k serves this store and k (and, for a fused query, these dims): its plan.
+bool u8_small_plan(const qamd_u8 *h, uint32_t k, SmallTopkPlan &plan) {
+    const int g = small_group(h->row_chunks);
+    if (!g || !fused_capable(h)) return false;
+    const uint32_t tile = 2 * (64 / g);
+    const uint32_t least = (uint32_t)std::max<uint64_t>(16 * tile, (128 * 1024) / std::max<uint64_t>(h->meta.actual_dim, 1));
+    return small_topk_plan(h->count, k, tile, least, plan);
+}
+
 // qc: the query's actual_dim codes (16-byte aligned), qo: its f32 offset -- inside a qamd_u8_query
 // or straight out of a query batch ([q][pitch] codes, [q] offsets).
 qamd_status scan_ptrs(const qamd_u8 *h, const uint4 *qc, const float *qo, float *out_dev, hipStream_t s,
@@ -1066,19 +1204,74 @@ qamd_status check_query(const qamd_u8 *h, const qamd_u8_query *q) {
     return QAMD_OK;
 }
 
-qamd_status score_ids_dev(const qamd_u8 *h, const uint4 *qc, const float *qo, float diff, int mode,
-                          const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t s) {
+// One launch of u8_score_pairs_kernel.  lists == nullptr: the single query (qc, qo) for every id.
+qamd_status score_pairs_dev(const qamd_u8 *h, const uint4 *qc, const float *qo, const uint8_t *q_batch, uint32_t q_pitch,
+                            const float *q_offs, const uint32_t *lists, uint32_t n_lists, const uint32_t *list_rows,
+                            float diff, int mode, const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t s) {
     if (n_ids == 0) return QAMD_OK;
     int grid = grid_for((n_ids + 3) / 4, kBlock / 64, 8);
     if (h->meta.vector_parameters.distance_type == QAMD_L1)
-        hipLaunchKernelGGL((u8_score_ids_kernel<true>), dim3(grid), dim3(kBlock), 0, s,
-                           h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier, diff,
-                           mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
+        hipLaunchKernelGGL((u8_score_pairs_kernel<true>), dim3(grid), dim3(kBlock), 0, s, h->codes.as<uint4>(),
+                           h->offsets.as<float>(), qc, qo, q_batch, q_pitch, q_offs, lists, n_lists, list_rows,
+                           h->meta.multiplier, diff, mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
     else
-        hipLaunchKernelGGL((u8_score_ids_kernel<false>), dim3(grid), dim3(kBlock), 0, s,
-                           h->codes.as<uint4>(), h->offsets.as<float>(), qc, qo, h->meta.multiplier, diff,
-                           mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
+        hipLaunchKernelGGL((u8_score_pairs_kernel<false>), dim3(grid), dim3(kBlock), 0, s, h->codes.as<uint4>(),
+                           h->offsets.as<float>(), qc, qo, q_batch, q_pitch, q_offs, lists, n_lists, list_rows,
+                           h->meta.multiplier, diff, mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
     QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
+qamd_status score_ids_dev(const qamd_u8 *h, const uint4 *qc, const float *qo, float diff, int mode,
+                          const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t s) {
+    return score_pairs_dev(h, qc, qo, nullptr, 0, nullptr, nullptr, 0, nullptr, diff, mode, ids_dev, n_ids, out_dev, s);
+}
+
+// encoded_vectors_u8.rs:389-395: the `diff` of score_internal, actual_dim * offset * offset (negated if invert)
+float internal_diff(const qamd_u8 *h) {
+    float diff = (float)h->meta.actual_dim * h->meta.offset * h->meta.offset;
+    return h->meta.vector_parameters.invert ? -diff : diff;
+}
+
+// out[k] = score of (query (qc, qo), ids[k]) for host or device ids / outputs: the body of score_ids
+// and, with (qc, qo) = row i of the store and the internal epilogue, of score_internal_ids.
+qamd_status score_ids_any(const qamd_u8 *h, const uint4 *qc, const float *qo, float diff, int mode, const uint32_t *ids,
+                          uint64_t n_ids, qamd_mem ids_mem, float *out, qamd_mem out_mem, hipStream_t s) {
+    DevBuf ids_tmp, out_tmp;
+    const uint32_t *ids_dev = ids;
+    // per-pair granularity (score_point and friends): ids and results through the calling
+    // thread's mapped host scratch -- no allocation, no copy calls
+    const HostScratch hs = (ids_mem == QAMD_MEM_HOST && out_mem == QAMD_MEM_HOST && n_ids <= 1024) ? host_scratch()
+                                                                                                  : HostScratch{};
+    if (hs.host) {
+        for (uint64_t k = 0; k < n_ids; k++) {
+            if (ids[k] >= h->count)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+            hs.host[k] = ids[k];
+        }
+        QAMD_TRY(score_ids_dev(h, qc, qo, diff, mode, hs.dev, n_ids, reinterpret_cast<float *>(hs.dev + 1024), s));
+        QAMD_HIP(hipStreamSynchronize(s));
+        memcpy(out, hs.host + 1024, n_ids * 4);
+        return QAMD_OK;
+    }
+    if (ids_mem == QAMD_MEM_HOST) {
+        for (uint64_t k = 0; k < n_ids; k++)
+            if (ids[k] >= h->count)  // the reference panics here (encoded_storage.rs:29)
+                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
+                            (unsigned long long)h->count);
+        QAMD_TRY(ids_tmp.alloc(n_ids * 4));
+        QAMD_TRY(copy_in(ids_tmp.ptr, ids, QAMD_MEM_HOST, n_ids * 4, s));
+        ids_dev = ids_tmp.as<uint32_t>();
+    }
+    float *out_dev = out;
+    if (out_mem == QAMD_MEM_HOST) {
+        QAMD_TRY(out_tmp.alloc(n_ids * 4));
+        out_dev = out_tmp.as<float>();
+    }
+    QAMD_TRY(score_ids_dev(h, qc, qo, diff, mode, ids_dev, n_ids, out_dev, s));
+    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, n_ids * 4, s));
+    else if (ids_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
     return QAMD_OK;
 }
 
@@ -1414,9 +1607,16 @@ qamd_status qamd_u8_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd
     return QAMD_OK;
 }
 
-qamd_status qamd_u8_export_rows(const qamd_u8 *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+// Rows [first_row, first_row + n_rows) in the reference's storage format: what a caller-owned
+// EncodedStorageBuilder receives through push_vector_data (encoded_storage.rs:17-25), in bounded
+// pieces -- the store never has to exist as one host buffer (19 GB per C4 shard).
+qamd_status qamd_u8_export_rows_range(const qamd_u8 *h, uint64_t first_row, uint64_t n_rows, uint8_t *rows,
+                                      qamd_mem rows_mem, void *stream) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
-    if (h->count == 0) return QAMD_OK;
+    if (first_row > h->count || n_rows > h->count - first_row)
+        return fail(QAMD_ERR_OUT_OF_RANGE, "rows [%llu, +%llu) out of range (count %llu)", (unsigned long long)first_row,
+                    (unsigned long long)n_rows, (unsigned long long)h->count);
+    if (n_rows == 0) return QAMD_OK;
     if (!rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
@@ -1424,19 +1624,24 @@ qamd_status qamd_u8_export_rows(const qamd_u8 *h, uint8_t *rows, qamd_mem rows_m
     const uint32_t row_dwords = (uint32_t)(stride / 4);
     const uint64_t batch_rows = std::max<uint64_t>(1, (256ull << 20) / stride);
     DevBuf stage;
-    if (rows_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(std::min<uint64_t>(batch_rows, h->count) * stride));
-    for (uint64_t r0 = 0; r0 < h->count; r0 += batch_rows) {
-        const uint64_t nr = std::min(batch_rows, h->count - r0);
+    if (rows_mem == QAMD_MEM_HOST) QAMD_TRY(stage.alloc(std::min<uint64_t>(batch_rows, n_rows) * stride));
+    for (uint64_t r0 = 0; r0 < n_rows; r0 += batch_rows) {
+        const uint64_t nr = std::min(batch_rows, n_rows - r0), src_row = first_row + r0;
         uint8_t *dst = rows_mem == QAMD_MEM_HOST ? stage.as<uint8_t>() : rows + r0 * stride;
         int grid = grid_for(nr * row_dwords, kBlock * 4, 8);
         hipLaunchKernelGGL(join_rows_kernel, dim3(grid), dim3(kBlock), 0, s,
-                           h->codes.as<uint32_t>() + r0 * (row_dwords - 1), h->offsets.as<float>() + r0, nr,
+                           h->codes.as<uint32_t>() + src_row * (row_dwords - 1), h->offsets.as<float>() + src_row, nr,
                            row_dwords, reinterpret_cast<uint32_t *>(dst));
         QAMD_HIP(hipGetLastError());
         if (rows_mem == QAMD_MEM_HOST)
             QAMD_TRY(copy_out(rows + r0 * stride, QAMD_MEM_HOST, dst, nr * stride, s));
     }
     return QAMD_OK;
+}
+
+qamd_status qamd_u8_export_rows(const qamd_u8 *h, uint8_t *rows, qamd_mem rows_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    return qamd_u8_export_rows_range(h, 0, h->count, rows, rows_mem, stream);
 }
 
 qamd_status qamd_u8_get_metadata(const qamd_u8 *h, qamd_u8_metadata *out) {
@@ -1510,6 +1715,53 @@ qamd_status qamd_u8_load(const char *data_path, const char *meta_path, const qam
     return st;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Runs the encode kernel for `query` (host or device f32) into q's buffer on stream s.
+qamd_status encode_now(const qamd_u8_query *q, const float *query, uint64_t qdim, qamd_mem query_mem, hipStream_t s) {
+    const uint64_t ad = q->actual_dim;
+    // The query is always encoded on the device (one implementation, no CPU arithmetic in the
+    // product): a host query is uploaded first (qdim * 4 bytes; the buffer keeps room for it
+    // behind the codes).
+    const float *q_dev = query;
+    bool via_scratch = false;
+    if (query_mem == QAMD_MEM_HOST && qdim) {
+        // through the thread's mapped host scratch when it fits: one memcpy on the host, the kernel
+        // reads the values over PCIe itself -- no copy call, no synchronisation
+        const float *dev_view = nullptr;
+        if (float *hq = host_query_acquire(qdim, &dev_view)) {
+            memcpy(hq, query, qdim * 4);
+            q_dev = dev_view;
+            via_scratch = true;
+        } else {
+            float *stage = reinterpret_cast<float *>(q->buf.as<uint8_t>() + 16 + round_up(ad, 16));
+            QAMD_TRY(copy_in(stage, query, QAMD_MEM_HOST, qdim * 4, s));
+            q_dev = stage;
+        }
+    }
+    hipLaunchKernelGGL(encode_query_kernel, dim3(1), dim3(64), 0, s, q_dev, (uint32_t)qdim, (uint32_t)ad, q->alpha,
+                       q->offset, q->distance, q->invert, q->buf.as<uint8_t>());
+    QAMD_HIP(hipGetLastError());
+    if (via_scratch) host_query_release(s);
+    return q->ready.record(s);
+}
+
+// A deferred host query (qamd_u8_query::host_f32) is encoded now, on the consumer's stream.
+qamd_status ensure_encoded(const qamd_u8_query *q, hipStream_t s) {
+    if (!q->deferred.load(std::memory_order_acquire)) return QAMD_OK;
+    std::lock_guard<std::mutex> lk(q->encode_mu);
+    if (!q->deferred.load(std::memory_order_relaxed)) return QAMD_OK;
+    QAMD_TRY(encode_now(q, q->host_f32.data(), q->host_f32.size(), QAMD_MEM_HOST, s));
+    q->deferred.store(false, std::memory_order_release);
+    return QAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t qdim, qamd_mem query_mem,
                                  void *stream, qamd_u8_query **query_io) {
     if (!h || !query_io || (!query && qdim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
@@ -1529,32 +1781,23 @@ qamd_status qamd_u8_encode_query(const qamd_u8 *h, const float *query, uint64_t 
         q->pooled = true;
         q->actual_dim = ad;
     }
-    const qamd_vector_parameters &vp = h->meta.vector_parameters;
-    // The query is always encoded on the device (one implementation, no CPU arithmetic in the
-    // product): a host query is uploaded first (qdim * 4 bytes; the buffer keeps room for it
-    // behind the codes).
-    const float *q_dev = query;
-    bool via_scratch = false;
-    if (query_mem == QAMD_MEM_HOST && qdim) {
-        // through the thread's mapped host scratch when it fits: one memcpy on the host, the kernel
-        // reads the values over PCIe itself -- no copy call, no synchronisation (106 -> ~45 us for
-        // encode_query(host) + topk on a 100k-row store)
-        const float *dev_view = nullptr;
-        if (float *hq = host_query_acquire(qdim, &dev_view)) {
-            memcpy(hq, query, qdim * 4);
-            q_dev = dev_view;
-            via_scratch = true;
-        } else {
-            float *stage = reinterpret_cast<float *>(q->buf.as<uint8_t>() + 16 + round_up(ad, 16));
-            QAMD_TRY(copy_in(stage, query, QAMD_MEM_HOST, qdim * 4, s));
-            q_dev = stage;
+    q->alpha = h->meta.alpha;
+    q->offset = h->meta.offset;
+    q->distance = h->meta.vector_parameters.distance_type;
+    q->invert = h->meta.vector_parameters.invert;
+    if (query_mem == QAMD_MEM_HOST && u8_host_encode_is_lazy(qdim)) {
+        // Deferred: the values are kept, nothing is launched.  On a small store the top-k kernel takes them
+        // by value and quantises them itself (u8_topk_small_fused_kernel); any other consumer encodes first.
+        std::lock_guard<std::mutex> lk(q->encode_mu);
+        q->host_f32.assign(query, query + qdim);
+        q->deferred.store(true, std::memory_order_release);
+    } else {
+        {
+            std::lock_guard<std::mutex> lk(q->encode_mu);
+            q->deferred.store(false, std::memory_order_release);
         }
+        QAMD_TRY(encode_now(q, query, qdim, query_mem, s));
     }
-    hipLaunchKernelGGL(encode_query_kernel, dim3(1), dim3(64), 0, s, q_dev, (uint32_t)qdim, (uint32_t)ad,
-                       h->meta.alpha, h->meta.offset, vp.distance_type, vp.invert, q->buf.as<uint8_t>());
-    QAMD_HIP(hipGetLastError());
-    if (via_scratch) host_query_release(s);
-    QAMD_TRY(q->ready.record(s));
     if (fresh) *query_io = fresh.release();
     return QAMD_OK;
 }
@@ -1564,6 +1807,7 @@ qamd_status qamd_u8_query_read(const qamd_u8_query *q, float *offset, uint8_t *c
     if (!q) return fail(QAMD_ERR_ARGUMENTS, "null query");
     QAMD_ON_DEVICE(q->device);
     if (codes_len) *codes_len = q->actual_dim;
+    QAMD_TRY(ensure_encoded(q, nullptr));
     QAMD_TRY(q->ready.wait(nullptr));
     if (offset) QAMD_TRY(copy_out(offset, QAMD_MEM_HOST, q->buf.ptr, 4, nullptr));
     if (codes) {
@@ -1582,6 +1826,7 @@ qamd_status qamd_u8_score_all(const qamd_u8 *h, const qamd_u8_query *q, float *o
     if (!out) return fail(QAMD_ERR_ARGUMENTS, "out is null");
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(ensure_encoded(q, s));
     QAMD_TRY(q->ready.wait(s));
     if (out_mem == QAMD_MEM_DEVICE) {
         q->async_used.store(true, std::memory_order_relaxed);
@@ -1602,46 +1847,38 @@ qamd_status qamd_u8_score_ids(const qamd_u8 *h, const qamd_u8_query *q, const ui
     if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    QAMD_TRY(ensure_encoded(q, s));
     QAMD_TRY(q->ready.wait(s));
     if (out_mem == QAMD_MEM_DEVICE) q->async_used.store(true, std::memory_order_relaxed);
-    DevBuf ids_tmp, out_tmp;
-    const uint32_t *ids_dev = ids;
-    // per-pair granularity (score_point and friends): ids and results through the calling
-    // thread's mapped host scratch -- no allocation, no copy calls
-    const HostScratch hs = (ids_mem == QAMD_MEM_HOST && out_mem == QAMD_MEM_HOST && n_ids <= 1024) ? host_scratch()
-                                                                                                  : HostScratch{};
-    if (hs.host) {
-        for (uint64_t k = 0; k < n_ids; k++) {
-            if (ids[k] >= h->count)
-                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
-                            (unsigned long long)h->count);
-            hs.host[k] = ids[k];
-        }
-        QAMD_TRY(score_ids_dev(h, reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16), q->buf.as<float>(), 0.0f,
-                               EPI_POINT, hs.dev, n_ids, reinterpret_cast<float *>(hs.dev + 1024), s));
-        QAMD_HIP(hipStreamSynchronize(s));
-        memcpy(out, hs.host + 1024, n_ids * 4);
-        return QAMD_OK;
-    }
-    if (ids_mem == QAMD_MEM_HOST) {
-        for (uint64_t k = 0; k < n_ids; k++)
-            if (ids[k] >= h->count)  // the reference panics here (encoded_storage.rs:29)
-                return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", ids[k],
-                            (unsigned long long)h->count);
-        QAMD_TRY(ids_tmp.alloc(n_ids * 4));
-        QAMD_TRY(copy_in(ids_tmp.ptr, ids, QAMD_MEM_HOST, n_ids * 4, s));
-        ids_dev = ids_tmp.as<uint32_t>();
-    }
-    float *out_dev = out;
-    if (out_mem == QAMD_MEM_HOST) {
-        QAMD_TRY(out_tmp.alloc(n_ids * 4));
-        out_dev = out_tmp.as<float>();
-    }
-    const uint4 *qc = reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16);
-    QAMD_TRY(score_ids_dev(h, qc, q->buf.as<float>(), 0.0f, EPI_POINT, ids_dev, n_ids, out_dev, s));
-    if (out_mem == QAMD_MEM_HOST) QAMD_TRY(copy_out(out, QAMD_MEM_HOST, out_dev, n_ids * 4, s));
-    else if (ids_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));
-    return QAMD_OK;
+    return score_ids_any(h, reinterpret_cast<const uint4 *>(q->buf.as<uint8_t>() + 16), q->buf.as<float>(), 0.0f, EPI_POINT,
+                         ids, n_ids, ids_mem, out, out_mem, s);
+}
+
+// score_internal (:386-453) for one stored row against many: out[k] = score_internal(i, ids[k]).
+qamd_status qamd_u8_score_internal_ids(const qamd_u8 *h, uint32_t i, const uint32_t *ids, uint64_t n_ids,
+                                       qamd_mem ids_mem, float *out, qamd_mem out_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (n_ids == 0) return QAMD_OK;
+    if (!ids || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (i >= h->count) return fail(QAMD_ERR_OUT_OF_RANGE, "row id %u out of range (count %llu)", i, (unsigned long long)h->count);
+    QAMD_ON_DEVICE(h->device);
+    return score_ids_any(h, h->codes.as<uint4>() + (uint64_t)i * h->row_chunks, h->offsets.as<float>() + i, internal_diff(h),
+                         EPI_INTERNAL, ids, n_ids, ids_mem, out, out_mem, as_stream(stream));
+}
+
+// Many stored rows, each against its own id list, in one launch (lists.hpp):
+// out[p] = score_internal(rows[l], ids[p]) for p in [list_offsets[l], list_offsets[l + 1]).
+qamd_status qamd_u8_score_internal_ids_batch(const qamd_u8 *h, const uint32_t *rows, const uint32_t *list_offsets,
+                                             uint32_t n_lists, const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem,
+                                             float *out, qamd_mem out_mem, void *stream) {
+    if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
+    if (n_lists && !rows) return fail(QAMD_ERR_ARGUMENTS, "rows is null");
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    return run_lists(list_offsets, n_lists, ids, n_ids, rows, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
+        return score_pairs_dev(h, nullptr, nullptr, nullptr, 0, nullptr, a.offsets, a.n_lists, a.rows, internal_diff(h),
+                               EPI_INTERNAL, a.ids, a.n_pairs, a.out, s);
+    });
 }
 
 qamd_status qamd_u8_score_point(const qamd_u8 *h, const qamd_u8_query *q, uint32_t i, float *out) {
@@ -1650,27 +1887,7 @@ qamd_status qamd_u8_score_point(const qamd_u8 *h, const qamd_u8_query *q, uint32
 
 qamd_status qamd_u8_score_internal(const qamd_u8 *h, uint32_t i, uint32_t j, float *out) {
     if (!h || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    if (i >= h->count || j >= h->count)
-        return fail(QAMD_ERR_OUT_OF_RANGE, "row id out of range (count %llu)", (unsigned long long)h->count);
-    QAMD_ON_DEVICE(h->device);
-    // :389-395  diff = actual_dim*offset*offset (negated if invert)
-    float diff = (float)h->meta.actual_dim * h->meta.offset * h->meta.offset;
-    if (h->meta.vector_parameters.invert) diff = -diff;
-    const uint4 *qc = h->codes.as<uint4>() + (uint64_t)i * h->row_chunks;
-    const float *qo = h->offsets.as<float>() + i;
-    const HostScratch hs = host_scratch();
-    if (hs.host) {
-        hs.host[0] = j;
-        QAMD_TRY(score_ids_dev(h, qc, qo, diff, EPI_INTERNAL, hs.dev, 1, reinterpret_cast<float *>(hs.dev + 1024), nullptr));
-        QAMD_HIP(hipStreamSynchronize(nullptr));
-        memcpy(out, hs.host + 1024, 4);
-        return QAMD_OK;
-    }
-    DevBuf tmp;
-    QAMD_TRY(tmp.alloc(16));
-    QAMD_TRY(copy_in(tmp.ptr, &j, QAMD_MEM_HOST, 4, nullptr));
-    QAMD_TRY(score_ids_dev(h, qc, qo, diff, EPI_INTERNAL, tmp.as<uint32_t>(), 1, tmp.as<float>() + 1, nullptr));
-    return copy_out(out, QAMD_MEM_HOST, tmp.as<float>() + 1, 4, nullptr);
+    return qamd_u8_score_internal_ids(h, i, &j, 1, QAMD_MEM_HOST, out, QAMD_MEM_HOST, nullptr);
 }
 
 qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, int largest, uint32_t *out_ids,
@@ -1680,6 +1897,26 @@ qamd_status qamd_u8_topk(const qamd_u8 *h, const qamd_u8_query *q, uint32_t k, i
     if (!out_ids || !out_scores) return fail(QAMD_ERR_ARGUMENTS, "null output");
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
+    if (q->deferred.load(std::memory_order_acquire)) {
+        // a host query that has not been encoded yet: on a small store the search is ONE launch, the
+        // top-k kernel quantises the query (passed by value) in its prologue and leaves the codes in the
+        // query object
+        std::unique_lock<std::mutex> lk(q->encode_mu);
+        SmallTopkPlan plan;
+        if (q->deferred.load(std::memory_order_relaxed) && u8_small_plan(h, k, plan)) {
+            FusedQuery fq{q->host_f32.data(), (uint32_t)q->host_f32.size(), q->buf.as<uint8_t>()};
+            if (out_mem == QAMD_MEM_DEVICE) q->async_used.store(true, std::memory_order_relaxed);
+            qamd_status st = u8_topk_ptrs(h, q->buf.as<uint8_t>() + 16, q->buf.as<float>(), k, largest, out_ids, out_scores,
+                                          out_mem, s, &fq);
+            if (st == QAMD_OK) {
+                st = q->ready.record(s);  // the codes are in the object once this launch has run
+                q->deferred.store(false, std::memory_order_release);
+            }
+            return st;
+        }
+        lk.unlock();
+        QAMD_TRY(ensure_encoded(q, s));
+    }
     QAMD_TRY(q->ready.wait(s));
     if (out_mem == QAMD_MEM_DEVICE) q->async_used.store(true, std::memory_order_relaxed);
     return u8_topk_ptrs(h, q->buf.as<uint8_t>() + 16, q->buf.as<float>(), k, largest, out_ids, out_scores, out_mem, s);
@@ -1956,7 +2193,7 @@ qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev,
 // qamd_u8_topk, also the per-query route of the batch API, which hands in rows of a query batch
 // without copying them into a query object.  Runs on the current device.
 qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float *qo, uint32_t k, int largest,
-                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t s) {
+                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t s, const FusedQuery *fq) {
     const uint4 *qc = reinterpret_cast<const uint4 *>(codes_dev);
     FusedScan scan;
     scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_ptrs(h, qc, qo, scores, st); };
@@ -1965,17 +2202,17 @@ qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float
         return score_ids_dev(h, qc, qo, 0.0f, EPI_POINT, ids, n_ids, out, st);
     };
     {   // small stores: one launch, no status read-back (device outputs only enqueue)
-        const int g = small_group(h->row_chunks);
         SmallTopkPlan plan;
-        if (g && fused_capable(h) && small_topk_plan(h->count, k, 2 * (64 / g), plan)) {
+        if (u8_small_plan(h, k, plan)) {
             const bool is_l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
             return small_topk(plan, k, largest, out_ids, out_scores, out_mem, s,
                               [&](const SmallTopk &p, hipStream_t st) {
-                                  return is_l1 ? launch_small<true>(h, qc, qo, plan, p, st)
-                                               : launch_small<false>(h, qc, qo, plan, p, st);
+                                  return is_l1 ? launch_small<true>(h, qc, qo, fq, plan, p, st)
+                                               : launch_small<false>(h, qc, qo, fq, plan, p, st);
                               });
         }
     }
+    if (fq) return fail(QAMD_ERR_ARGUMENTS, "a deferred query needs the single-launch path");
     if (!fused_capable(h)) {  // rare layouts: classic path only
         float *scores = nullptr;
         QAMD_TRY(thread_ws_acquire(WS_SCORES, std::max<uint64_t>(h->count, 1) * 4, s, reinterpret_cast<void **>(&scores)));
@@ -2019,6 +2256,15 @@ qamd_status u8_topk_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint
     return fused_topk_batch(h->count, n_queries, k, largest, out_ids, out_scores, out_mem, stream, scan);
 }
 
+bool u8_host_encode_is_lazy(uint64_t qdim) { return qdim > 0 && actual_dim_of(qdim) <= kFusedQueryDims; }
+
+// score_ids_batch: query l of a batch ([q][pitch] codes, [q] offsets) against list l (lists.hpp).
+qamd_status u8_score_lists(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
+                           const ListArgs &a, hipStream_t stream) {
+    return score_pairs_dev(h, nullptr, nullptr, codes_dev, (uint32_t)pitch, offsets_dev, a.offsets, a.n_lists, nullptr, 0.0f,
+                           EPI_POINT, a.ids, a.n_pairs, a.out, stream);
+}
+
 // How many queries the vector-ALU multi-query scan takes per pass for this store (0: none).
 uint32_t u8_multi_width(const qamd_u8 *h) { return multi_width(h); }
 
@@ -2050,7 +2296,7 @@ qamd_status u8_score_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uin
 // allocation; on small stores (single-launch path) with device outputs it only enqueues.
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,
                            int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream) {
-    return u8_topk_ptrs(h, codes_dev, offset_dev, k, largest, out_ids, out_scores, out_mem, stream);
+    return u8_topk_ptrs(h, codes_dev, offset_dev, k, largest, out_ids, out_scores, out_mem, stream, nullptr);
 }
 
 // score_all for one member of a query batch (the L1 route of the batch API: L1 has no MFMA form).

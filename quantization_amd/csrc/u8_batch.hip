@@ -1683,6 +1683,21 @@ qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, u
 
 void qamd_u8_query_batch_free(qamd_u8_query_batch *b) { delete b; }
 
+// Many (query, id list) pairs in one launch (lists.hpp): out[p] = score_point(query l, ids[p]) for p in
+// [list_offsets[l], list_offsets[l + 1]) -- one HNSW hop of every in-flight search.
+qamd_status qamd_u8_score_ids_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint32_t *list_offsets,
+                                    uint32_t n_lists, const uint32_t *ids, uint64_t n_ids, qamd_mem lists_mem, float *out,
+                                    qamd_mem out_mem, void *stream) {
+    QAMD_TRY(check_batch(h, b));
+    if (n_lists > b->n_queries)
+        return fail(QAMD_ERR_ARGUMENTS, "%u lists, but the batch holds %llu queries", n_lists, (unsigned long long)b->n_queries);
+    QAMD_ON_DEVICE(h->device);
+    hipStream_t s = as_stream(stream);
+    return run_lists(list_offsets, n_lists, ids, n_ids, nullptr, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
+        return u8_score_lists(h, b->codes.as<uint8_t>(), b->pitch, b->offsets.as<float>(), a, s);
+    });
+}
+
 qamd_status qamd_u8_score_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, float *out, qamd_mem out_mem,
                                 void *stream) {
     QAMD_TRY(check_batch(h, b));

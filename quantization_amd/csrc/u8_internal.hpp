@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "common.hpp"
+#include "lists.hpp"
 
 struct qamd_u8 {
     int device = 0;
@@ -26,7 +27,16 @@ struct qamd_u8_query {
     int device = 0;
     uint64_t actual_dim = 0;
     qamd::DevBuf buf;  // [0..4) offset f32, [16..16+actual_dim) codes
-    qamd::ReadyEvent ready;  // the last encode_query (stream order for consumers on other streams)
+    mutable qamd::ReadyEvent ready;  // the last encode_query (stream order for consumers on other streams)
+    // A HOST query of up to kFusedQueryDims values is not encoded by encode_query itself: its f32 values
+    // wait here until the first consumer.  The single-launch top-k of a small store takes them BY VALUE in
+    // its kernel arguments and quantises them in its prologue (one launch per search instead of two, no
+    // PCIe read by the GPU); any other consumer runs the encode kernel first (u8.hip ensure_encoded).
+    mutable std::vector<float> host_f32;
+    float alpha = 0.0f, offset = 0.0f;  // of the store the query was (or will be) encoded for
+    int distance = 0, invert = 0;
+    mutable std::atomic<bool> deferred{false};
+    mutable std::mutex encode_mu;  // two threads may consume one deferred query
     bool pooled = false;     // buf came from / goes back to the query buffer cache
     mutable std::atomic<bool> async_used{false};  // a consumer call only ENQUEUED (device outputs)
     ~qamd_u8_query() {
@@ -48,8 +58,16 @@ qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev,
                                      uint8_t *codes_dev /* [n][code_pitch], actual_dim written */, uint64_t code_pitch,
                                      float *offsets_dev /* [n] */,
                                      hipStream_t stream);
+bool u8_host_encode_is_lazy(uint64_t qdim);  // encode_query(host query of qdim values) launches nothing
+// A host query the single-launch top-k quantises itself (qamd_u8_query::host_f32) and where its codes go.
+struct FusedQuery {
+    const float *values = nullptr;
+    uint32_t qdim = 0;
+    uint8_t *qbuf = nullptr;
+};
 qamd_status u8_topk_ptrs(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k, int largest,
-                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);
+                         uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream,
+                         const FusedQuery *fq = nullptr);
 qamd_status u8_topk_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
                                 uint32_t n_queries, uint32_t k, int largest, uint32_t *out_ids, float *out_scores,
                                 qamd_mem out_mem, hipStream_t stream);
@@ -58,6 +76,8 @@ qamd_status u8_score_batch_scans(const qamd_u8 *h, const uint8_t *codes_dev, uin
                                  uint32_t n_queries, float *out_dev, hipStream_t stream);
 qamd_status u8_score_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, float *out_dev,
                             hipStream_t stream);
+qamd_status u8_score_lists(const qamd_u8 *h, const uint8_t *codes_dev, uint64_t pitch, const float *offsets_dev,
+                           const ListArgs &a, hipStream_t stream);
 qamd_status u8_topk_single(const qamd_u8 *h, const uint8_t *codes_dev, const float *offset_dev, uint32_t k,
                            int largest, uint32_t *out_ids, float *out_scores, qamd_mem out_mem, hipStream_t stream);
 }  // namespace qamd

@@ -141,3 +141,12 @@ class EncodedVectorsBin(EncodedVectorsBase):
         buf, ret = out_buf(out, n * nb, np.uint8)
         check(_lib.lib().qamd_bin_export_rows(self._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret.reshape(n, nb) if isinstance(ret, np.ndarray) else ret
+
+    def storage_rows(self, first_row: int, n_rows: int, out=None, stream=None):
+        """Rows [first_row, first_row + n_rows) as push_vector_data would receive them (encoded_storage.rs:17-25)."""
+        nb = self.get_quantized_vector_size_from_params(self._vp, self._store)
+        check_same_device(self._device, out)
+        buf, ret = out_buf(out, n_rows * nb, np.uint8)
+        check(_lib.lib().qamd_bin_export_rows_range(self._h, int(first_row), int(n_rows), buf.ptr, buf.mem,
+                                                    stream_ptr(stream)))
+        return ret.reshape(n_rows, nb) if isinstance(ret, np.ndarray) else ret

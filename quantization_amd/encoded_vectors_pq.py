@@ -178,3 +178,12 @@ class EncodedVectorsPQ(EncodedVectorsBase):
         buf, ret = out_buf(out, n * m, np.uint8)
         check(_lib.lib().qamd_pq_export_rows(self._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret.reshape(n, m) if isinstance(ret, np.ndarray) else ret
+
+    def storage_rows(self, first_row: int, n_rows: int, out=None, stream=None):
+        """Rows [first_row, first_row + n_rows) as push_vector_data would receive them (encoded_storage.rs:17-25)."""
+        m = self.get_quantized_vector_size(self._vp, self._chunk_size)
+        check_same_device(self._device, out)
+        buf, ret = out_buf(out, n_rows * m, np.uint8)
+        check(_lib.lib().qamd_pq_export_rows_range(self._h, int(first_row), int(n_rows), buf.ptr, buf.mem,
+                                                   stream_ptr(stream)))
+        return ret.reshape(n_rows, m) if isinstance(ret, np.ndarray) else ret

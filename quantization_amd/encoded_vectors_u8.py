@@ -172,6 +172,16 @@ class EncodedVectorsU8(EncodedVectorsBase):
         check(_lib.lib().qamd_u8_export_rows(self._h, buf.ptr, buf.mem, stream_ptr(stream)))
         return ret.reshape(n, stride) if isinstance(ret, np.ndarray) else ret
 
+    def storage_rows(self, first_row: int, n_rows: int, out=None, stream=None):
+        """Rows [first_row, first_row + n_rows) in the reference's storage format — what a caller-owned
+        EncodedStorageBuilder receives through push_vector_data (encoded_storage.rs:17-25), piece by piece."""
+        stride = self.metadata["actual_dim"] + 4
+        check_same_device(self._device, out)
+        buf, ret = out_buf(out, n_rows * stride, np.uint8)
+        check(_lib.lib().qamd_u8_export_rows_range(self._h, int(first_row), int(n_rows), buf.ptr, buf.mem,
+                                                   stream_ptr(stream)))
+        return ret.reshape(n_rows, stride) if isinstance(ret, np.ndarray) else ret
+
     def set_lane_mode(self, mode: int) -> None:
         """0: integer sum rounded once (default); 1: avx2.c 8-lane f32 summation order."""
         check(_lib.lib().qamd_u8_set_lane_mode(self._h, mode))

@@ -2,7 +2,7 @@
  * c_abi_smoke.c -- the drop-in boundary exercised from plain C99 (no Python, no ctypes, no torch):
  * what a Rust `extern "C"` binding of include/quantization_amd.h would do.
  *
- *   encode (one-shot AND streaming) -> get_metadata -> export_rows -> encode_query -> score_all
+ *   encode (one-shot AND streaming) -> get_metadata -> export_rows (whole and in ranges) -> encode_query -> score_all
  *   -> topk -> sharded (2 logical shards) score_all / topk
  *
  * Inputs come from a fixed LCG (every value k/65536, exactly representable), so the pytest wrapper
@@ -99,7 +99,17 @@ int main(int argc, char **argv) {
     }
     CHECK(qamd_u8_encoder_finish(enc, &hs));
     CHECK(qamd_u8_get_metadata(hs, &meta2));
-    CHECK(qamd_u8_export_rows(hs, rows2, QAMD_MEM_HOST, NULL));
+    /* the caller-owned-storage half of encode (storage_builder.push_vector_data, encoded_storage.rs:17-25):
+     * the rows leave the handle in bounded ranges, here 512 at a time, and must be the whole export */
+    memset(rows2, 0xEE, stride * COUNT);
+    for (off = 0; off < COUNT; off += 512) {
+        uint64_t n = COUNT - off < 512 ? COUNT - off : 512;
+        CHECK(qamd_u8_export_rows_range(hs, off, n, rows2 + off * stride, QAMD_MEM_HOST, NULL));
+    }
+    if (qamd_u8_export_rows_range(hs, COUNT - 1, 2, rows2, QAMD_MEM_HOST, NULL) != QAMD_ERR_OUT_OF_RANGE) {
+        fprintf(stderr, "a range past the end of the store must be refused\n");
+        return 1;
+    }
     if (memcmp(rows, rows2, stride * COUNT) != 0 || bits_of(meta.alpha) != bits_of(meta2.alpha) ||
         bits_of(meta.offset) != bits_of(meta2.offset) || bits_of(meta.multiplier) != bits_of(meta2.multiplier)) {
         fprintf(stderr, "streaming encode differs from the one-shot encode\n");

@@ -19,11 +19,11 @@
 
 #include "quantization_amd.h"
 
-#define ROWS 96000u
+#define ROWS 24000u
 #define DIM 64u
-#define SHARDS 8u
+#define SHARDS 4u
 #define THREADS 6u
-#define CALLS 150u
+#define CALLS 300u
 #define K 30u
 
 static uint32_t lcg_state = 777u;

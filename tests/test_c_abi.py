@@ -79,7 +79,7 @@ def test_threaded_c_program_compiles_and_links(tmp_path):
 
 @pytest.mark.gpu
 def test_sharded_handle_lets_search_threads_overlap(tmp_path):
-    """Six pthreads searching one 8-shard handle (tests/c_abi/sharded_threads.c): every answer equals
+    """Six pthreads searching one 4-shard handle (tests/c_abi/sharded_threads.c): every answer equals
     the plain handle's, and the calls INTERLEAVE -- there is no per-handle lock: the wall time of the
     concurrent run is under half the serial one (logical shards on one GPU, latency-bound searches)."""
     exe = build_program(tmp_path, THREADS_SRC, std="gnu99", extra=("-lpthread",))
