@@ -679,18 +679,23 @@ def main():
         if traffic is not None:
             roofline["traffic"] = traffic
             roofline["traffic_source"] = source
-        # on-box streaming-read ceiling with the same load shape (16 B/lane, nt)
+        # on-box streaming-read ceiling with the same load shape (16 B/lane, nt): a measurement helper built
+        # beside the tools (tools/probe), not an entry point of the product library
         try:
+            P = C.CDLL(_lib.PROBE_PATH)
+            P.qamd_probe_stream_read.restype = C.c_int
+            P.qamd_probe_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
             probe = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
             probe.zero_()
             scratch = torch.empty(1 << 16, dtype=torch.uint8, device=dev)
             s = torch.cuda.current_stream().cuda_stream
             for _ in range(3):
-                L.qamd_stream_read(probe.data_ptr(), probe.numel(), scratch.data_ptr(), s)
+                if P.qamd_probe_stream_read(probe.data_ptr(), probe.numel(), scratch.data_ptr(), s):
+                    raise RuntimeError("probe launch failed")
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(10):
-                L.qamd_stream_read(probe.data_ptr(), probe.numel(), scratch.data_ptr(), s)
+                P.qamd_probe_stream_read(probe.data_ptr(), probe.numel(), scratch.data_ptr(), s)
             b.record()
             torch.cuda.synchronize()
             roofline["stream_read_ceiling_GBps"] = probe.numel() * 10 / (a.elapsed_time(b) * 1e-3) / 1e9

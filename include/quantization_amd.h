@@ -598,13 +598,8 @@ QAMD_API qamd_status qamd_topk_merge(const uint32_t *ids_dev, const float *score
                                      void *stream);
 
 /* ===================================================================================
- * Measurement helpers (bench.py): HIP events on the caller's stream, and a plain
- * streaming-read kernel that measures the box's achievable HBM read ceiling.
+ * Measurement helper (bench.py's roofline arithmetic).
  * =================================================================================== */
-/* Sums `bytes` of device memory with 16-byte loads; writes one u32 per workgroup to
- * scratch (>= 64 KiB).  Used only to calibrate the roofline ceiling. */
-QAMD_API qamd_status qamd_stream_read(const void *dev_ptr, uint64_t bytes, void *scratch,
-                                      void *stream);
 /* Per-row store traffic of the u8 scan kernel: bytes read per scored row (codes + offset). */
 QAMD_API uint64_t qamd_u8_scan_bytes_per_row(const qamd_u8 *h);
 

@@ -43,7 +43,7 @@ done
 set -- $CSVS
 FIRST=$1; shift
 python3 profiles/summarize.py counters "$FIRST" u8_gemm_qs_kernel\<1 "gpurun_out/${TAG}_batch_counters_1024.txt" "$@"
-export QAMD_LIB_PATH=$PWD/quantization_amd/libquantization_amd_dev.so
+export QAMD_LIB_PATH=$PWD/tools/lib/libquantization_amd_dev.so
 python3 tools/mfma_peak.py 2>&1 | grep -v amdgpu.ids > "gpurun_out/${TAG}_mfma_int8_ceiling.txt"
 python3 tools/tune_stream.py 2>&1 | grep -v amdgpu.ids > "gpurun_out/${TAG}_row_stream_patterns.txt"
 QAMD_GEMM_CFG=q python3 tools/gemm_timeline.py 1024 10000000 768 2>&1 | grep -v amdgpu.ids > "gpurun_out/${TAG}_qs_timeline.txt"

@@ -31,13 +31,20 @@ class U8MetadataC(C.Structure):
 STOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
+PROBE_PATH = os.path.join(HERE, "..", "tools", "probe", "libqamd_probe.so")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into quantization_amd/libquantization_amd.so."""
+    """Compile every HIP source for gfx950 into quantization_amd/libquantization_amd.so (and the bench's
+    streaming-read probe into tools/probe/libqamd_probe.so)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
             if f.endswith((".hip", ".cpp", ".hpp"))] + [
         os.path.join(HERE, "..", "include", "quantization_amd.h")]
     newest = max(os.path.getmtime(p) for p in srcs)
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+    probe_src = os.path.join(HERE, "..", "tools", "probe", "stream_read.hip")
+    probe_stale = os.path.exists(probe_src) and (not os.path.exists(PROBE_PATH)
+                                                  or os.path.getmtime(PROBE_PATH) < os.path.getmtime(probe_src))
+    if force or probe_stale or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
         cmd = ["make", "-C", CSRC, "-j8"]
         res = subprocess.run(cmd, capture_output=not verbose, text=True)
         if res.returncode != 0:
@@ -209,8 +216,6 @@ def lib() -> C.CDLL:
         "qamd_pq_sharded_free": (None, [vp]),
         "qamd_topk_scores": (i32, [vp, u64, u32, i32, vp, vp, i32, vp]),
         "qamd_topk_merge": (i32, [vp, vp, u64, vp, u32, u32, u32, i32, vp, vp, i32, vp]),
-        # measurement
-        "qamd_stream_read": (i32, [vp, u64, vp, vp]),
     }
     undeclared = set(sig) - set(declared_symbols())
     if undeclared:  # the binding may only name what include/quantization_amd.h declares

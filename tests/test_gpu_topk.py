@@ -169,3 +169,82 @@ def test_small_store_topk_is_capturable_with_device_outputs():
         wi, ws = enc.topk(enc.encode_query(query), 30)
         assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), wi), trial
         assert np.array_equal(d_sc.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("dim", [65, 768, 896, 897, 1536])
+@pytest.mark.parametrize("dist,invert", [(D.Dot, False), (D.L2, False), (D.L1, True), (D.Dot, True)])
+def test_one_launch_search_quantises_the_host_query_in_the_topk_kernel(dim, dist, invert, qo):
+    """encode_query(host query) is deferred (<= 896 code bytes); on a small store topk() is then ONE launch whose
+    prologue quantises the query passed by value (u8_topk_small_fused_kernel).  Codes, offset and every score must
+    be the reference's (encoded_vectors_u8.rs:290-329, :331-384), and the query object must afterwards behave as
+    an ordinary encoded query.  897 / 1536 dims: not deferred, same results through the two-launch path."""
+    from util import assert_bits_equal
+
+    rng = np.random.default_rng(dim + int(dist) + 10 * invert)
+    n = 20_000
+    data = rng.random((n, dim), dtype=np.float32) - (0.5 if dist == D.L1 else 0.0)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
+    rows, meta = qo.u8_encode(data, int(dist), invert)
+    query = rng.random(dim, dtype=np.float32)
+    query[::7] = [np.nan, np.inf, -np.inf, 1e30, -0.0][dim % 5]  # the encoder's edge values
+    codes, qoff = qo.u8_encode_query(meta, query)
+    want = qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_SIMPLE)
+    for k, largest in ((30, True), (64, False), (1, True)):
+        q = enc.encode_query(query)  # host query: nothing launched yet for <= 896 dims
+        ids, sc = enc.topk(q, k, largest=largest)
+        wi, ws = _expect(want, k, largest)
+        assert np.array_equal(ids, wi), (k, largest)
+        assert_bits_equal(sc, ws, "fused top-k scores")
+        # workgroup 0 left the codes and the offset in the query object
+        assert np.array_equal(q.encoded_query, codes)
+        assert np.float32(q.offset).view(np.uint32) == np.float32(qoff).view(np.uint32)
+        assert_bits_equal(enc.score_all(q), want, "score_all after the fused launch")
+    # a deferred query whose FIRST consumer is not the small top-k is encoded on demand
+    q = enc.encode_query(query)
+    assert_bits_equal(enc.score_all(q), want, "score_all of a deferred query")
+    q = enc.encode_query(query)
+    assert np.array_equal(q.encoded_query, codes)
+    q = enc.encode_query(query)
+    assert np.float32(enc.score_point(q, 123)).view(np.uint32) == want[123:124].view(np.uint32)[0]
+    q = enc.encode_query(query)
+    ids_k, _ = enc.topk(q, 200, largest=True)  # k > 64: not the single-launch path
+    assert np.array_equal(ids_k, _expect(want, 200, True)[0])
+    # re-using the object for another query
+    query2 = rng.random(dim, dtype=np.float32)
+    q = enc.encode_query(query2, reuse=q)
+    c2, o2 = qo.u8_encode_query(meta, query2)
+    want2 = qo.u8_score_all(meta, rows, c2, o2, order=qo.ORDER_SIMPLE)
+    ids, sc = enc.topk(q, 30)
+    assert np.array_equal(ids, _expect(want2, 30, True)[0])
+    assert_bits_equal(sc, _expect(want2, 30, True)[1], "reused query object")
+
+
+def test_deferred_query_shared_by_threads():
+    import threading
+
+    rng = np.random.default_rng(77)
+    n, dim = 50_000, 128
+    enc = qa.EncodedVectorsU8.encode(rng.random((n, dim), dtype=np.float32), qa.VectorParameters(dim, n, D.Dot, False))
+    query = rng.random(dim, dtype=np.float32)
+    ref_q = enc.encode_query(query)
+    want = enc.topk(ref_q, 20)
+    want_all = enc.score_all(ref_q)
+    for _ in range(20):
+        q = enc.encode_query(query)  # deferred; four threads consume it at once
+        out, errs = [None] * 4, []
+
+        def work(i):
+            try:
+                out[i] = enc.topk(q, 20) if i % 2 == 0 else enc.score_all(q)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        for i in range(4):
+            if i % 2 == 0:
+                assert np.array_equal(out[i][0], want[0]) and np.array_equal(out[i][1].view(np.uint32), want[1].view(np.uint32))
+            else:
+                assert np.array_equal(out[i].view(np.uint32), want_all.view(np.uint32))

@@ -1,5 +1,9 @@
 """One-off stress check: PQ 200M x m=32 and u8 250M x 64 dims (row counts near 2^28, byte offsets
 far beyond 2^32): top-k against torch.topk on score_all, score_ids at the far end of the store."""
+import sys as _sys
+if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:  # every tool answers --help without touching the GPU (tests/test_tools.py)
+    print(__doc__)
+    _sys.exit(0)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Developer fuzz (GPU box): random shapes through the binary topk_batch (matrix-core path from 16 queries and
 32768 rows on) against the single-query top-k.    python tools/fuzz_bin_batch.py [cases] [seed]"""
+import sys as _sys
+if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:  # every tool answers --help without touching the GPU (tests/test_tools.py)
+    print(__doc__)
+    _sys.exit(0)
 import os
 import sys
 import time

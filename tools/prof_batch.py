@@ -1,3 +1,8 @@
+"""Minimal driver to put after `rocprofv3 ... --`: a few topk_batch calls of one batch size on a 10M x 768 store."""
+import sys as _sys
+if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:  # every tool answers --help without touching the GPU (tests/test_tools.py)
+    print(__doc__)
+    _sys.exit(0)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,8 @@
 """Profiling driver: PQ encode with given centroids (500k x 768, chunk 8), three calls."""
+import sys as _sys
+if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:  # every tool answers --help without touching the GPU (tests/test_tools.py)
+    print(__doc__)
+    _sys.exit(0)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

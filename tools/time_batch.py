@@ -1,5 +1,9 @@
 """Time topk_batch for a list of batch sizes on one store (developer A/B driver: run it under
 QAMD_LIB_PATH=<other build> to compare two builds on the same box)."""
+import sys as _sys
+if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:  # every tool answers --help without touching the GPU (tests/test_tools.py)
+    print(__doc__)
+    _sys.exit(0)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,9 @@
 """Host query in -> host results out on a small store, calling the C ABI directly through ctypes with
 pre-bound arguments (what a Rust / C caller pays), next to the Python mirror's figure in time_small.py."""
+import sys as _sys
+if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:  # every tool answers --help without touching the GPU (tests/test_tools.py)
+    print(__doc__)
+    _sys.exit(0)
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -2,6 +2,10 @@
 1, 2, 8 logical shards against the plain handle.  With every shard on one device the scans serialise,
 so what this shows is the cost of the fan-out to the worker threads, the peer-copy stand-in and the
 device-side merge -- not a speed-up."""
+import sys as _sys
+if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:  # every tool answers --help without touching the GPU (tests/test_tools.py)
+    print(__doc__)
+    _sys.exit(0)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
