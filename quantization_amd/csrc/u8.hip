@@ -110,6 +110,32 @@ __device__ __forceinline__ uint32_t f32_to_u8(float v, float alpha, float offset
     return (x != x) ? 0u : (uint32_t)x;
 }
 
+// f32_to_u8 for four values without the division, for all but ~6 values in 100 000.
+// x = RN((v - offset) / alpha) and y = RN((v - offset) * RN(1 / alpha)) differ by at most
+// |x| * (2^-23 + 2^-24) < 2.3e-5 for |x| <= 128 (three roundings of relative size 2^-24), so whenever y
+// lies further than 2^-15 = 3.05e-5 from every integer -- or anywhere outside (-2^-15, 128 + 2^-15),
+// where the clamp decides -- trunc(clamp(x)) == trunc(clamp(y)).  If any of the four values is inside
+// one of those bands (or NaN: both tests fail), all four take the reference's division: ONE branch per
+// float4, taken by 1.5 % of the waves.  The host selects this path only for a normal alpha in
+// 2^-60 .. 2^60 (1 / alpha exact to half an ulp, no overflow).  Codes are the reference's, bit for bit
+// (tests/test_gpu_u8.py: boundary sweep).  Returns the four codes packed into a dword.
+__device__ __forceinline__ bool quant_decided(float y) {
+    constexpr float kBand = 3.0517578125e-05f;  // 2^-15
+    const float fr = __builtin_amdgcn_fractf(y);
+    return (__builtin_fabsf(fr - 0.5f) <= 0.5f - kBand) || (__builtin_fabsf(y - 64.0f) >= 64.0f + kBand);
+}
+__device__ __forceinline__ uint32_t quant_code(float y) {  // y is not NaN here
+    return (uint32_t)__builtin_amdgcn_fmed3f(y, 0.0f, 127.0f);
+}
+__device__ __forceinline__ uint32_t f32x4_to_u8x4_fast(const float4 &f, float alpha, float offset, float r_alpha) {
+    const float y0 = (f.x - offset) * r_alpha, y1 = (f.y - offset) * r_alpha, y2 = (f.z - offset) * r_alpha,
+                y3 = (f.w - offset) * r_alpha;
+    if (quant_decided(y0) && quant_decided(y1) && quant_decided(y2) && quant_decided(y3))
+        return quant_code(y0) | (quant_code(y1) << 8) | (quant_code(y2) << 16) | (quant_code(y3) << 24);
+    return f32_to_u8(f.x, alpha, offset) | (f32_to_u8(f.y, alpha, offset) << 8) | (f32_to_u8(f.z, alpha, offset) << 16) |
+           (f32_to_u8(f.w, alpha, offset) << 24);
+}
+
 // ------------------------------------------------------------------------------ scan kernel
 // One wave covers ONE tile of (64/G)*UNROLL consecutive rows and exits; the grid is one wave
 // per tile.  Measured on MI355X (10M x 768, tools/tune_u8.py): this non-persistent form
@@ -670,11 +696,16 @@ __global__ __launch_bounds__(kScanBlock) void minmax_stream_kernel(const float4 
 // wave, one wave per tile.  Lane `sub` converts float4 #(sub + 16*it) of its row into one dword
 // of codes: every wave-load is 4 x 256 contiguous bytes and up to four are in flight per lane;
 // the row sums finish with DPP row adds.  Same arithmetic as quantize_kernel.
-template <int ITERS /* float4 per lane, 0 = any dim (loop of 4-deep batches) */>
+// Measured (2M x 768, profiles/r03_quantize_shapes.txt): 1.36-1.37 ms = 5.6 TB/s of read + written bytes with the
+// exact division AND with the division-free conversion -- the kernel is bound by the mixed read/write stream, not
+// by the vector ALU; plain instead of nt stores: the same; a lane owning four consecutive float4 (one 16-byte
+// store per lane, loads at a 64-byte lane stride): 3.6 ms.
+template <int ITERS /* float4 per lane, 0 = any dim (loop of 4-deep batches) */, bool FAST /* f32x4_to_u8x4_fast */>
 __global__ __launch_bounds__(kScanBlock) void quantize16_kernel(
     const float *__restrict__ data, uint64_t n_rows, uint32_t dim, uint32_t actual_dim, float alpha,
     float offset, int distance, int invert, uint32_t *__restrict__ codes32, float *__restrict__ offsets,
     uint64_t row0) {
+    const float r_alpha = 1.0f / alpha;
     const int lane = threadIdx.x & 63, sub = lane & 15, rslot = lane >> 4;
     const uint64_t wave = ((uint64_t)blockIdx.x * kScanBlock + threadIdx.x) >> 6;
     if (wave * 4 >= n_rows) return;
@@ -703,11 +734,14 @@ __global__ __launch_bounds__(kScanBlock) void quantize16_kernel(
             if (d >= dwords) break;
             uint32_t packed;
             if (d < f4) {
-                const uint32_t c0 = f32_to_u8(f[j].x, alpha, offset), c1 = f32_to_u8(f[j].y, alpha, offset),
-                               c2 = f32_to_u8(f[j].z, alpha, offset), c3 = f32_to_u8(f[j].w, alpha, offset);
-                packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-                s1 += c0 + c1 + c2 + c3;
-                s2 += c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+                if (FAST) {
+                    packed = f32x4_to_u8x4_fast(f[j], alpha, offset, r_alpha);
+                } else {
+                    packed = f32_to_u8(f[j].x, alpha, offset) | (f32_to_u8(f[j].y, alpha, offset) << 8) |
+                             (f32_to_u8(f[j].z, alpha, offset) << 16) | (f32_to_u8(f[j].w, alpha, offset) << 24);
+                }
+                s1 = __builtin_amdgcn_udot4(packed, 0x01010101u, s1, false);  // sum of the four codes
+                s2 = __builtin_amdgcn_udot4(packed, packed, s2, false);       // sum of their squares
             } else {
                 packed = pad_dword;
                 s1 += 4 * pad_code;
@@ -1414,10 +1448,19 @@ qamd_status launch_quantize(qamd_u8 *h, const float *src, uint64_t nr, uint64_t 
         const uint64_t waves = (nr + 3) / 4;
         const unsigned grid = (unsigned)((waves + kScanBlock / 64 - 1) / (kScanBlock / 64));
         const uint32_t per_lane = (uint32_t)((h->meta.actual_dim / 4 + 15) / 16);  // float4 per lane
+        // the division-free conversion needs a normal alpha well inside the exponent range (f32_to_u8_fast)
+        const bool fast = alpha >= 8.673617379884035e-19f && alpha <= 1.152921504606847e+18f;  // 2^-60 .. 2^60
 #define QAMD_Q16(IT)                                                                                          \
-    hipLaunchKernelGGL(quantize16_kernel<IT>, dim3(grid), dim3(kScanBlock), 0, s, src, nr, (uint32_t)dim,     \
-                       (uint32_t)h->meta.actual_dim, alpha, offset, vp.distance_type, vp.invert,              \
-                       h->codes.as<uint32_t>(), h->offsets.as<float>(), r0)
+    do {                                                                                                      \
+        if (fast)                                                                                             \
+            hipLaunchKernelGGL((quantize16_kernel<IT, true>), dim3(grid), dim3(kScanBlock), 0, s, src, nr,    \
+                               (uint32_t)dim, (uint32_t)h->meta.actual_dim, alpha, offset, vp.distance_type,  \
+                               vp.invert, h->codes.as<uint32_t>(), h->offsets.as<float>(), r0);               \
+        else                                                                                                  \
+            hipLaunchKernelGGL((quantize16_kernel<IT, false>), dim3(grid), dim3(kScanBlock), 0, s, src, nr,   \
+                               (uint32_t)dim, (uint32_t)h->meta.actual_dim, alpha, offset, vp.distance_type,  \
+                               vp.invert, h->codes.as<uint32_t>(), h->offsets.as<float>(), r0);               \
+    } while (0)
         if (per_lane <= 2) QAMD_Q16(2);
         else if (per_lane <= 4) QAMD_Q16(4);
         else if (per_lane <= 6) QAMD_Q16(6);

@@ -336,3 +336,41 @@ def test_cosine_is_normalised_dot(qo):
     assert np.max(np.abs(got - true_cos)) < 0.01
     top = np.argsort(-got)[:10]
     assert len(set(top) & set(np.argsort(-true_cos)[:20])) >= 8  # recall sanity, as ann_benchmark's same_10
+
+
+def test_division_free_quantize_is_exact_at_every_code_boundary(qo):
+    """quantize16_kernel converts with (v - offset) * (1 / alpha) and redoes the reference's division
+    ((v - offset) / alpha, encoded_vectors_u8.rs:234-237) only inside a 2^-15 band around the integers.
+    Adversarial sweep: for several (alpha, offset), every boundary k = -2 .. 130, the f32 values within +-6 ulp of
+    offset + alpha * k (where a reciprocal-multiply alone WOULD flip codes), plus specials; alphas outside
+    2^-60 .. 2^60 take the exact kernel.  Codes and vector_offset must equal the oracle's byte for byte."""
+    rng = np.random.default_rng(5)
+    pairs = [(1.0 / 127.0, 0.0), (float(np.float32(0.999999) / np.float32(127.0)), 1e-7), (0.0078125, -0.5),
+             (3.1415927e-3, 2.7182817), (1.7e-5, -1234.5), (9.313226e-10, 0.25), (123456.789, -1e7),
+             (1e-25, 0.0), (1e25, 3.0), (float(np.float32(2.0) ** -70), 0.0)]
+    for alpha, offset in pairs:
+        a32, o32 = np.float32(alpha), np.float32(offset)
+        vals = []
+        for k in range(-2, 131):
+            centre = np.float32(np.float64(o32) + np.float64(a32) * k)
+            bits = centre.view(np.int32)
+            for d in range(-6, 7):
+                vals.append(np.int32(bits + d).view(np.float32))
+        vals += [np.float32(x) for x in (np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-45, -1e-45, 3.4e38, -3.4e38)]
+        vals = np.array(vals, dtype=np.float32)
+        vals = vals[np.isfinite(vals) | np.isnan(vals) | np.isinf(vals)]
+        dim = 64
+        n = (vals.size + dim - 1) // dim + 64
+        data = rng.uniform(float(o32) - float(a32), float(o32) + 128 * float(a32), (n, dim)).astype(np.float32)
+        data.reshape(-1)[:vals.size] = vals
+        for dist in (D.Dot, D.L2):
+            enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, False), alpha_offset=(float(a32), float(o32)))
+            rows, _meta = qo.u8_encode_with(data, int(dist), False, float(a32), float(o32))
+            got = enc.storage_bytes()
+            assert np.array_equal(got[:, 4:], rows[:, 4:]), f"codes differ for alpha={alpha} offset={offset}"
+            assert np.array_equal(got, rows), f"vector_offset differs for alpha={alpha} offset={offset}"
+    # random data at a realistic scale, 2M values: the fast and the exact conversion must agree everywhere
+    data = rng.random((4096, 512), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(512, 4096, D.Dot, False))
+    rows, _ = qo.u8_encode(data, qo.DOT, False)
+    assert np.array_equal(enc.storage_bytes(), rows)
