@@ -615,49 +615,91 @@ __global__ __launch_bounds__(kBlock) void pq_restride_kernel(const uint8_t *__re
 // group with the same partial boundaries, one thread per chunk adds up the shifts.  Given the
 // same sample rows and no empty cluster the centroids equal the reference's bit for bit.
 
-// Step 1: per chunk, the rows of every centroid in ascending row order.
+// Step 1: per chunk, the rows of every centroid in ascending row order (a stable counting sort).
 //   order[c][.]: row ids grouped by centroid; start[c][kc] .. start[c][kc+1]: centroid kc's group.
-// One 256-thread workgroup per chunk; thread kc scans the chunk's assignment column (staged in
-// LDS, S bytes) twice: count, then fill.
-__global__ __launch_bounds__(kCentroids) void km_group_kernel(const uint8_t *__restrict__ assign /*[S][m]*/, uint32_t S,
-                                                             uint32_t m, const int *__restrict__ done,
-                                                             uint32_t *__restrict__ order /*[m][S]*/,
-                                                             uint32_t *__restrict__ start /*[m][257]*/) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t col[];  // S bytes (+ padding to a whole dword)
-    __shared__ uint32_t cum[kCentroids];
-    const uint32_t c = blockIdx.x, kc = threadIdx.x;
+// The sample's rows are cut into P segments; workgroup (chunk c, segment p) stages its piece of the
+// chunk's assignment column in LDS and thread kc scans it -- sixteen rows per 16-byte LDS read, all
+// four bytes of a dword compared at once (x ^ kc*0x01010101 has a zero byte exactly where the row is
+// assigned to kc).  km_count_kernel counts, km_fill_kernel turns the counts into positions (segment p
+// of centroid kc starts after every earlier centroid and after the earlier segments of kc: ascending
+// row order is kept) and writes the row ids.  Round 2 had one workgroup per chunk and a byte-wise
+// compare: 621 us per iteration at 10 000 x 96 chunks; this form: see DESIGN 3.4.
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {  // 0x80 in every byte of v that is zero (exact)
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+constexpr uint32_t kKmMaxSegments = 16;
+
+// LDS image of segment [lo, hi) of column c, as dwords; bytes past `hi` are filled with `fill`.
+__device__ __forceinline__ void km_stage_column(const uint8_t *__restrict__ assign, uint32_t m, uint32_t c, uint32_t lo,
+                                                uint32_t hi, uint32_t words, uint8_t *col) {
+    for (uint32_t i = threadIdx.x; i < words * 4; i += kCentroids) col[i] = lo + i < hi ? assign[(size_t)(lo + i) * m + c] : 0;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kCentroids) void km_count_kernel(const uint8_t *__restrict__ assign /*[S][m]*/, uint32_t S,
+                                                             uint32_t m, uint32_t seg_rows, const int *__restrict__ done,
+                                                             uint32_t *__restrict__ cnt /*[m][P][256]*/) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t col[];
+    const uint32_t c = blockIdx.x, p = blockIdx.y, P = gridDim.y, kc = threadIdx.x;
     if (done[c]) return;  // uniform per workgroup
-    const uint32_t S4 = (S + 3) / 4;
-    for (uint32_t s0 = kc; s0 < S4 * 4; s0 += kCentroids) col[s0] = s0 < S ? assign[(size_t)s0 * m + c] : 0;
-    __syncthreads();
-    // every thread scans the whole column (an LDS broadcast read per dword, four rows each); rows past S
-    // sit in the padding of the last dword and are masked out
-    const uint32_t *col32 = reinterpret_cast<const uint32_t *>(col);
-    auto hits = [&](uint32_t w, uint32_t x) -> uint32_t {  // bit b set: row 4w + b is assigned to kc
-        uint32_t h = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < 4; b++) h |= (((x >> (8 * b)) & 255u) == kc && 4 * w + b < S) ? (1u << b) : 0u;
-        return h;
-    };
+    const uint32_t lo = min(p * seg_rows, S), hi = min(lo + seg_rows, S), n_rows = hi - lo;
+    const uint32_t words = (n_rows + 15) / 16 * 4;  // whole 16-byte pieces
+    km_stage_column(assign, m, c, lo, hi, words, col);
+    const uint32_t kc4 = kc * 0x01010101u;
+    const uint4 *col4 = reinterpret_cast<const uint4 *>(col);
     uint32_t n = 0;
-    for (uint32_t w = 0; w < S4; w++) n += __builtin_popcount(hits(w, col32[w]));
-    cum[kc] = n;
+    for (uint32_t w = 0; w < words / 4; w++) {
+        const uint4 x = col4[w];  // every thread reads the same address: an LDS broadcast
+        n += __builtin_popcount(zero_bytes(x.x ^ kc4)) + __builtin_popcount(zero_bytes(x.y ^ kc4)) +
+             __builtin_popcount(zero_bytes(x.z ^ kc4)) + __builtin_popcount(zero_bytes(x.w ^ kc4));
+    }
+    if (kc == 0) n -= words * 4 - n_rows;  // the zero padding past the segment looks like centroid 0
+    cnt[((size_t)c * P + p) * kCentroids + kc] = n;
+}
+
+__global__ __launch_bounds__(kCentroids) void km_fill_kernel(const uint8_t *__restrict__ assign /*[S][m]*/, uint32_t S,
+                                                            uint32_t m, uint32_t seg_rows, const int *__restrict__ done,
+                                                            const uint32_t *__restrict__ cnt /*[m][P][256]*/,
+                                                            uint32_t *__restrict__ order /*[m][S]*/,
+                                                            uint32_t *__restrict__ start /*[m][257]*/) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t col[];
+    __shared__ uint32_t cum[kCentroids];
+    const uint32_t c = blockIdx.x, p = blockIdx.y, P = gridDim.y, kc = threadIdx.x;
+    if (done[c]) return;
+    uint32_t total = 0, before = 0;  // rows of centroid kc in all segments / in the segments before this one
+    for (uint32_t q = 0; q < P; q++) {
+        const uint32_t v = cnt[((size_t)c * P + q) * kCentroids + kc];
+        total += v;
+        if (q < p) before += v;
+    }
+    cum[kc] = total;
     __syncthreads();
-    for (int off = 1; off < kCentroids; off <<= 1) {  // inclusive scan
+    for (int off = 1; off < kCentroids; off <<= 1) {  // inclusive scan over the centroids
         const uint32_t v = (int)kc >= off ? cum[kc - off] : 0;
         __syncthreads();
         cum[kc] += v;
         __syncthreads();
     }
-    uint32_t pos = cum[kc] - n;
-    start[(size_t)c * (kCentroids + 1) + kc] = pos;
-    if (kc == kCentroids - 1) start[(size_t)c * (kCentroids + 1) + kCentroids] = cum[kc];
+    const uint32_t first = cum[kc] - total;
+    if (p == 0) {
+        start[(size_t)c * (kCentroids + 1) + kc] = first;
+        if (kc == kCentroids - 1) start[(size_t)c * (kCentroids + 1) + kCentroids] = cum[kc];
+    }
+    const uint32_t lo = min(p * seg_rows, S), hi = min(lo + seg_rows, S), n_rows = hi - lo;
+    const uint32_t words = (n_rows + 15) / 16 * 4;
+    km_stage_column(assign, m, c, lo, hi, words, col);
+    const uint32_t kc4 = kc * 0x01010101u;
+    const uint32_t *col32 = reinterpret_cast<const uint32_t *>(col);
     uint32_t *dst = order + (size_t)c * S;
-    for (uint32_t w = 0; w < S4; w++) {
-        const uint32_t h = hits(w, col32[w]);
-#pragma unroll
-        for (uint32_t b = 0; b < 4; b++)
-            if (h & (1u << b)) dst[pos++] = 4 * w + b;
+    uint32_t pos = first + before;
+    for (uint32_t w = 0; w < words; w++) {
+        uint32_t z = zero_bytes(col32[w] ^ kc4);
+        while (z) {  // rare: one row in 256 belongs to kc
+            const uint32_t b = (uint32_t)__builtin_ctz(z) >> 3;
+            z &= z - 1;
+            const uint32_t row = lo + 4 * w + b;
+            if (row < hi) dst[pos++] = row;
+        }
     }
 }
 
@@ -707,17 +749,49 @@ __global__ __launch_bounds__(kBlock) void km_update_kernel(const float *__restri
     cen[i] = nv;
 }
 
-// Step 3: the chunk's total shift, a sequential f32 sum over [centroid][j] (:125-135).
-__global__ __launch_bounds__(64) void km_shift_sum_kernel(const float *__restrict__ shift, uint32_t dim,
-                                                         uint32_t chunk_size, uint32_t m, const int *__restrict__ done,
-                                                         float *__restrict__ diff /*[m]*/) {
-    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= m || done[c]) return;
-    const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo);
+// Step 3: the chunk's total shift, a sequential f32 sum over [centroid][j] (:125-135), and the stopping rule
+// (:136: done once the shift is below KMEANS_ACCURACY).  One 256-thread workgroup per chunk gathers the
+// 256 x len values into LDS in summation order, 4096 at a time; thread 0 adds them up one after the other
+// (the order is the reference's; only the loads are parallel).  Round 2: one thread per chunk doing the 2048
+// dependent global loads itself, 201 us per iteration.  The kernel also keeps the device-side state of the
+// iteration: done[c], and in `progress` the number of chunks still running after this iteration.
+constexpr uint32_t kKmShiftTile = 4096;
+__global__ __launch_bounds__(kCentroids) void km_shift_sum_kernel(const float *__restrict__ shift, uint32_t dim,
+                                                                 uint32_t chunk_size, uint32_t m, int *__restrict__ done,
+                                                                 float *__restrict__ diff /*[m]*/, float accuracy,
+                                                                 uint32_t *__restrict__ running /* chunks not done, device */) {
+    __shared__ __attribute__((aligned(16))) float vals[kKmShiftTile];
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    if (done[c]) return;  // uniform per workgroup
+    const uint32_t lo = c * chunk_size, len = min(chunk_size, dim - lo), total = (uint32_t)kCentroids * len;
     float sum = 0.0f;
-    for (uint32_t kc = 0; kc < (uint32_t)kCentroids; kc++)
-        for (uint32_t j = 0; j < len; j++) sum += shift[(size_t)kc * dim + lo + j];
-    diff[c] = sum;
+    for (uint32_t base = 0; base < total; base += kKmShiftTile) {
+        const uint32_t n = min(kKmShiftTile, total - base);
+        for (uint32_t i = t; i < n; i += kCentroids) {
+            const uint32_t v = base + i, kc = v / len, j = v - kc * len;
+            vals[i] = shift[(size_t)kc * dim + lo + j];
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t i = 0;
+            for (; i + 4 <= n; i += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(vals + i);
+                sum += x.x;
+                sum += x.y;
+                sum += x.z;
+                sum += x.w;
+            }
+            for (; i < n; i++) sum += vals[i];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        diff[c] = sum;
+        if (sum < accuracy) {
+            done[c] = 1;
+            atomicSub(running, 1u);
+        }
+    }
 }
 
 // The k-means sample: n_out evenly strided rows of a device-resident [count][dim] array.
@@ -1002,13 +1076,28 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
 }
 
 // kmeans (kmeans.rs:7-47) for every chunk at once on a device-resident sample [S][dim].
+// The iteration state (done[c], the number of running chunks) lives on the device; every iteration
+// publishes the running count into one word of mapped host memory, and the host reads iteration i's
+// word only after it has enqueued iteration i + 1: the GPU never waits for the host (round 2: two
+// synchronisations per iteration).  An iteration enqueued after the last chunk has converged finds
+// every done[c] set and does nothing, so the centroids are exactly those of the reference's loop.
+__global__ void km_publish_kernel(const uint32_t *__restrict__ running, uint32_t *__restrict__ slot) {
+    __hip_atomic_store(slot, *running, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 qamd_status train_from_sample(qamd_pq *h, const float *sample, uint32_t S, qamd_stop_fn stop, void *stop_user,
                               hipStream_t s) {
     const uint64_t dim = h->vp.dim;
     const uint32_t m = (uint32_t)h->m;
     const uint32_t workers = std::max<uint32_t>(1, h->kmeans_workers);
     const size_t ncen = (size_t)kCentroids * dim;
-    DevBuf cen, shift, done, diff, assign, order, start, empties, pair_table;
+    // segments of the sample per chunk for the grouping step: enough workgroups for two per CU, segments of >= 1024 rows
+    const uint32_t want_wgs = (uint32_t)device_info().cu_count * 2;
+    uint32_t P = std::max<uint32_t>(1, std::min<uint32_t>(kKmMaxSegments, (want_wgs + m - 1) / std::max<uint32_t>(m, 1)));
+    P = std::max<uint32_t>(1, std::min<uint32_t>(P, (S + 1023) / 1024));
+    const uint32_t seg_rows = (uint32_t)round_up((S + P - 1) / P, 16);
+    P = (S + seg_rows - 1) / seg_rows;
+    DevBuf cen, shift, done, diff, assign, order, start, counters, cnt, pair_table;
     QAMD_TRY(cen.alloc(ncen * 4));
     QAMD_TRY(shift.alloc(ncen * 4));
     QAMD_TRY(done.alloc((size_t)m * 4, true));
@@ -1016,39 +1105,69 @@ qamd_status train_from_sample(qamd_pq *h, const float *sample, uint32_t S, qamd_
     QAMD_TRY(assign.alloc((size_t)S * m));
     QAMD_TRY(order.alloc((size_t)S * m * 4));
     QAMD_TRY(start.alloc((size_t)m * (kCentroids + 1) * 4));
-    QAMD_TRY(empties.alloc(4, true));
+    QAMD_TRY(cnt.alloc((size_t)m * P * kCentroids * 4));
+    QAMD_TRY(counters.alloc(8, true));  // [0] empty-cluster re-seeds, [1] chunks still running
+    uint32_t *empties = counters.as<uint32_t>(), *running = counters.as<uint32_t>() + 1;
+    QAMD_TRY(copy_in(running, &m, QAMD_MEM_HOST, 4, s));
+    // progress words in mapped host memory, one per iteration (0xFFFFFFFF: not published yet)
+    struct Mapped {
+        uint32_t *host = nullptr, *dev = nullptr;
+        ~Mapped() {
+            if (host) (void)hipHostFree(host);
+        }
+    } prog;
+    QAMD_HIP(hipHostMalloc(reinterpret_cast<void **>(&prog.host), kKmeansMaxIter * 4, hipHostMallocMapped));
+    QAMD_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&prog.dev), prog.host, 0));
+    memset(prog.host, 0xFF, kKmeansMaxIter * 4);
+    struct Events {
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        ~Events() {
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } evs;
+    for (hipEvent_t &e : evs.ev) QAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // initial centroids = the first 256 sample rows (kmeans.rs:25)
     QAMD_HIP(hipMemcpyAsync(cen.ptr, sample, ncen * 4, hipMemcpyDeviceToDevice, s));
     const bool cs = cs_fast_shape(dim, h->chunk_size);
-    std::vector<int> done_h(m, 0);
-    std::vector<float> diff_h(m);
+    const size_t col_lds = (size_t)round_up(seg_rows, 16);
     h->kmeans_iterations = 0;
-    for (int iter = 0; iter < kKmeansMaxIter; iter++) {
-        if (stop && stop(stop_user)) return fail(QAMD_ERR_STOPPED, "Stopped");  // kmeans.rs:29-31
+    auto iteration_done = [&](int it, bool &all) -> qamd_status {  // waits for iteration `it`, reads its progress word
+        QAMD_HIP(hipEventSynchronize(evs.ev[it & 1]));
+        const uint32_t left = *const_cast<volatile uint32_t *>(prog.host + it);
+        h->kmeans_iterations = (uint32_t)it + 1;
+        all = left == 0;
+        return QAMD_OK;
+    };
+    int enqueued = 0;
+    bool all = false;
+    for (int iter = 0; iter < kKmeansMaxIter && !all; iter++) {
+        if (stop && stop(stop_user)) {
+            (void)hipStreamSynchronize(s);  // the mapped progress words are freed on return
+            return fail(QAMD_ERR_STOPPED, "Stopped");  // kmeans.rs:29-31
+        }
         // update_indexes (:139-166) = the PQ encoder's own nearest-centroid kernel on the sample
         if (cs) QAMD_TRY(build_pair_table(cen.as<float>(), dim, h->chunk_size, m, pair_table, s));
         QAMD_TRY(launch_assign(sample, S, dim, h->chunk_size, m, cen.as<float>(), &pair_table, assign.as<uint8_t>(), m,
                                0, s));
-        hipLaunchKernelGGL(km_group_kernel, dim3(m), dim3(kCentroids), round_up(S, 4), s, assign.as<uint8_t>(), S, m, done.as<int>(),
-                           order.as<uint32_t>(), start.as<uint32_t>());
+        hipLaunchKernelGGL(km_count_kernel, dim3(m, P), dim3(kCentroids), col_lds, s, assign.as<uint8_t>(), S, m, seg_rows,
+                           done.as<int>(), cnt.as<uint32_t>());
+        hipLaunchKernelGGL(km_fill_kernel, dim3(m, P), dim3(kCentroids), col_lds, s, assign.as<uint8_t>(), S, m, seg_rows,
+                           done.as<int>(), cnt.as<uint32_t>(), order.as<uint32_t>(), start.as<uint32_t>());
         hipLaunchKernelGGL(km_update_kernel, dim3((uint32_t)((ncen + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, sample, S,
                            (uint32_t)dim, (uint32_t)h->chunk_size, m, workers, cen.as<float>(), done.as<int>(),
-                           order.as<uint32_t>(), start.as<uint32_t>(), shift.as<float>(), empties.as<uint32_t>(),
-                           (uint32_t)iter);
-        hipLaunchKernelGGL(km_shift_sum_kernel, dim3((m + 63) / 64), dim3(64), 0, s, shift.as<float>(), (uint32_t)dim,
-                           (uint32_t)h->chunk_size, m, done.as<int>(), diff.as<float>());
+                           order.as<uint32_t>(), start.as<uint32_t>(), shift.as<float>(), empties, (uint32_t)iter);
+        hipLaunchKernelGGL(km_shift_sum_kernel, dim3(m), dim3(kCentroids), 0, s, shift.as<float>(), (uint32_t)dim,
+                           (uint32_t)h->chunk_size, m, done.as<int>(), diff.as<float>(), kKmeansAccuracy, running);
+        hipLaunchKernelGGL(km_publish_kernel, dim3(1), dim3(1), 0, s, running, prog.dev + iter);
         QAMD_HIP(hipGetLastError());
-        QAMD_TRY(copy_out(diff_h.data(), QAMD_MEM_HOST, diff.ptr, (size_t)m * 4, s));
-        h->kmeans_iterations = (uint32_t)iter + 1;
-        bool all = true;
-        for (uint32_t c = 0; c < m; c++) {
-            if (!done_h[c] && diff_h[c] < kKmeansAccuracy) done_h[c] = 1;  // :136
-            all = all && done_h[c];
-        }
-        if (all) break;
-        QAMD_TRY(copy_in(done.ptr, done_h.data(), QAMD_MEM_HOST, (size_t)m * 4, s));
+        QAMD_HIP(hipEventRecord(evs.ev[iter & 1], s));
+        enqueued = iter + 1;
+        if (iter >= 1) QAMD_TRY(iteration_done(iter - 1, all));  // one iteration behind: the GPU is never idle
     }
-    QAMD_TRY(copy_out(&h->kmeans_empty_clusters, QAMD_MEM_HOST, empties.ptr, 4, s));
+    if (!all && enqueued) QAMD_TRY(iteration_done(enqueued - 1, all));
+    QAMD_HIP(hipStreamSynchronize(s));
+    QAMD_TRY(copy_out(&h->kmeans_empty_clusters, QAMD_MEM_HOST, empties, 4, s));
     std::vector<float> cen_h(ncen);
     QAMD_TRY(copy_out(cen_h.data(), QAMD_MEM_HOST, cen.ptr, ncen * 4, s));
     return set_centroids(h, cen_h.data(), s);
