@@ -95,20 +95,30 @@ def test_batch_edge_cases():
     (4992, 33_000, 33),     # 39 K-blocks: only a 32-query tile fits in LDS
     (640, 50_000, 300),     # five tiles
 ])
-def test_binary_batch_on_the_matrix_cores(dim, n, nq):
+def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
     """12 queries and more on 32k rows and more take bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
     registers, int8 MFMA, u8-style epilogue with integer operands): every list must equal the single-query
-    top-k, for the four metric variants and both directions."""
+    top-k AND the oracle's restatement of the caller loop (score_point for every row,
+    encoded_vectors_binary.rs:293-300 -> calculate_metric :219-253, then a stable best-k: ties to the
+    lower id), for the four metric variants and both directions."""
     rng = np.random.default_rng(dim + nq)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    rows = qo.bin_encode(data)
+    qbits = qo.bin_encode(queries)
     for dist, invert, largest in ((D.Dot, False, True), (D.L2, False, False), (D.Dot, True, False), (D.L1, True, True)):
         enc = qa.EncodedVectorsBin.encode(data, qa.VectorParameters(dim, n, dist, invert))
         ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30, largest=largest)
-        for qi in sorted({0, 1, min(31, nq - 1), min(32, nq - 1), nq // 2, nq - 2, nq - 1}):
+        picks = sorted({0, 1, min(31, nq - 1), min(32, nq - 1), nq // 2, nq - 2, nq - 1})
+        for j, qi in enumerate(picks):
             wi, ws = enc.topk(enc.encode_query(queries[qi]), 30, largest=largest)
             assert np.array_equal(ids[qi], wi), (dist, invert, largest, qi)
             assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (dist, invert, largest, qi)
+            if j % 3 == 0:  # the oracle: every score of the store, stable best-30
+                want = qo.bin_score_all(rows, qbits[qi], dim, int(dist), invert)
+                order = np.lexsort((np.arange(n), -want if largest else want))[:30]
+                assert np.array_equal(ids[qi], order.astype(np.uint32)), ("vs oracle", dist, invert, largest, qi)
+                assert np.array_equal(sc[qi].view(np.uint32), want[order].view(np.uint32)), ("vs oracle", dist, invert, qi)
 
 
 def test_binary_batch_of_identical_queries():

@@ -241,6 +241,66 @@ def test_c4_shard_pq_1536_m192(qo):
     _free()
 
 
+def test_c4_shard_pq_batched_topk_12m5_x_1536_m192(qo):
+    """configs[4]'s PQ leg, batched: qamd_pq_topk_batch at 12.5M x 1536 (m = 192, sliced LUT), 24 queries:
+    eight sampled queries against the exact single-query top-k (ids and score bits), the winners' scores
+    against the oracle's SSE-order LUT sum (encoded_vectors_pq.rs:405-440)."""
+    n, dim, chunk, nq, k = 12_500_000, 1536, 8, 24, 30
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(27)
+    cen = np.random.default_rng(27).random((256, dim), dtype=np.float32)
+    rows = torch.randint(0, 256, (n, 192), generator=g, device=dev, dtype=torch.uint8)
+    enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, D.Dot, False), chunk, cen)
+    queries = np.random.default_rng(28).random((nq, dim), dtype=np.float32)
+    ids, sc = enc.topk_batch(enc.encode_query_batch(queries), k)
+    assert np.all(np.diff(sc.astype(np.float64), axis=1) <= 0)
+    for j, qi in enumerate(sorted({0, nq - 1, *np.random.default_rng(5).integers(0, nq, 8).tolist()})):
+        wi, ws = enc.topk(enc.encode_query(queries[qi]), k)
+        assert np.array_equal(ids[qi], wi), f"query {qi}: ids differ from the single-query top-k"
+        assert_bits_equal(sc[qi], ws, f"query {qi}: scores")
+        if j < 3:
+            lut = qo.pq_encode_query(queries[qi], chunk, cen, qo.DOT, False)
+            win = torch.from_numpy(ids[qi].astype(np.int64)).to(dev)
+            assert_bits_equal(sc[qi], qo.pq_score_all(rows[win].cpu().numpy(), lut, order=qo.ORDER_SSE), f"query {qi} vs oracle")
+    del enc, rows
+    _free()
+
+
+def test_c3_binary_batched_topk_64q_50m_x_1024(qo):
+    """configs[3]'s store with 64 queries at once (bin_gemm_rs_kernel: bits expanded to 0/1 bytes, int8 MFMA, 64-bit
+    row offsets on 6.4 GB): sampled queries against the exact single-query top-k and against the oracle's scores of
+    the winners computed with the REFERENCE's compiled popcount kernel (impl_xor_popcnt_sse_uint128) when oracle/_ref
+    is present; plus, for one query, a full-store check that nothing better than the list's worst entry was missed."""
+    n, dim, nq, k = 50_000_000, 1024, 64, 30
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(33)
+    rows = torch.randint(0, 256, (n, 128), generator=g, device=dev, dtype=torch.uint8)
+    enc = qa.EncodedVectorsBin.from_storage(rows, qa.VectorParameters(dim, n, D.Dot, False))
+    queries = torch.randn((nq, dim), generator=g, device=dev)
+    batch = enc.encode_query_batch(queries)
+    ids, sc = enc.topk_batch(batch, k)
+    assert np.all(np.diff(sc.astype(np.float64), axis=1) <= 0)
+    qobj = None
+    for j, qi in enumerate(sorted({0, 31, 32, nq - 1, *np.random.default_rng(9).integers(0, nq, 6).tolist()})):
+        qobj = enc.encode_query(queries[qi], reuse=qobj)
+        wi, ws = enc.topk(qobj, k)
+        assert np.array_equal(ids[qi], wi), f"query {qi}: ids differ from the single-query top-k"
+        assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), f"query {qi}: scores"
+        if j < 3:
+            win = torch.from_numpy(ids[qi].astype(np.int64)).to(dev)
+            want = qo.bin_score_all(rows[win].cpu().numpy(), qobj.encoded_vector, dim, qo.DOT, False, use_ref=qo.ref() is not None)
+            assert np.array_equal(sc[qi].view(np.uint32), want.view(np.uint32)), f"query {qi} vs oracle / reference popcount"
+        if j == 0:  # nothing in the store beats the list's last entry unless it is in the list (ties: lower id wins)
+            s_all = enc.score_all(qobj, out=torch.empty(n, device=dev))
+            better = torch.nonzero(s_all > float(sc[qi][-1])).flatten().cpu().numpy()
+            assert set(better.tolist()) <= set(ids[qi].tolist())
+            del s_all
+    del enc, rows
+    _free()
+
+
 def test_c0_u8_100k_x_128_full_compare(qo):
     """configs[0]: 100k x 128 f32 -> scalar u8 + dot, every row against the reference CPU SIMD path
     (the oracle's loop over the reference's own compiled impl_score_dot_avx when oracle/_ref is
