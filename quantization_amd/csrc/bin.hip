@@ -313,19 +313,21 @@ __global__ __launch_bounds__(kBlock) void bin_pairs_kernel(const uint32_t *__res
                                                           const uint32_t *__restrict__ lists, uint32_t n_lists,
                                                           const uint32_t *__restrict__ list_rows, float dim_f, int is_dot,
                                                           int invert, const uint32_t *__restrict__ ids, uint64_t n,
-                                                          uint32_t n_rows, uint32_t row_words, float *__restrict__ out) {
-    constexpr int G = VEC16 ? 8 : 16, RW = 64 / G;
+                                                          uint32_t n_rows, uint32_t row_words, uint32_t pairs_per_block,
+                                                          float *__restrict__ out) {
+    constexpr int G = VEC16 ? 8 : 16, GROUPS = kBlock / G;
+    __shared__ uint32_t first_list;
     const int lane = threadIdx.x & 63;
-    const int sub = lane % G, rslot = lane / G;
-    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
-    for (uint64_t base = wave * RW; base < n; base += n_waves * RW) {
-        const uint64_t k = base + rslot;
-        const uint32_t row = k < n ? ids[k] : 0xFFFFFFFFu;
+    const int sub = lane % G, group = threadIdx.x / G;
+    const uint64_t p0 = (uint64_t)blockIdx.x * pairs_per_block;
+    const uint64_t p1 = p0 + pairs_per_block < n ? p0 + pairs_per_block : n;
+    uint32_t l = lists ? first_list_of_block(lists, n_lists, p0, &first_list) : 0u;  // (lists.hpp)
+    for (uint64_t k = p0 + group; k < p1; k += GROUPS) {
+        const uint32_t row = ids[k];
         bool ok = row < n_rows;
         const uint32_t *qp = q_single;
         if (lists) {
-            const uint32_t l = k < n ? list_of_pair(lists, n_lists, (uint32_t)k) : 0u;
+            l = advance_list(lists, n_lists, l, k);
             if (list_rows) {
                 const uint32_t qr = list_rows[l];
                 ok = ok && qr < n_rows;
@@ -339,23 +341,27 @@ __global__ __launch_bounds__(kBlock) void bin_pairs_kernel(const uint32_t *__res
         if (VEC16) {
             const uint32_t chunks = row_words / 4;
             const uint4 *p4 = reinterpret_cast<const uint4 *>(p), *q4 = reinterpret_cast<const uint4 *>(qp);
-            for (uint32_t c0 = sub; c0 < chunks; c0 += 4 * G) {
-                uint4 v[4], qv[4];
+            if (chunks <= (uint32_t)G) {  // the common rows (<= 1024 bits): one 16-byte piece per lane
+                if ((uint32_t)sub < chunks) acc = xpop16(p4[sub], q4[sub], acc);
+            } else {
+                for (uint32_t c0 = sub; c0 < chunks; c0 += 4 * G) {
+                    uint4 v[4], qv[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t c = c0 + j * G, cc = c < chunks ? c : chunks - 1;
-                    v[j] = p4[cc];
-                    qv[j] = q4[cc];
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t c = c0 + j * G, cc = c < chunks ? c : chunks - 1;
+                        v[j] = p4[cc];
+                        qv[j] = q4[cc];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (c0 + j * G < chunks) acc = xpop16(v[j], qv[j], acc);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (c0 + j * G < chunks) acc = xpop16(v[j], qv[j], acc);
             }
         } else {
             for (uint32_t w = sub; w < row_words; w += G) acc += __popc(p[w] ^ qp[w]);
         }
         acc = group_sum<G>(acc);
-        if (sub == 0 && k < n) out[k] = ok ? metric(acc, dim_f, is_dot, invert) : __builtin_nanf("");
+        if (sub == 0) out[k] = ok ? metric(acc, dim_f, is_dot, invert) : __builtin_nanf("");
     }
 }
 
@@ -511,12 +517,13 @@ qamd_status pairs_launch(const qamd_bin *h, const uint32_t *q_single, const uint
                          uint64_t n, float *out_dev, hipStream_t s) {
     if (n == 0) return QAMD_OK;
     const bool vec16 = h->ds % 16 == 0;
-    const int grid = grid_for((n + (vec16 ? 7 : 3)) / (vec16 ? 8 : 4), kBlock / 64, 8);
+    const uint32_t ppb = pairs_per_block(n, vec16 ? 32 : 16);  // lane groups per workgroup
+    const unsigned grid = (unsigned)((n + ppb - 1) / ppb);
 #define QAMD_BIN_PAIRS(V)                                                                                          \
     hipLaunchKernelGGL(bin_pairs_kernel<V>, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint32_t>(), q_single, q_batch, \
                        (uint32_t)q_stride, lists, n_lists, list_rows, (float)h->vp.dim,                            \
                        (int)(h->vp.distance_type == QAMD_DOT), h->vp.invert, ids_dev, n, (uint32_t)h->count,        \
-                       (uint32_t)(h->ds / 4), out_dev)
+                       (uint32_t)(h->ds / 4), ppb, out_dev)
     if (vec16) QAMD_BIN_PAIRS(true);
     else QAMD_BIN_PAIRS(false);
 #undef QAMD_BIN_PAIRS

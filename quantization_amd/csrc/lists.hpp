@@ -16,6 +16,8 @@
 // the device-side pair -> list lookup.
 #pragma once
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace qamd {
@@ -41,7 +43,31 @@ __device__ __forceinline__ uint32_t list_of_pair(const uint32_t *__restrict__ of
     }
     return lo;
 }
+
+// The kernels give every workgroup `pairs_per_block` consecutive pairs: ONE binary search per workgroup
+// (its first pair), after which each lane group walks forward as its pair index grows -- a search per pair
+// is ~log2(n_lists) dependent loads in front of every row fetch.
+__device__ __forceinline__ uint32_t first_list_of_block(const uint32_t *__restrict__ offsets, uint32_t n_lists, uint64_t p0,
+                                                        uint32_t *lds_word) {
+    if (threadIdx.x == 0) *lds_word = list_of_pair(offsets, n_lists, (uint32_t)p0);
+    __syncthreads();
+    return *lds_word;
+}
+__device__ __forceinline__ uint32_t advance_list(const uint32_t *__restrict__ offsets, uint32_t n_lists, uint32_t l, uint64_t p) {
+    while (l + 1 < n_lists && offsets[l + 1] <= (uint32_t)p) l++;
+    return l;
+}
 #endif
+
+// Pairs per workgroup for a burst of n pairs: one to four passes of the workgroup's `groups` lane groups.  Small bursts get
+// one pass (every pair in flight at once: they are latency-bound); large ones at most four -- workgroups are dispatched in
+// pair order, so the resident ones cover a compact window of the lists (a PQ burst re-reads each list's 96 KiB LUT from L2
+// only while that window is a few dozen lists wide).
+inline uint32_t pairs_per_block(uint64_t n, uint32_t groups, uint32_t max_passes = 4) {
+    const uint64_t one_pass_blocks = (n + groups - 1) / groups, resident = (uint64_t)device_info().cu_count * 8;
+    const uint64_t passes = std::min<uint64_t>(max_passes, std::max<uint64_t>(1, one_pass_blocks / resident));
+    return (uint32_t)(groups * passes);
+}
 
 // Brings (list_offsets, ids, rows) and the output of one burst to the device, runs `launch(args)` on
 // `s`, and delivers the scores.

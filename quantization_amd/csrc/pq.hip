@@ -493,17 +493,21 @@ __global__ __launch_bounds__(kBlock) void pq_lists_kernel(const uint32_t *__rest
                                                          const float *__restrict__ luts, uint64_t lut_stride,
                                                          const uint32_t *__restrict__ lists, uint32_t n_lists,
                                                          const uint32_t *__restrict__ ids, uint64_t n, uint32_t n_rows,
-                                                         uint32_t m, uint32_t row_words, float *__restrict__ out) {
+                                                         uint32_t m, uint32_t row_words, uint32_t pairs_per_block,
+                                                         float *__restrict__ out) {
+    constexpr int GROUPS = kBlock / 4;
+    __shared__ uint32_t first_list;
     const int lane = threadIdx.x & 63;
-    const int k = lane & 3, rslot = lane >> 2;
-    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const int k = lane & 3, group = threadIdx.x / 4;
+    const uint64_t p0 = (uint64_t)blockIdx.x * pairs_per_block;
+    const uint64_t p1 = p0 + pairs_per_block < n ? p0 + pairs_per_block : n;
+    uint32_t l = first_list_of_block(lists, n_lists, p0, &first_list);  // (lists.hpp)
     const uint32_t groups = m / 4, shift = 8 * k;
-    for (uint64_t base = wave * 16; base < n; base += n_waves * 16) {
-        const uint64_t idx = base + rslot;
-        const uint32_t row = idx < n ? ids[idx] : 0xFFFFFFFFu;
+    // all four lanes of a pair stay in the loop together (the quad exchanges below): the bound is the pair's
+    for (uint64_t idx = p0 + group; idx < p1; idx += GROUPS) {
+        const uint32_t row = ids[idx];
         const bool ok = row < n_rows;
-        const uint32_t l = idx < n ? list_of_pair(lists, n_lists, (uint32_t)idx) : 0u;
+        l = advance_list(lists, n_lists, l, idx);
         const float *lut = luts + (size_t)l * lut_stride;
         const float *lut_k = lut + k * kCentroids;
         const uint32_t *p = rows32 + (uint64_t)(ok ? row : 0) * row_words;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void pq_lists_kernel(const uint32_t *__rest
         }
         float a = acc + __shfl_xor(acc, 2, 64);  // (l0 + l2) + (l1 + l3)  (:430-432)
         float sc = a + __shfl_xor(a, 1, 64);
-        if (k == 0 && idx < n) {
+        if (k == 0) {
             if (ok) {
                 for (uint32_t c = groups * 4; c < m; c++) {  // tail (:434-438)
                     const uint32_t code = (p[c >> 2] >> (8 * (c & 3))) & 255u;
@@ -552,21 +556,26 @@ __global__ __launch_bounds__(kBlock) void pq_internal_pairs_kernel(const uint8_t
                                                                   const uint32_t *__restrict__ lists, uint32_t n_lists,
                                                                   const uint32_t *__restrict__ list_rows,
                                                                   const uint32_t *__restrict__ ids, uint64_t n,
-                                                                  uint32_t n_rows, float *__restrict__ out) {
-    constexpr int G = 16, RW = 4;
+                                                                  uint32_t n_rows, uint32_t pairs_per_block,
+                                                                  float *__restrict__ out) {
+    constexpr int G = 16, GROUPS = kBlock / G;
+    __shared__ uint32_t first_list;
     const int lane = threadIdx.x & 63;
-    const int sub = lane % G, rslot = lane / G;
-    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
-    for (uint64_t base = wave * RW; base < n; base += n_waves * RW) {
-        const uint64_t k = base + rslot;
-        const uint32_t rj = k < n ? ids[k] : 0xFFFFFFFFu;
+    const int sub = lane % G, group = threadIdx.x / G;
+    const uint64_t p0 = (uint64_t)blockIdx.x * pairs_per_block;
+    const uint64_t p1 = p0 + pairs_per_block < n ? p0 + pairs_per_block : n;
+    uint32_t l = lists ? first_list_of_block(lists, n_lists, p0, &first_list) : 0u;  // (lists.hpp)
+    for (uint64_t k = p0 + group; k < p1; k += GROUPS) {
+        const uint32_t rj = ids[k];
         uint32_t ri = single_row;
-        if (lists) ri = list_rows[k < n ? list_of_pair(lists, n_lists, (uint32_t)k) : 0u];
+        if (lists) {
+            l = advance_list(lists, n_lists, l, k);
+            ri = list_rows[l];
+        }
         const bool ok = rj < n_rows && ri < n_rows;
         const uint8_t *ci = rows + (size_t)(ok ? ri : 0u) * row_stride, *cj = rows + (size_t)(ok ? rj : 0u) * row_stride;
         float total = 0.0f;
-        for (uint32_t c0 = 0; c0 < m; c0 += G) {  // wave-uniform trip count: the shuffles below are executed by all lanes
+        for (uint32_t c0 = 0; c0 < m; c0 += G) {  // group-uniform trip count: the shuffles below involve all 16 lanes
             const uint32_t c = c0 + sub;
             float sc = 0.0f;
             if (c < m) {
@@ -580,12 +589,12 @@ __global__ __launch_bounds__(kBlock) void pq_internal_pairs_kernel(const uint8_t
                     for (uint32_t t = 0; t < len; t++) sc += (a[t] - b[t]) * (a[t] - b[t]);
             }
 #pragma unroll
-            for (int l = 0; l < G; l++) {
-                const float v = __shfl(sc, l, G);
-                if (c0 + l < m) total += v;
+            for (int q = 0; q < G; q++) {
+                const float v = __shfl(sc, q, G);
+                if (c0 + q < m) total += v;
             }
         }
-        if (sub == 0 && k < n) out[k] = ok ? (invert ? -total : total) : __builtin_nanf("");
+        if (sub == 0) out[k] = ok ? (invert ? -total : total) : __builtin_nanf("");
     }
 }
 
@@ -1540,11 +1549,11 @@ qamd_status internal_pairs_launch(const qamd_pq *h, uint32_t single_row, const u
                                   const uint32_t *list_rows, const uint32_t *ids_dev, uint64_t n, float *out_dev,
                                   hipStream_t s) {
     if (n == 0) return QAMD_OK;
-    const int grid = grid_for((n + 3) / 4, kBlock / 64, 8);
-    hipLaunchKernelGGL(pq_internal_pairs_kernel, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint8_t>(), (uint32_t)h->ds,
-                       (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
-                       h->vp.distance_type, h->vp.invert, single_row, lists, n_lists, list_rows, ids_dev, n,
-                       (uint32_t)h->count, out_dev);
+    const uint32_t ppb = pairs_per_block(n, 16);  // 16 lane groups per workgroup
+    hipLaunchKernelGGL(pq_internal_pairs_kernel, dim3((unsigned)((n + ppb - 1) / ppb)), dim3(kBlock), 0, s,
+                       h->rows.as<uint8_t>(), (uint32_t)h->ds, (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m,
+                       h->centroids.as<float>(), h->vp.distance_type, h->vp.invert, single_row, lists, n_lists, list_rows,
+                       ids_dev, n, (uint32_t)h->count, ppb, out_dev);
     QAMD_HIP(hipGetLastError());
     return QAMD_OK;
 }
@@ -1865,15 +1874,16 @@ qamd_status qamd_pq_score_ids_batch(const qamd_pq *h, const qamd_pq_query_batch 
     const size_t per = (size_t)h->m * kCentroids;
     return run_lists(list_offsets, n_lists, ids, n_ids, nullptr, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
         const uint32_t row_words = (uint32_t)(h->ds / 4);
-        const int grid = grid_for((a.n_pairs + 15) / 16, kBlock / 64, 8);
+        const uint32_t ppb = pairs_per_block(a.n_pairs, 64, 1);  // 64 lane groups per workgroup, one pass: the window of LUTs in use stays L2-sized
+        const unsigned grid = (unsigned)((a.n_pairs + ppb - 1) / ppb);
         if (row_words % 4 == 0)
             hipLaunchKernelGGL(pq_lists_kernel<true>, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint32_t>(), b->luts.as<float>(),
                                (uint64_t)per, a.offsets, a.n_lists, a.ids, a.n_pairs, (uint32_t)h->count, (uint32_t)h->m,
-                               row_words, a.out);
+                               row_words, ppb, a.out);
         else
             hipLaunchKernelGGL(pq_lists_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->rows.as<uint32_t>(), b->luts.as<float>(),
                                (uint64_t)per, a.offsets, a.n_lists, a.ids, a.n_pairs, (uint32_t)h->count, (uint32_t)h->m,
-                               row_words, a.out);
+                               row_words, ppb, a.out);
         QAMD_HIP(hipGetLastError());
         return QAMD_OK;
     });

@@ -525,34 +525,41 @@ __global__ __launch_bounds__(kBlock) void u8_scan_avx2_lanes_kernel(
     }
 }
 
-// Random access: out[k] = score(query of pair k, ids[k]).  One 16-lane group per pair, up to four
-// 16-byte pieces of the row (and of the query) in flight per lane.  Which query a pair is scored
-// against:
+// Random access: out[k] = score(query of pair k, ids[k]).  One 16-lane group per pair; ITERS =
+// ceil(row_chunks / 16) is a template parameter so that all of a row's 16-byte pieces (and the query's)
+// are in flight at once with no clamped duplicate loads (ITERS = 0: any row length, four-deep batches).
+// Which query a pair is scored against:
 //   lists == nullptr            one query for every pair (score_ids): q_single / q_off_single, which
 //                               may point into the store itself (score_internal: "query" = row i);
 //   lists, list_rows == nullptr query l of a batch for the pairs of list l (score_ids_batch);
 //   lists, list_rows            stored row list_rows[l] for the pairs of list l (score_internal_ids_batch).
+// A workgroup takes `pairs_per_block` consecutive pairs; with lists it finds the list of its first pair
+// by ONE binary search (thread 0, through LDS) and every group then walks forward from there as its
+// pair index grows -- a binary search per pair was ten dependent loads in front of every row fetch
+// (1M random pairs: 0.26 ms; this form: profiles/r03_bursts.jsonl).
 // Same integer sum and the same f32 epilogue as the scan => the same score bits.
-template <bool IS_L1>
+template <bool IS_L1, int ITERS>
 __global__ __launch_bounds__(kBlock) void u8_score_pairs_kernel(
     const uint4 *__restrict__ codes, const float *__restrict__ offsets, const uint4 *q_single, const float *q_off_single,
     const uint8_t *__restrict__ q_batch, uint32_t q_pitch, const float *__restrict__ q_offs,
     const uint32_t *__restrict__ lists, uint32_t n_lists, const uint32_t *__restrict__ list_rows, float multiplier,
     float diff, int mode, const uint32_t *__restrict__ ids, uint64_t n_ids, uint32_t n_rows, uint32_t row_chunks,
-    float *__restrict__ out) {
-    constexpr int G = 16, RW = 4;
+    uint32_t pairs_per_block, float *__restrict__ out) {
+    constexpr int G = 16, GROUPS = kBlock / G;
+    __shared__ uint32_t first_list;
     const int lane = threadIdx.x & 63;
-    const int sub = lane % G, rslot = lane / G;
-    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
-    for (uint64_t base = wave * RW; base < n_ids; base += n_waves * RW) {
-        const uint64_t k = base + rslot;
-        const uint32_t row = k < n_ids ? ids[k] : 0xFFFFFFFFu;
+    const int sub = lane % G, group = threadIdx.x / G;
+    const uint64_t p0 = (uint64_t)blockIdx.x * pairs_per_block;
+    const uint64_t p1 = p0 + pairs_per_block < n_ids ? p0 + pairs_per_block : n_ids;
+    uint32_t l = lists ? first_list_of_block(lists, n_lists, p0, &first_list) : 0u;
+    const float q_off_one = lists ? 0.0f : *q_off_single;
+    for (uint64_t k = p0 + group; k < p1; k += GROUPS) {
+        const uint32_t row = ids[k];
         bool ok = row < n_rows;
         const uint4 *qp = q_single;
-        float q_off = 0.0f;
+        float q_off = q_off_one;
         if (lists) {
-            const uint32_t l = k < n_ids ? list_of_pair(lists, n_lists, (uint32_t)k) : 0u;
+            l = advance_list(lists, n_lists, l, k);  // the pair index only grows: a step or two
             if (list_rows) {
                 const uint32_t qr = list_rows[l];
                 ok = ok && qr < n_rows;
@@ -563,27 +570,36 @@ __global__ __launch_bounds__(kBlock) void u8_score_pairs_kernel(
                 qp = reinterpret_cast<const uint4 *>(q_batch + (size_t)l * q_pitch);
                 q_off = q_offs[l];
             }
-        } else {
-            q_off = *q_off_single;
         }
         const uint4 *p = codes + (uint64_t)(ok ? row : 0u) * row_chunks;
         uint32_t acc = 0;
-        for (uint32_t c0 = sub; c0 < row_chunks; c0 += 4 * G) {
-            uint4 v[4], qv[4];
+        if (ITERS > 0) {
+            uint4 v[ITERS > 0 ? ITERS : 1], qv[ITERS > 0 ? ITERS : 1];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {  // unconditional loads (clamped address): all four issue back to back
-                const uint32_t c = c0 + j * G, cc = c < row_chunks ? c : row_chunks - 1;
+            for (int j = 0; j < ITERS; j++) {
+                const uint32_t c = sub + j * G, cc = c < row_chunks ? c : row_chunks - 1;  // only the last piece can be clamped
                 v[j] = p[cc];
                 qv[j] = qp[cc];
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (c0 + j * G < row_chunks) acc = IS_L1 ? sad16(v[j], qv[j], acc) : dot16(v[j], qv[j], acc);
+            for (int j = 0; j < ITERS; j++)
+                if (j + 1 < ITERS || sub + j * G < row_chunks) acc = IS_L1 ? sad16(v[j], qv[j], acc) : dot16(v[j], qv[j], acc);
+        } else {
+            for (uint32_t c0 = sub; c0 < row_chunks; c0 += 4 * G) {
+                uint4 v[4], qv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {  // unconditional loads (clamped address): all four issue back to back
+                    const uint32_t c = c0 + j * G, cc = c < row_chunks ? c : row_chunks - 1;
+                    v[j] = p[cc];
+                    qv[j] = qp[cc];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c0 + j * G < row_chunks) acc = IS_L1 ? sad16(v[j], qv[j], acc) : dot16(v[j], qv[j], acc);
             }
         }
         acc = group_sum<G>(acc);
-        if (sub == 0 && k < n_ids)
-            out[k] = ok ? epilogue(multiplier, acc, q_off, offsets[row], diff, mode) : __builtin_nanf("");
+        if (sub == 0) out[k] = ok ? epilogue(multiplier, acc, q_off, offsets[row], diff, mode) : __builtin_nanf("");
     }
 }
 
@@ -1239,21 +1255,41 @@ qamd_status check_query(const qamd_u8 *h, const qamd_u8_query *q) {
 }
 
 // One launch of u8_score_pairs_kernel.  lists == nullptr: the single query (qc, qo) for every id.
+template <bool IS_L1>
+qamd_status launch_pairs(const qamd_u8 *h, const uint4 *qc, const float *qo, const uint8_t *q_batch, uint32_t q_pitch,
+                         const float *q_offs, const uint32_t *lists, uint32_t n_lists, const uint32_t *list_rows, float diff,
+                         int mode, const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t s) {
+    const uint64_t ppb = pairs_per_block(n_ids, 16);  // 16 lane groups per workgroup
+    const unsigned grid = (unsigned)((n_ids + ppb - 1) / ppb);
+    const uint32_t iters = (h->row_chunks + 15) / 16;
+#define QAMD_U8_PAIRS(IT)                                                                                                \
+    hipLaunchKernelGGL((u8_score_pairs_kernel<IS_L1, IT>), dim3(grid), dim3(kBlock), 0, s, h->codes.as<uint4>(),         \
+                       h->offsets.as<float>(), qc, qo, q_batch, q_pitch, q_offs, lists, n_lists, list_rows,              \
+                       h->meta.multiplier, diff, mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, (uint32_t)ppb, \
+                       out_dev)
+    switch (iters) {
+        case 1: QAMD_U8_PAIRS(1); break;
+        case 2: QAMD_U8_PAIRS(2); break;
+        case 3: QAMD_U8_PAIRS(3); break;
+        case 4: QAMD_U8_PAIRS(4); break;
+        case 5: QAMD_U8_PAIRS(5); break;
+        case 6: QAMD_U8_PAIRS(6); break;
+        case 7: QAMD_U8_PAIRS(7); break;
+        case 8: QAMD_U8_PAIRS(8); break;
+        default: QAMD_U8_PAIRS(0); break;
+    }
+#undef QAMD_U8_PAIRS
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
 qamd_status score_pairs_dev(const qamd_u8 *h, const uint4 *qc, const float *qo, const uint8_t *q_batch, uint32_t q_pitch,
                             const float *q_offs, const uint32_t *lists, uint32_t n_lists, const uint32_t *list_rows,
                             float diff, int mode, const uint32_t *ids_dev, uint64_t n_ids, float *out_dev, hipStream_t s) {
     if (n_ids == 0) return QAMD_OK;
-    int grid = grid_for((n_ids + 3) / 4, kBlock / 64, 8);
     if (h->meta.vector_parameters.distance_type == QAMD_L1)
-        hipLaunchKernelGGL((u8_score_pairs_kernel<true>), dim3(grid), dim3(kBlock), 0, s, h->codes.as<uint4>(),
-                           h->offsets.as<float>(), qc, qo, q_batch, q_pitch, q_offs, lists, n_lists, list_rows,
-                           h->meta.multiplier, diff, mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
-    else
-        hipLaunchKernelGGL((u8_score_pairs_kernel<false>), dim3(grid), dim3(kBlock), 0, s, h->codes.as<uint4>(),
-                           h->offsets.as<float>(), qc, qo, q_batch, q_pitch, q_offs, lists, n_lists, list_rows,
-                           h->meta.multiplier, diff, mode, ids_dev, n_ids, (uint32_t)h->count, h->row_chunks, out_dev);
-    QAMD_HIP(hipGetLastError());
-    return QAMD_OK;
+        return launch_pairs<true>(h, qc, qo, q_batch, q_pitch, q_offs, lists, n_lists, list_rows, diff, mode, ids_dev, n_ids, out_dev, s);
+    return launch_pairs<false>(h, qc, qo, q_batch, q_pitch, q_offs, lists, n_lists, list_rows, diff, mode, ids_dev, n_ids, out_dev, s);
 }
 
 qamd_status score_ids_dev(const qamd_u8 *h, const uint4 *qc, const float *qo, float diff, int mode,
