@@ -320,6 +320,7 @@ __global__ __launch_bounds__(512) void tune_mfma_peak(uint32_t iters, uint32_t s
     };
     mv4 a0 = {rnd(), rnd(), rnd(), rnd()}, a1 = {rnd(), rnd(), rnd(), rnd()};
     mv4 b0 = {rnd(), rnd(), rnd(), rnd()}, b1 = {rnd(), rnd(), rnd(), rnd()};
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (uint32_t it = 0; it < iters; it++) {
 #pragma unroll
         for (int a = 0; a < NACC; a++)
@@ -334,6 +335,10 @@ __global__ __launch_bounds__(512) void tune_mfma_peak(uint32_t iters, uint32_t s
 #pragma unroll
         for (int e = 0; e < 16; e++) t ^= acc[a][e];
     if (t == 0x7fffffff) sink[0] = t;
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {  // shader clocks and 10 ns ticks of the loop: the clock it ran at
+        reinterpret_cast<unsigned long long *>(sink)[1] = __builtin_amdgcn_s_memtime() - c0;
+        reinterpret_cast<unsigned long long *>(sink)[2] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 }  // namespace
 
@@ -358,9 +363,13 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_mfma_peak
         }
         std::sort(ms.begin(), ms.end());
         const double ops = (double)cu * (threads / 64) * (double)iters * nacc * 32.0 * 32.0 * 32.0 * 2.0;
+        unsigned long long clk[3] = {0, 0, 0};
+        QAMD_HIP(hipMemcpy(clk, sink, sizeof clk, hipMemcpyDeviceToHost));
+        const double mhz = clk[2] ? (double)clk[1] / (double)clk[2] * 100.0 : 0.0;
         char line[256];
-        snprintf(line, sizeof line, "%-34s median %.3f ms  %.0f TOP/s  (%.3f of 5000)\n", name, ms[2], ops / (ms[2] * 1e-3) / 1e12,
-                 ops / (ms[2] * 1e-3) / 5e15);
+        snprintf(line, sizeof line, "%-34s median %.3f ms  %.0f TOP/s  (%.3f of 5000)  shader clock %.0f MHz, %.1f cycles per MFMA and SIMD\n",
+                 name, ms[2], ops / (ms[2] * 1e-3) / 1e12, ops / (ms[2] * 1e-3) / 5e15, mhz,
+                 (double)clk[1] / ((double)iters * nacc * (threads / 256)));
         rep += line;
         return QAMD_OK;
     };

@@ -281,11 +281,15 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 constexpr int PP_KT = 64;  // K-tile bytes per row
 // Batch size from which the query-streaming kernel is preferred, by 128-byte K-blocks per row (measured,
 // whole topk_batch(30) calls at 7.68 GB of rows; below it several 128-query tiles of the row-streaming
-// kernel, or the ping-pong kernel where only 64-query tiles fit):
-//   rows <= 384 B : 30M x 256:    640 q  rs 7.1  qs 8.5  pp 9.5 ms;  1024 q  qs 10.3  pp 11.4
-//   rows <= 1152 B: 10M x 768:    640 q  rs 5.65 qs 6.0  pp 7.2;      768 q  rs 6.6   qs 6.2
-//   rows <= 1536 B: 12.5M x 1536: 256 q  pp 5.84 qs 6.34; 384 q  pp 10.3 qs 8.8; 640 q  pp 16.1 qs 13.8
-inline uint64_t qs_min_queries(uint32_t nkb) { return nkb <= 3 ? 960 : nkb <= 9 ? 704 : 320; }
+// kernel, or the ping-pong kernel where only 64-query tiles fit).  Round 3 (profiles/r03_qs_experiments.txt), ms:
+//   rows of 384 B,  20M:   385 q  rs 4.57 qs 4.42;  512 q  rs 4.76 qs 4.91;  703 q  rs 7.04 qs 6.56   (unchanged: 960)
+//   rows of 512 B,  15M:   260 q  rs 3.43 qs 3.55;  385 q  rs 4.35 qs 4.12;  640 q  rs 5.83 qs 5.77;  703 q  rs 6.75 qs 6.01
+//   rows of 768 B,  10M:   260 q  rs 3.20 qs 3.08;  384 q  rs 3.35 qs 3.48;  385 q  rs 4.07 qs 3.61;  703 q  rs 6.35 qs 5.54
+//   rows of 1024 B, 7.5M:  260 q  rs 3.40 qs 3.10;  385 q  rs 4.79 qs 3.62;  703 q  rs 8.60 qs 5.41
+//   rows <= 1536 B: 12.5M x 1536: 256 q  pp 5.84 qs 6.34; 384 q  pp 10.3 qs 8.8; 640 q  pp 16.1 qs 13.8   (round 2)
+// i.e. the query-streaming kernel from the fourth 128-query tile on (the round-2 threshold of 704 dated from before its
+// block-change and epilogue work), from the third for rows past 768 B.
+inline uint64_t qs_min_queries(uint32_t nkb) { return nkb <= 3 ? 960 : nkb <= 6 ? 385 : nkb <= 9 ? 257 : 320; }
 // Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
 //   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
 //   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
@@ -1075,6 +1079,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
     unsigned long long *stamps = QAMD_GEMM_STAMPS();
     const bool timed = stamps != nullptr;
     unsigned long long tm_prev = timed ? __builtin_amdgcn_s_memtime() : 0ull, tm_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tm_first = tm_prev, rt_first = timed ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz
     auto lap = [&](int slot) {
         if (timed) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -1283,6 +1288,8 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
     if (timed && lane == 0 && blockIdx.x < kStampBlocks) {
         unsigned long long *o = stamps + ((uint64_t)blockIdx.x * 8 + wave) * 16;
         for (int i = 0; i < 6; i++) o[i] = tm_acc[i];
+        o[6] = __builtin_amdgcn_s_memtime() - tm_first;      // shader clocks spent in the kernel ...
+        o[7] = __builtin_amdgcn_s_memrealtime() - rt_first;  // ... and 10 ns ticks: the clock the kernel ran at
         o[15] = 1;
     }
     if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;

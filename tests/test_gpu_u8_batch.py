@@ -355,8 +355,13 @@ print("ok")
     assert res.returncode == 0 and "ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
 
 
-# ---- query-streaming kernel (u8_gemm_qs_kernel): 704 queries or more, rows of up to 1536 code bytes
+# ---- query-streaming kernel (u8_gemm_qs_kernel): rows of up to 1536 code bytes, from 960 / 385 / 257 / 320 queries
+# (rows of up to 384 / 768 / 1152 / 1536 bytes: qs_min_queries in csrc/u8_batch.hip)
 @pytest.mark.parametrize("n,dim,nq", [
+    (33_000, 768, 385),     # the first batch size past three row-streaming tiles: 7 query chunks over 8 waves
+    (33_000, 768, 384),     # ... and the last one the row-streaming kernel keeps
+    (33_000, 512, 390),
+    (33_000, 1024, 257),    # rows past 768 bytes: from the third tile on; 5 chunks, three waves idle
     (40_003, 96, 704),      # one K-block per row (odd count)
     (35_000, 200, 800),     # row length 208, two K-blocks; 13 query chunks over 8 waves
     (70_001, 384, 1024),    # three K-blocks (odd), two chunks per wave, several row blocks per workgroup, ragged tail

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer fuzz (GPU box): random shapes through score_batch / topk_batch against the single-query
 path (itself pinned to the oracle by tests/test_gpu_u8.py).  Exercises the kernel selection
-boundaries of csrc/u8_batch.hip (query counts around 4/5, 32, 64, 128, 703/704, 2048; row lengths
+boundaries of csrc/u8_batch.hip (query counts around 4/5, 32, 64, 128, 256/257, 384/385, 703/704, 959/960, 2048; row lengths
 around 128, 1152, 1536, 2304, 4608; stores around the 32768-row fused threshold and ragged tails).
     python tools/fuzz_batch.py [cases] [seed]      (QAMD_GEMM_CFG=r|q|p forces one kernel)"""
 import sys as _sys
@@ -22,7 +22,7 @@ D = qa.DistanceType
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda", 0)
-NQ = [2, 4, 5, 31, 32, 33, 64, 65, 127, 128, 129, 200, 256, 300, 511, 512, 640, 703, 704, 705, 768, 1000, 1024, 1100, 2047, 2048,
+NQ = [2, 4, 5, 31, 32, 33, 64, 65, 127, 128, 129, 200, 256, 257, 300, 384, 385, 511, 512, 640, 703, 704, 705, 768, 959, 960, 1000, 1024, 1100, 2047, 2048,
       2049, 2500]
 DIMS = [16, 17, 64, 100, 128, 129, 144, 256, 300, 384, 512, 700, 768, 1000, 1024, 1152, 1153, 1168, 1300, 1536, 1537, 1552, 2000, 2304,
         2320, 4608, 4700]

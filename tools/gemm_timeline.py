@@ -46,7 +46,8 @@ print(f"topk_batch with stamps: {e0.elapsed_time(e1):.2f} ms")
 st = stamps.cpu().numpy().reshape(4096, WAVES, 16)
 if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "q":
     # query-streaming kernel: per wave, cycles summed over its row blocks
-    blk = st[:256]
+    n_wg, blk_rows = 256, int(os.environ.get("BLK_ROWS", 128))  # BLK_ROWS=96: rows of 1153-1536 bytes
+    blk = st[:n_wg]
     ok = (blk[:, :, 15] > 0).all(axis=1)
     blk = blk[ok].astype(np.float64)
     tot = blk[:, :, :6].sum(axis=2).mean()
@@ -56,9 +57,12 @@ if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "q":
     for i, nm in enumerate(names):
         x = blk[:, :, i]
         print(f"  {nm:46s} {x.mean():12.0f}  {100 * x.mean() / tot:5.1f} %   (p10 {np.percentile(x, 10):10.0f}, p90 {np.percentile(x, 90):10.0f})")
-    n_blocks = (n + 127) // 128 / 256
-    mf = n_blocks * ((nq + 63) // 64) / 8 * ((enc.metadata["actual_dim"] + 127) // 128) * 32
+    n_blocks = (n + blk_rows - 1) // blk_rows / n_wg
+    mf = n_blocks * ((nq + 63) // 64) / WAVES * ((enc.metadata["actual_dim"] + 127) // 128) * (blk_rows // 4)
     print(f"  MFMAs per wave {mf:.0f}: K loop cycles per MFMA {blk[:, :, 3].mean() / mf:.1f} (two waves share a SIMD: 64 nominal)")
+    if blk[:, :, 7].mean() > 0:
+        print(f"  kernel {blk[:, :, 7].mean() / 100:.1f} us per wave (10 ns ticks), shader clock while it ran "
+              f"{blk[:, :, 6].mean() / blk[:, :, 7].mean() * 100:.0f} MHz")
     for i in (0, 3, 4):
         print("  per wave index,", names[i][:24], ":", " ".join(f"{v/1e3:8.0f}k" for v in blk[:, :, i].mean(axis=0)))
     sys.exit(0)
