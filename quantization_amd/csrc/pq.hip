@@ -40,6 +40,12 @@ constexpr uint64_t kKmeansSample = 10000;  // KMEANS_SAMPLE_SIZE (:22)
 constexpr int kKmeansMaxIter = 100;        // KMEANS_MAX_ITERATIONS (:23)
 constexpr float kKmeansAccuracy = 1e-5f;   // KMEANS_ACCURACY (:24)
 constexpr size_t kLdsBudget = 160 * 1024 - 1024;
+// The whole-store scan keeps a LUT slice of at most 9 row pieces (144 chunks, 144 KiB) in LDS per launch.  A row that needs
+// several slices is laid out on a 128-byte pitch and scanned in slices of 8 pieces = one 128-byte line each: a slice
+// launch then reads whole lines that no other slice touches (m = 192 on the natural 192-byte pitch cut every row's
+// lines across both slices: 6 line fetches per 2 rows instead of 3).
+constexpr uint32_t kMaxSlicePieces = 9, kSlicePiecesAligned = 8;
+inline uint64_t valid_pieces(uint64_t m) { return (m + 15) / 16; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
@@ -864,7 +870,8 @@ namespace {
 qamd_status alloc_store(qamd_pq *h) {
     h->m = chunks_of(h->vp.dim, h->chunk_size);
     // rows of 16-byte pieces (the scan's load unit); tiny rows keep whole dwords
-    h->ds = h->m >= 16 ? round_up(h->m, 16) : round_up(std::max<uint64_t>(h->m, 1), 4);
+    h->ds = h->m < 16 ? round_up(std::max<uint64_t>(h->m, 1), 4)
+          : valid_pieces(h->m) > kMaxSlicePieces ? round_up(h->m, 16 * kSlicePiecesAligned) : round_up(h->m, 16);
     const uint64_t padded = round_up(h->count, kRowPad) + kRowPad;
     return h->rows.alloc(padded * h->ds, true);
 }
@@ -880,15 +887,14 @@ bool fast_capable(const qamd_pq *h, uint64_t n) {
     return n >= 4096 && h->m >= 16 && n == h->count;
 }
 
-// Slices of at most 9 pieces (144 chunks, 144 KiB of LUT) per launch, balanced.
-constexpr uint32_t kMaxSlicePieces = 9;
+// One slice (at most 9 pieces: 144 chunks, 144 KiB of LUT) when the row fits, else line-sized slices (kMaxSlicePieces above).
 
 template <bool FILTER>
 qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, const TopkFilter *filt,
                         hipStream_t s) {
-    const uint32_t m = (uint32_t)h->m, pieces = (uint32_t)(h->ds / 16);
-    const uint32_t n_slices = (pieces + kMaxSlicePieces - 1) / kMaxSlicePieces;
-    const uint32_t per = (pieces + n_slices - 1) / n_slices;
+    const uint32_t m = (uint32_t)h->m, pitch_pieces = (uint32_t)(h->ds / 16), pieces = (uint32_t)valid_pieces(m);
+    const uint32_t per = pieces <= kMaxSlicePieces ? pieces : kSlicePiecesAligned;
+    const uint32_t n_slices = (pieces + per - 1) / per;
     const uint64_t n = h->count;
     const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
     float *partial = nullptr;
@@ -916,7 +922,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
                                (uint32_t)n, out_dev, filt ? *filt : TopkFilter{});                          \
         else                                                                                                \
             hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, FILTER, false>), dim3(grid), dim3(kScanBlock), lds, s, \
-                               h->rows.as<uint4>(), pieces, piece0, lut_dev, m / 4, m, first, last, partial, \
+                               h->rows.as<uint4>(), pitch_pieces, piece0, lut_dev, m / 4, m, first, last, partial, \
                                (uint32_t)n, out_dev, filt ? *filt : TopkFilter{});                          \
         break;                                                                                              \
     }
