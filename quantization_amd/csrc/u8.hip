@@ -1179,11 +1179,14 @@ void launch_multi_shape(const qamd_u8 *h, const uint8_t *qcodes, uint64_t q_pitc
 // pieces), 0 = none.  Measured on 10M x 768 / 12.5M x 1536, top-30 per query, whole call: 2 queries
 // 1.24 / 2.93 ms and 4 queries 1.38 / 3.50 ms against 1.65 / 3.85 ms on the matrix-core path; an
 // 8-wide pass (96 query VGPRs, 3 waves per SIMD) took 1.97 ms at dim 768 -- worse than the matrix
-// cores -- so batches of 5 and more stay there.
+// cores -- so batches of 5 and more stay there.  L1 has no matrix form: its batches are served by this kernel alone,
+// and there the 8-wide pass is the better one (8 queries per 1.97 ms against two 4-wide passes of 1.38 ms; rows of up
+// to 768 bytes: 96 query registers).
 uint32_t multi_width(const qamd_u8 *h) {
     const uint32_t rc = h->row_chunks, iters = (rc + 15) / 16;
-    if (rc < 9 || iters > 8 || (h->lane_mode != 0 && h->meta.vector_parameters.distance_type != QAMD_L1)) return 0;
-    return iters <= 6 ? 4 : 2;
+    const bool l1 = h->meta.vector_parameters.distance_type == QAMD_L1;
+    if (rc < 9 || iters > 8 || (h->lane_mode != 0 && !l1)) return 0;
+    return l1 && iters <= 3 ? 8 : iters <= 6 ? 4 : 2;
 }
 
 // One pass for `nq_valid` (2 .. multi_width) queries; false = unsupported.
@@ -1194,6 +1197,12 @@ bool launch_multi(const qamd_u8 *h, uint32_t nq_valid, const uint8_t *qcodes, ui
     if (nq_valid < 2 || nq_valid > width) return false;
 #define QAMD_U8_MULTI_IT(IT, UN)                                                                              \
     case IT:                                                                                                  \
+        if constexpr (IS_L1 && IT <= 3) {                                                                     \
+            if (nq_valid > 4) {                                                                               \
+                launch_multi_shape<IS_L1, 16, IT, UN, 8>(h, qcodes, q_pitch, q_offs, nq_valid, out, slices, s); \
+                return true;                                                                                  \
+            }                                                                                                 \
+        }                                                                                                     \
         if (nq_valid > 2) launch_multi_shape<IS_L1, 16, IT, UN, (IT <= 6 ? 4 : 2)>(h, qcodes, q_pitch, q_offs, nq_valid, out, slices, s); \
         else launch_multi_shape<IS_L1, 16, IT, UN, 2>(h, qcodes, q_pitch, q_offs, nq_valid, out, slices, s);  \
         return true;
