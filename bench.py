@@ -665,7 +665,11 @@ def main():
                     "kernel": kernel_name, "kernel_ms": kern_ms,
                     "kernel_ms_min": float(np.min(kern_all)), "kernel_ms_median": float(np.median(kern_all)),
                     "kernel_ms_mean": kern_ms,
-                    "algorithmic_bytes_per_row": bytes_per_row, "rows_per_launch": n}
+                    "algorithmic_bytes_per_row": bytes_per_row, "rows_per_launch": n,
+                    # `achieved` counts what SURVEY 8(d) counts: the row bytes READ.  The scan also writes one f32 score per
+                    # row; with it the kernel moves this much (3 % more for 128-byte binary rows, 0.5 % for u8 at dim 768):
+                    "score_bytes_written_per_row": 4,
+                    "achieved_incl_score_writes": (bytes_per_row + 4) * n / (kern_ms * 1e-3) / 1e9}
         if args.quantizer == "pq":
             # The PQ scan reads only m bytes per row from HBM; its limiter is the LDS gather (one
             # ds_read_b32 per chunk and row, bank-conflicting by construction: DESIGN 3.3).
