@@ -340,6 +340,39 @@ __global__ __launch_bounds__(512) void tune_mfma_peak(uint32_t iters, uint32_t s
         reinterpret_cast<unsigned long long *>(sink)[2] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
+// the same loop on v_mfma_i32_16x16x64_i8 (half the ops per instruction, 4 accumulator registers instead of 16):
+// the same arithmetic per cycle on paper - does the part clock it differently?
+template <int NACC>
+__global__ __launch_bounds__(512) void tune_mfma_peak16(uint32_t iters, uint32_t seed, int *__restrict__ sink) {
+    mv4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = mv4{0, 0, 0, 0};
+    uint32_t x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+    auto rnd = [&]() {
+        x = x * 1664525u + 1013904223u;
+        return (int)(x & 0x7F7F7F7Fu);
+    };
+    mv4 a0 = {rnd(), rnd(), rnd(), rnd()}, a1 = {rnd(), rnd(), rnd(), rnd()};
+    mv4 b0 = {rnd(), rnd(), rnd(), rnd()}, b1 = {rnd(), rnd(), rnd(), rnd()};
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+        for (int a = 0; a < NACC; a++)
+            acc[a] = __builtin_amdgcn_mfma_i32_16x16x64_i8((a & 1) ? a1 : a0, (a & 2) ? b1 : b0, acc[a], 0, 0, 0);
+        a0.x ^= (int)it;
+        b1.y ^= (int)(it << 3);
+    }
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < NACC; a++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) t ^= acc[a][e];
+    if (t == 0x7fffffff) sink[0] = t;
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+        reinterpret_cast<unsigned long long *>(sink)[1] = __builtin_amdgcn_s_memtime() - c0;
+        reinterpret_cast<unsigned long long *>(sink)[2] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
 }  // namespace
 
 extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_mfma_peak(int *sink, char *report, size_t cap) {
@@ -349,7 +382,7 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_mfma_peak
     QAMD_HIP(hipEventCreate(&e0));
     QAMD_HIP(hipEventCreate(&e1));
     std::string rep;
-    auto run = [&](const char *name, int threads, int nacc, auto kernel) -> qamd_status {
+    auto run = [&](const char *name, int threads, int nacc, auto kernel, double ops_per_mfma = 32.0 * 32.0 * 32.0 * 2.0) -> qamd_status {
         const uint32_t iters = 20000;
         std::vector<float> ms;
         for (int r = 0; r < 5; r++) {
@@ -362,7 +395,7 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_mfma_peak
             ms.push_back(t);
         }
         std::sort(ms.begin(), ms.end());
-        const double ops = (double)cu * (threads / 64) * (double)iters * nacc * 32.0 * 32.0 * 32.0 * 2.0;
+        const double ops = (double)cu * (threads / 64) * (double)iters * nacc * ops_per_mfma;
         unsigned long long clk[3] = {0, 0, 0};
         QAMD_HIP(hipMemcpy(clk, sink, sizeof clk, hipMemcpyDeviceToHost));
         const double mhz = clk[2] ? (double)clk[1] / (double)clk[2] * 100.0 : 0.0;
@@ -377,6 +410,9 @@ extern "C" __attribute__((visibility("default"))) qamd_status qamd_dev_mfma_peak
     QAMD_TRY(run("8 waves/CU, 8 accumulators", 512, 8, tune_mfma_peak<8>));
     QAMD_TRY(run("8 waves/CU, 4 accumulators", 512, 4, tune_mfma_peak<4>));
     QAMD_TRY(run("4 waves/CU, 16 accumulators", 256, 16, tune_mfma_peak<16>));
+    QAMD_TRY(run("16x16x64: 8 waves/CU, 8 accumulators", 512, 8, tune_mfma_peak16<8>, 16.0 * 16.0 * 64.0 * 2.0));
+    QAMD_TRY(run("16x16x64: 8 waves/CU, 16 accumulators", 512, 16, tune_mfma_peak16<16>, 16.0 * 16.0 * 64.0 * 2.0));
+    QAMD_TRY(run("16x16x64: 4 waves/CU, 16 accumulators", 256, 16, tune_mfma_peak16<16>, 16.0 * 16.0 * 64.0 * 2.0));
     snprintf(report, cap, "%s", rep.c_str());
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
