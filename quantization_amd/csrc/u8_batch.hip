@@ -279,17 +279,19 @@ __global__ __launch_bounds__(64 * WQ * WR) void u8_gemm_kernel(const uint8_t *__
 // With DMA, barriers and fragment reads all removed the K loop still takes 1.2-1.4x the nominal
 // 32 cycles per MFMA in s_memtime ticks: the chip runs this kernel at about 1.8-2.0 GHz.
 constexpr int PP_KT = 64;  // K-tile bytes per row
-// Batch size from which the query-streaming kernel is preferred, by 128-byte K-blocks per row (measured,
-// whole topk_batch(30) calls at 7.68 GB of rows; below it several 128-query tiles of the row-streaming
-// kernel, or the ping-pong kernel where only 64-query tiles fit).  Round 3 (profiles/r03_qs_experiments.txt), ms:
-//   rows of 384 B,  20M:   385 q  rs 4.57 qs 4.42;  512 q  rs 4.76 qs 4.91;  703 q  rs 7.04 qs 6.56   (unchanged: 960)
-//   rows of 512 B,  15M:   260 q  rs 3.43 qs 3.55;  385 q  rs 4.35 qs 4.12;  640 q  rs 5.83 qs 5.77;  703 q  rs 6.75 qs 6.01
-//   rows of 768 B,  10M:   260 q  rs 3.20 qs 3.08;  384 q  rs 3.35 qs 3.48;  385 q  rs 4.07 qs 3.61;  703 q  rs 6.35 qs 5.54
-//   rows of 1024 B, 7.5M:  260 q  rs 3.40 qs 3.10;  385 q  rs 4.79 qs 3.62;  703 q  rs 8.60 qs 5.41
+// Batch size from which the query-streaming kernel is preferred, by 128-byte K-blocks per row (measured, whole
+// topk_batch(30) calls at 7.68 GB of rows; below it several 128-query tiles of the row-streaming kernel, or the
+// ping-pong kernel where only 64-query tiles fit).  Round 3, with the 16x16x64 form of the kernel for rows of up to
+// 1024 bytes (profiles/r03_qs_experiments.txt), ms, row-streaming / query-streaming:
+//   rows of 256 B,  30M:   257 q  3.96 / 4.45    385 q  5.10 / 4.73    704 q  7.81 / 6.98    960 q  9.80 / 8.07
+//   rows of 384 B,  20M:   257 q  3.64 / 3.69    385 q  4.60 / 3.97    704 q  7.07 / 5.98    960 q  8.96 / 7.16
+//   rows of 512 B,  15M:   192 q  2.34 / 2.73    257 q  3.44 / 3.30    385 q  4.35 / 3.70    704 q  6.77 / 5.53
+//   rows of 768 B,  10M:   192 q  2.19 / 2.35    257 q  3.24 / 2.88    385 q  4.10 / 3.39    704 q  6.36 / 5.07
+//   rows of 1024 B, 7.5M:  192 q  2.22 / 2.21    257 q  3.41 / 2.74    385 q  4.76 / 3.25    704 q  8.61 / 4.89
 //   rows <= 1536 B: 12.5M x 1536: 256 q  pp 5.84 qs 6.34; 384 q  pp 10.3 qs 8.8; 640 q  pp 16.1 qs 13.8   (round 2)
-// i.e. the query-streaming kernel from the fourth 128-query tile on (the round-2 threshold of 704 dated from before its
-// block-change and epilogue work), from the third for rows past 768 B.
-inline uint64_t qs_min_queries(uint32_t nkb) { return nkb <= 3 ? 960 : nkb <= 6 ? 385 : nkb <= 9 ? 257 : 320; }
+// i.e. from the third 128-query tile on (the fourth for rows of up to 384 bytes); the round-2 thresholds (960 / 704)
+// dated from before that round's block-change and epilogue work and this round's matrix instruction.
+inline uint64_t qs_min_queries(uint32_t nkb) { return nkb <= 3 ? 385 : nkb <= 9 ? 257 : 320; }
 // Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
 //   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
 //   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
@@ -1295,6 +1297,360 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
     if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The query-streaming kernel on v_mfma_i32_16x16x64_i8 (round 3).  Same structure, arithmetic and results as
+// u8_gemm_qs_kernel; what changes is the matrix instruction.  Under int8 MFMA load this part is clock-limited: a bare
+// loop of 32x32x32 instructions runs at 1.84-1.89 GHz (3.6-3.8 POP/s), the same loop on 16x16x64 at 2.2-2.3 GHz
+// (4.35-4.40 POP/s) - a fifth more work per second out of the same pipes (tools/mfma_peak.py).  A wave's tile is
+// unchanged, 64 queries x 128 rows = 4 x 8 accumulator tiles of 16 x 16 (128 registers), and so is the operand
+// traffic per multiply: per 64-byte k-step 4 query fragments (streamed from L2 in fragment order, two K-blocks in
+// flight) and 8 row fragments (ds_read_b128) feed 32 MFMAs.
+//   * fragment order of the batch copy (swizzle_queries16_kernel): per 16 queries, 128-byte K-block and 64-byte
+//     k-step one 1 KiB piece, lane (i = lane % 16, g = lane / 16) holding bytes [64 s + 16 g, +16) of query i;
+//   * the resident rows lie on a pitch of whole 256-byte LDS bank rows, the 16-byte chunks of a row XOR-swizzled
+//     by (row & 15): lane (i, g) reads chunk 8 kb + 4 s + g of row 16 jt + i, and the 16 lanes of every ds_read_b128
+//     group ({0-3, 12-15, 20-27}, ...: two values of g) land on 16 different slots;
+//   * lane (i, g) ends up with queries 4 g .. 4 g + 3 of the tile against row i of the tile: four accumulators.
+// Rows of up to 1024 bytes (128 x 1024 B of LDS); longer rows keep the 32x32x32 kernel.
+__global__ __launch_bounds__(256) void swizzle_queries16_kernel(const uint8_t *__restrict__ codes, uint32_t pitch,
+                                                               uint32_t q_pad, uint32_t nkb, uint4 *__restrict__ out) {
+    // out[((t * nkb + kb) * 2 + s) * 64 + lane] = bytes [128 kb + 64 s + 16 g, +16) of query 16 t + i
+    const uint64_t total = (uint64_t)(q_pad / 16) * nkb * 128;
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+        const uint32_t lane = (uint32_t)(idx & 63u), sx = (uint32_t)(idx >> 6) & 1u;
+        const uint64_t tk = idx >> 7;
+        const uint32_t kb = (uint32_t)(tk % nkb), t16 = (uint32_t)(tk / nkb);
+        const uint32_t i = lane & 15u, g = lane >> 4, k = kb * 128u + 64u * sx + 16u * g;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < pitch) v = *reinterpret_cast<const uint4 *>(codes + (uint64_t)(16u * t16 + i) * pitch + k);
+        out[idx] = v;
+    }
+}
+
+template <int MODE, bool LOW>
+__global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__restrict__ codes,
+                                                          const float *__restrict__ v_offsets,
+                                                          const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
+                                                          const int *__restrict__ bq_all, float multiplier, uint32_t n_rows,
+                                                          uint32_t n_queries, uint32_t q_pad, uint32_t ad,
+                                                          float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr int IT = 4, JT = 8, KB = 128, QS_ROWS = 16 * JT;  // 64 queries x 128 rows per wave and chunk
+    constexpr bool FILTER = MODE == 1 || MODE == 2;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
+    const uint32_t nkb = __builtin_amdgcn_readfirstlane((ad + KB - 1) / KB);
+    const uint32_t per = ad / 16;                                              // 16-byte chunks per row
+    const uint32_t PA = __builtin_amdgcn_readfirstlane(((per + 15) / 16) * 256);  // LDS pitch: whole 256-byte bank rows
+    const uint32_t n_blocks = (n_rows + QS_ROWS - 1) / QS_ROWS;
+    const uint32_t live_chunks = (n_queries + 63) / 64;
+    float *voff_s = reinterpret_cast<float *>(lds_raw + (size_t)QS_ROWS * PA);  // [128]
+    int *br_s = reinterpret_cast<int *>(voff_s + QS_ROWS);                       // [128]
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(br_s + QS_ROWS) + wave;
+    int *bq_s = reinterpret_cast<int *>(br_s + QS_ROWS) + 16;                    // [64 * live_chunks] integer query bounds
+    constexpr bool LARGEST = MODE == 1;
+    if (FILTER && lane == 0) *wcount_s = 0;
+    if (FILTER)
+        for (uint32_t i = t; i < 64 * live_chunks; i += 512) bq_s[i] = bq_all[i];
+    const float never = (MODE == 3 ? filt.largest != 0 : LARGEST) ? -__builtin_huge_valf() : __builtin_huge_valf();
+
+    // streamed operand: chunk c, k-step j (64 bytes of K: K-block j / 2, half j % 2) -> one 1 KiB piece per 16-query tile
+    // 4c .. 4c + 3.  Three buffers of one k-step each rotate: the step in use and the next two on their way (two k-steps
+    // = one K-block of lead, as in u8_gemm_qs_kernel, in 48 registers instead of 64: the 128 accumulator registers and
+    // two waves per SIMD leave no more).
+    const uint32_t nsteps = 2 * nkb;
+    v4i Q0[IT], Q1[IT], Q2[IT];
+    auto load_step = [&](v4i(&a)[IT], uint32_t c, uint32_t j) {
+        const uint4 *p = qfrag + ((uint64_t)(4 * c) * nkb * 2 + j) * 64 + lane;  // (tile 4c, K-block j / 2, half j % 2)
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const uint4 v = p[(uint64_t)it * nkb * 128];
+            a[it] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        }
+    };
+    // resident operand: lane (i16, g4) reads chunk 8 kb + 4 sx + g4 of row 16 jt + i16; the chunk's place in the row
+    // is its index XOR i16 (the low four bits: K-block parity, k-step and g4), whole 256-byte groups (kb >> 1) apart
+    // (k-step j of the chunk = chunk 4 j + g4 of the row: place (4 (j & 3) + g4) ^ i16 of 256-byte group j >> 2; 4 (j & 3)
+    // has no bit in common with g4, so the place is ((g4 ^ i16) ^ 4 (j & 3)): one XOR with a scalar per k-step)
+    const uint32_t b_row = i16 * PA, b_gi = (g4 ^ i16) * 16u;
+
+    // Row-block fill: thread t takes the 16-byte pieces t, t + 512, ... of the block's 128 * ad contiguous bytes
+    // (requested before the barrier that frees the LDS rows, written after it, as in u8_gemm_qs_kernel); piece c of
+    // row r goes to place c ^ (r & 15).  Places a row does not fill (past its last chunk) are only ever multiplied
+    // with the zero bytes of the query image.
+    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane((QS_ROWS * per + 511) / 512);
+    const uint32_t p_row0 = (uint32_t)t / per, p_c0 = (uint32_t)t % per, d_row = 512 / per, d_c = 512 % per;
+    constexpr int MAXP = 16;  // rows of up to 1024 bytes: 128 * 64 / 512
+    v4i st[MAXP];
+    float vo_pf = 0.0f;
+    auto fill_request = [&](uint32_t blk) {
+        const uint8_t *p = codes + (uint64_t)blk * QS_ROWS * ad + (size_t)t * 16;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;  // wave-uniform
+            st[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + (size_t)ii * 8192));
+        }
+        if (n_pieces > 12) {
+#pragma unroll
+            for (int i = 12; i < MAXP; i++) {
+                const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;
+                st[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + (size_t)ii * 8192));
+            }
+        } else {
+#pragma unroll
+            for (int i = 12; i < MAXP; i++) asm volatile("" : "=v"(st[i]));
+        }
+        vo_pf = v_offsets[(uint64_t)blk * QS_ROWS + (t < QS_ROWS ? t : 0)];  // padded like codes[]
+    };
+    auto fill_write = [&]() {
+        uint32_t row = p_row0, c = p_c0;
+        asm volatile("" : "+v"(row), "+v"(c));
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            if ((uint32_t)i < n_pieces && row < (uint32_t)QS_ROWS)
+                *reinterpret_cast<v4i *>(lds_raw + row * PA + ((c ^ (row & 15u)) * 16u)) = st[i];
+            row += d_row;
+            c += d_c;
+            if (c >= per) {
+                c -= per;
+                row++;
+            }
+        }
+    };
+    const uint32_t my_first = wave;
+    unsigned long long *stamps = QAMD_GEMM_STAMPS();
+    const bool timed = stamps != nullptr;
+    unsigned long long tm_prev = timed ? __builtin_amdgcn_s_memtime() : 0ull, tm_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tm_first = tm_prev, rt_first = timed ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto lap = [&](int slot) {
+        if (timed) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tm_acc[slot] += now - tm_prev;
+            tm_prev = now;
+        }
+    };
+    fill_request(blockIdx.x < n_blocks ? blockIdx.x : 0u);
+    if (my_first < live_chunks) {
+        load_step(Q0, my_first, 0);
+        load_step(Q1, my_first, 1);
+    }
+
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t row0 = (uint64_t)blk * QS_ROWS;
+        const uint32_t next_blk = blk + gridDim.x < n_blocks ? blk + gridDim.x : blk;
+        lap(5);
+        __syncthreads();  // every wave is done with the previous block's rows
+        lap(0);
+        fill_write();
+        if (t < QS_ROWS) {
+            const bool ok = row0 + t < n_rows;
+            const float vo = vo_pf;
+            voff_s[t] = ok ? vo : never;
+            if (FILTER) br_s[t] = ok ? pp_bound<LOW>(-vo, fabsf(vo), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+        }
+        __syncthreads();
+        lap(1);
+
+        for (uint32_t c = wave; c < live_chunks; c += 8) {
+            const uint32_t c_next = c + 8 < live_chunks ? c + 8 : my_first;
+            v4i acc[IT][JT];
+            {
+                int br[JT];  // (re-read in the epilogue's rare path: eight registers less across the K loop)
+#pragma unroll
+                for (int jt = 0; jt < JT; jt++) br[jt] = FILTER ? br_s[jt * 16 + i16] : 0;
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    v4i bq4 = {0, 0, 0, 0};
+                    if (FILTER) bq4 = *reinterpret_cast<const v4i *>(bq_s + 64 * c + 16 * it + 4 * g4);
+#pragma unroll
+                    for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[it][jt][e] = FILTER ? -(bq4[e] + br[jt]) : 0;
+                }
+            }
+            // k-step j with its streamed fragments in `a`: 8 row fragments (two halves of 4 tiles), 32 MFMAs.  (Reading the
+            // row fragments half a k-step ahead in a pinned order - 4 reads, 16 MFMAs, 4 reads, 16 MFMAs - was measured:
+            // no gain, 7 registers more; the other wave of the SIMD already covers the LDS round trip.)
+            auto compute = [&](const v4i(&a)[IT], uint32_t j) {
+                // this lane's address in tile 0; the tiles are 16 * PA apart (a scalar).  Opaque to the optimiser: left
+                // alone it keeps all (k-step, tile) addresses in registers across the loop - and spills them
+                uint32_t lane_addr = b_row + (b_gi ^ ((j & 3u) * 64u)) + (j >> 2) * 256u;
+                asm volatile("" : "+v"(lane_addr));
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    v4i bf[4];
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; j4++)
+                        bf[j4] = *reinterpret_cast<const v4i *>(lds_raw + lane_addr + (uint32_t)(4 * hf + j4) * 16u * PA);
+#pragma unroll
+                    for (int it = 0; it < IT; it++)
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; j4++)
+                            acc[it][4 * hf + j4] =
+                                __builtin_amdgcn_mfma_i32_16x16x64_i8(a[it], bf[j4], acc[it][4 * hf + j4], 0, 0, 0);
+                }
+            };
+            // k-step j >= nsteps of a chunk is k-step j - nsteps of the next one (its first two are requested under this
+            // chunk's last MFMAs; the queries do not depend on the rows, so across row blocks as well)
+            auto request = [&](v4i(&a)[IT], uint32_t j) {
+                if (j < nsteps) load_step(a, c, j);
+                else load_step(a, c_next, j - nsteps);
+            };
+            lap(2);
+            if (((c >> 3) + ((uint32_t)wave >> 2)) & 1u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+            // at entry Q0 = k-step 0 and Q1 = k-step 1 are on their way; sched_barrier: the four loads are issued HERE
+            uint32_t j = 0;
+            for (; j + 2 < nsteps; j += 3) {
+                request(Q2, j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q0, j);
+                __builtin_amdgcn_sched_barrier(0);
+                request(Q0, j + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q1, j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                request(Q1, j + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q2, j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const uint32_t left = nsteps - j;  // 0, 1 or 2 k-steps (nsteps is even: 2 when nsteps % 3 == 2, 1 when == 1)
+            if (left >= 1) {
+                request(Q2, j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q0, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (left == 2) {
+                request(Q0, j + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q1, j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            lap(3);
+            // ---- epilogue: lane (i16, g4) holds, per (it, jt), queries 64 c + 16 it + 4 g4 + e against row 16 jt + i16
+            uint32_t c_e = c, wave_e = (uint32_t)wave, lane_e = (uint32_t)lane;
+            asm volatile("" : "+s"(c_e), "+s"(wave_e), "+v"(lane_e));
+            const uint32_t i_e = lane_e & 15u, g_e = lane_e >> 4;
+            if (MODE == 3) {  // best score per query over the block's rows
+                const bool lg = filt.largest != 0;
+                float vo3[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; jt++) vo3[jt] = voff_s[jt * 16 + i_e];  // `never` for rows past the end
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const uint32_t q = 64 * c_e + 16 * it + 4 * g_e;
+                    const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+                    const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float best = never;
+#pragma unroll
+                        for (int jt = 0; jt < JT; jt++) {
+                            const float sc = (multiplier * (float)acc[it][jt][e] + qo[e]) + vo3[jt];
+                            best = lg ? fmaxf(best, sc) : fminf(best, sc);
+                        }
+#pragma unroll
+                        for (int d = 8; d >= 1; d >>= 1) {
+                            const float o = __shfl_xor(best, d);
+                            best = lg ? fmaxf(best, o) : fminf(best, o);
+                        }
+                        if (i_e == 0 && q + e < n_queries) out[(uint64_t)(q + e) * out_pitch + blk] = best;
+                    }
+                }
+            } else {
+                uint4 *wave_list = FILTER ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const uint32_t q = 64 * c_e + 16 * it + 4 * g_e;  // first of this lane's four consecutive queries
+                    if (FILTER) {
+                        // "some accumulator of these 8 tiles may pass" = the smallest is negative (LOW) / the largest is not
+                        int ext = acc[it][0][0];
+#pragma unroll
+                        for (int jt = 0; jt < JT; jt++) {
+                            ext = LOW ? min(min(ext, acc[it][jt][0]), acc[it][jt][1]) : max(max(ext, acc[it][jt][0]), acc[it][jt][1]);
+                            ext = LOW ? min(min(ext, acc[it][jt][2]), acc[it][jt][3]) : max(max(ext, acc[it][jt][2]), acc[it][jt][3]);
+                        }
+                        if (!__builtin_amdgcn_readfirstlane(__ballot(LOW ? ext < 0 : ext >= 0) != 0)) continue;
+                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JT; jt++) {
+                        __builtin_amdgcn_sched_barrier(0);  // one tile at a time: no hoisting of the next tiles' address arithmetic
+                        const uint64_t row = row0 + jt * 16 + i_e;
+                        const bool row_ok = row < n_rows;
+                        if (!FILTER) {
+                            const float v_off = voff_s[jt * 16 + i_e];
+                            const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+                            const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float sc = (multiplier * (float)acc[it][jt][e] + qo[e]) + v_off;
+                                if (row_ok && q + e < n_queries) out[(uint64_t)(q + e) * out_pitch + row] = sc;
+                            }
+                        } else {
+                            const int a0 = acc[it][jt][0], a1 = acc[it][jt][1], a2 = acc[it][jt][2], a3 = acc[it][jt][3];
+                            const bool may_pass = LOW ? ((a0 | a1 | a2 | a3) < 0) : ((a0 & a1 & a2 & a3) >= 0);
+                            if (may_pass) {
+                                const float v_off = voff_s[jt * 16 + i_e];
+                                const v4i bq4 = *reinterpret_cast<const v4i *>(bq_all + q);
+                                const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+                                const float4 pv4 = *reinterpret_cast<const float4 *>(filt.pivot_scores + q);
+                                const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                                const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                                const int av[4] = {a0, a1, a2, a3};
+                                const int brj = br_s[jt * 16 + i_e];
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int s_int = av[e] + bq4[e] + brj;  // the plain integer dot product
+                                    const float sc = (multiplier * (float)s_int + qo[e]) + v_off;
+                                    const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
+                                    if (d >= 0.0f) {
+                                        const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                        if (pos < filt.wave_cap)
+                                            wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row,
+                                                                        filt.query_base + q + e, 0u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // the next chunk's k-steps 0 and 1 belong in Q0 and Q1: after one left-over step they sit in Q1, Q2; after two in Q2, Q0
+            if (left == 1) {
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    Q0[it] = Q1[it];
+                    Q1[it] = Q2[it];
+                }
+            } else if (left == 2) {
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const v4i k1 = Q0[it];
+                    Q0[it] = Q2[it];
+                    Q1[it] = k1;
+                }
+            }
+            lap(4);
+        }
+        fill_request(next_blk);
+    }
+    if (timed && lane == 0 && blockIdx.x < kStampBlocks) {
+        unsigned long long *o = stamps + ((uint64_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 6; i++) o[i] = tm_acc[i];
+        o[6] = __builtin_amdgcn_s_memtime() - tm_first;
+        o[7] = __builtin_amdgcn_s_memrealtime() - rt_first;
+        o[15] = 1;
+    }
+    if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+}
+
 }  // namespace
 
 struct qamd_u8_query_batch {
@@ -1307,6 +1663,7 @@ struct qamd_u8_query_batch {
     DevBuf offsets;      // [q_pad] f32
     DevBuf frag;         // the codes again in MFMA fragment order (swizzle_queries_kernel), for u8_gemm_qs_kernel
     uint32_t frag_nkb = 0;  // 128-byte K-blocks per query in `frag`
+    bool frag16 = false;    // `frag` is in the order of u8_gemm_qs16_kernel (16-query tiles), else of u8_gemm_qs_kernel
 };
 
 namespace {
@@ -1511,11 +1868,50 @@ qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
     return QAMD_OK;
 }
 
+// The same on v_mfma_i32_16x16x64_i8 (u8_gemm_qs16_kernel): rows of up to 1024 bytes, the batch's fragment copy in its order.
+inline bool qs16_wanted(uint32_t nkb) {
+    static const char *e = getenv("QAMD_QS16");  // developer A/B: 0 = the 32x32x32 kernel for every row length
+    return nkb >= 1 && nkb <= 8 && !(e && e[0] == '0');
+}
+
+template <int MODE, bool LOW>
+qamd_status launch_gemm_qs16_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                                 const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                                 const BatchFilter &filt, const int *bq, hipStream_t s) {
+    static std::atomic<uint64_t> set_on{0};
+    if (first_use_on_device(set_on))
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs16_kernel<MODE, LOW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const uint32_t nkb = b->frag_nkb;
+    constexpr int QS_ROWS = 128;
+    const uint32_t per = (uint32_t)(h->meta.actual_dim / 16);
+    const size_t lds_bytes = (size_t)QS_ROWS * (((per + 15) / 16) * 256) + 2 * QS_ROWS * 4 + 64 + kQsSlice * 4;
+    const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
+    for (uint64_t q_base = 0; q_base < b->n_queries; q_base += kQsSlice) {
+        const uint32_t nq = (uint32_t)std::min<uint64_t>(kQsSlice, b->n_queries - q_base);
+        BatchFilter f = filt;
+        if (MODE == 1 || MODE == 2) {
+            f.pivot_scores += q_base;
+            f.query_base = (uint32_t)q_base;
+            f.wave_base = (uint32_t)(q_base / kQsSlice) * pp_waves_per_launch();
+        }
+        hipLaunchKernelGGL((u8_gemm_qs16_kernel<MODE, LOW>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
+                           b->frag.as<uint4>() + (q_base / 16) * nkb * 128, b->offsets.as<float>() + q_base,
+                           (MODE == 1 || MODE == 2) ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,
+                           (uint32_t)round_up((uint64_t)nq, 64), (uint32_t)h->meta.actual_dim,
+                           (MODE == 0 || MODE == 3) ? out + q_base * out_pitch : out, out_pitch, f);
+        QAMD_HIP(hipGetLastError());
+    }
+    return QAMD_OK;
+}
+
 template <int MODE>
 qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
     const bool wide = b->frag_nkb <= 9;  // 128 resident rows fit (rows of up to 1152 B), else 96
+    if (b->frag16 && MODE == 0) return launch_gemm_qs16_cfg<0, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    if (b->frag16 && MODE == 3) return launch_gemm_qs16_cfg<3, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
     if (MODE == 0)
         return wide ? launch_gemm_qs_cfg<0, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
                     : launch_gemm_qs_cfg<0, false, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
@@ -1533,6 +1929,9 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
         hipLaunchKernelGGL(qs_bounds_kernel<false>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
                            b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
     QAMD_HIP(hipGetLastError());
+    if (b->frag16)
+        return low ? launch_gemm_qs16_cfg<M, true>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
+                   : launch_gemm_qs16_cfg<M, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
     if (wide)
         return low ? launch_gemm_qs_cfg<M, true, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
                    : launch_gemm_qs_cfg<M, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
@@ -1676,8 +2075,13 @@ qamd_status qamd_u8_encode_query_batch(const qamd_u8 *h, const float *queries, u
             const size_t frag_bytes = (size_t)(q_pad / 32) * nkb * 4096;
             if (b->frag.bytes < frag_bytes) QAMD_TRY(b->frag.alloc(frag_bytes));
             b->frag_nkb = nkb;
-            hipLaunchKernelGGL(swizzle_queries_kernel, dim3((unsigned)std::min<uint64_t>(2048, (frag_bytes / 16 + 255) / 256)),
-                               dim3(256), 0, s, b->codes.as<uint8_t>(), (uint32_t)b->pitch, (uint32_t)q_pad, nkb, b->frag.as<uint4>());
+            b->frag16 = qs16_wanted(nkb);
+            if (b->frag16)
+                hipLaunchKernelGGL(swizzle_queries16_kernel, dim3((unsigned)std::min<uint64_t>(2048, (frag_bytes / 16 + 255) / 256)),
+                                   dim3(256), 0, s, b->codes.as<uint8_t>(), (uint32_t)b->pitch, (uint32_t)q_pad, nkb, b->frag.as<uint4>());
+            else
+                hipLaunchKernelGGL(swizzle_queries_kernel, dim3((unsigned)std::min<uint64_t>(2048, (frag_bytes / 16 + 255) / 256)),
+                                   dim3(256), 0, s, b->codes.as<uint8_t>(), (uint32_t)b->pitch, (uint32_t)q_pad, nkb, b->frag.as<uint4>());
             QAMD_HIP(hipGetLastError());
         } else {
             b->frag_nkb = 0;

@@ -355,13 +355,18 @@ print("ok")
     assert res.returncode == 0 and "ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
 
 
-# ---- query-streaming kernel (u8_gemm_qs_kernel): rows of up to 1536 code bytes, from 960 / 385 / 257 / 320 queries
-# (rows of up to 384 / 768 / 1152 / 1536 bytes: qs_min_queries in csrc/u8_batch.hip)
+# ---- query-streaming kernels (u8_gemm_qs16_kernel on 16x16x64 MFMAs for rows of up to 1024 code bytes, u8_gemm_qs_kernel
+# on 32x32x32 up to 1536): from 385 / 257 / 320 queries (rows of up to 384 / 1152 / 1536 bytes: qs_min_queries)
 @pytest.mark.parametrize("n,dim,nq", [
-    (33_000, 768, 385),     # the first batch size past three row-streaming tiles: 7 query chunks over 8 waves
-    (33_000, 768, 384),     # ... and the last one the row-streaming kernel keeps
+    (33_000, 768, 257),     # the first batch size past two row-streaming tiles: 5 query chunks, three waves idle
+    (33_000, 768, 256),     # ... and the last one the row-streaming kernel keeps
+    (33_000, 768, 385),
     (33_000, 512, 390),
-    (33_000, 1024, 257),    # rows past 768 bytes: from the third tile on; 5 chunks, three waves idle
+    (33_000, 1024, 700),    # the longest row of the 16x16x64 form: 16 k-steps (one left over after five turns of three)
+    (33_000, 896, 300),     # 14 k-steps (two left over)
+    (33_000, 640, 300),     # rows that end inside a 256-byte LDS group (pitch 768)
+    (33_000, 256, 400),     # 4 k-steps
+    (33_000, 1040, 300),    # one step longer: the 32x32x32 form
     (40_003, 96, 704),      # one K-block per row (odd count)
     (35_000, 200, 800),     # row length 208, two K-blocks; 13 query chunks over 8 waves
     (70_001, 384, 1024),    # three K-blocks (odd), two chunks per wave, several row blocks per workgroup, ragged tail

@@ -24,7 +24,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda", 0)
 NQ = [2, 4, 5, 31, 32, 33, 64, 65, 127, 128, 129, 200, 256, 257, 300, 384, 385, 511, 512, 640, 703, 704, 705, 768, 959, 960, 1000, 1024, 1100, 2047, 2048,
       2049, 2500]
-DIMS = [16, 17, 64, 100, 128, 129, 144, 256, 300, 384, 512, 700, 768, 1000, 1024, 1152, 1153, 1168, 1300, 1536, 1537, 1552, 2000, 2304,
+DIMS = [16, 17, 64, 100, 128, 129, 144, 256, 300, 384, 512, 640, 700, 768, 896, 1000, 1024, 1040, 1152, 1153, 1168, 1300, 1536, 1537, 1552, 2000, 2304,
         2320, 4608, 4700]
 t0 = time.time()
 bad = 0
