@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs_kernel(const uint8_t *__restri
 //     by (row & 15): lane (i, g) reads chunk 8 kb + 4 s + g of row 16 jt + i, and the 16 lanes of every ds_read_b128
 //     group ({0-3, 12-15, 20-27}, ...: two values of g) land on 16 different slots;
 //   * lane (i, g) ends up with queries 4 g .. 4 g + 3 of the tile against row i of the tile: four accumulators.
-// Rows of up to 1024 bytes (128 x 1024 B of LDS); longer rows keep the 32x32x32 kernel.
+// JT = 8: 128 resident rows, rows of up to 1024 bytes (128 KiB of LDS); JT = 6: 96 rows of up to 1536 bytes (144 KiB).
 __global__ __launch_bounds__(256) void swizzle_queries16_kernel(const uint8_t *__restrict__ codes, uint32_t pitch,
                                                                uint32_t q_pad, uint32_t nkb, uint4 *__restrict__ out) {
     // out[((t * nkb + kb) * 2 + s) * 64 + lane] = bytes [128 kb + 64 s + 16 g, +16) of query 16 t + i
@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(256) void swizzle_queries16_kernel(const uint8_t *_
     }
 }
 
-template <int MODE, bool LOW>
+template <int MODE, bool LOW, int JT>
 __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__restrict__ codes,
                                                           const float *__restrict__ v_offsets,
                                                           const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
                                                           uint32_t n_queries, uint32_t q_pad, uint32_t ad,
                                                           float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
-    constexpr int IT = 4, JT = 8, KB = 128, QS_ROWS = 16 * JT;  // 64 queries x 128 rows per wave and chunk
+    constexpr int IT = 4, KB = 128, QS_ROWS = 16 * JT, JH = JT / 2;  // 64 queries x 128 (96) rows per wave and chunk
     constexpr bool FILTER = MODE == 1 || MODE == 2;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1382,7 +1382,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
     // with the zero bytes of the query image.
     const uint32_t n_pieces = __builtin_amdgcn_readfirstlane((QS_ROWS * per + 511) / 512);
     const uint32_t p_row0 = (uint32_t)t / per, p_c0 = (uint32_t)t % per, d_row = 512 / per, d_c = 512 % per;
-    constexpr int MAXP = 16;  // rows of up to 1024 bytes: 128 * 64 / 512
+    constexpr int MAXP = JT == 8 ? 16 : 18;  // 128 rows x 64 pieces / 512 threads; 96 x 96 / 512
     v4i st[MAXP];
     float vo_pf = 0.0f;
     auto fill_request = [&](uint32_t blk) {
@@ -1480,16 +1480,16 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
                 asm volatile("" : "+v"(lane_addr));
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    v4i bf[4];
+                    v4i bf[JH];
 #pragma unroll
-                    for (int j4 = 0; j4 < 4; j4++)
-                        bf[j4] = *reinterpret_cast<const v4i *>(lds_raw + lane_addr + (uint32_t)(4 * hf + j4) * 16u * PA);
+                    for (int j4 = 0; j4 < JH; j4++)
+                        bf[j4] = *reinterpret_cast<const v4i *>(lds_raw + lane_addr + (uint32_t)(JH * hf + j4) * 16u * PA);
 #pragma unroll
                     for (int it = 0; it < IT; it++)
 #pragma unroll
-                        for (int j4 = 0; j4 < 4; j4++)
-                            acc[it][4 * hf + j4] =
-                                __builtin_amdgcn_mfma_i32_16x16x64_i8(a[it], bf[j4], acc[it][4 * hf + j4], 0, 0, 0);
+                        for (int j4 = 0; j4 < JH; j4++)
+                            acc[it][JH * hf + j4] =
+                                __builtin_amdgcn_mfma_i32_16x16x64_i8(a[it], bf[j4], acc[it][JH * hf + j4], 0, 0, 0);
                 }
             };
             // k-step j >= nsteps of a chunk is k-step j - nsteps of the next one (its first two are requested under this
@@ -1871,19 +1871,19 @@ qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
 // The same on v_mfma_i32_16x16x64_i8 (u8_gemm_qs16_kernel): rows of up to 1024 bytes, the batch's fragment copy in its order.
 inline bool qs16_wanted(uint32_t nkb) {
     static const char *e = getenv("QAMD_QS16");  // developer A/B: 0 = the 32x32x32 kernel for every row length
-    return nkb >= 1 && nkb <= 8 && !(e && e[0] == '0');
+    return nkb >= 1 && nkb <= 12 && !(e && e[0] == '0');
 }
 
-template <int MODE, bool LOW>
+template <int MODE, bool LOW, int JT>
 qamd_status launch_gemm_qs16_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                                  const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                                  const BatchFilter &filt, const int *bq, hipStream_t s) {
     static std::atomic<uint64_t> set_on{0};
     if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs16_kernel<MODE, LOW>),
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs16_kernel<MODE, LOW, JT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t nkb = b->frag_nkb;
-    constexpr int QS_ROWS = 128;
+    constexpr int QS_ROWS = 16 * JT;
     const uint32_t per = (uint32_t)(h->meta.actual_dim / 16);
     const size_t lds_bytes = (size_t)QS_ROWS * (((per + 15) / 16) * 256) + 2 * QS_ROWS * 4 + 64 + kQsSlice * 4;
     const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
@@ -1895,7 +1895,7 @@ qamd_status launch_gemm_qs16_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b,
             f.query_base = (uint32_t)q_base;
             f.wave_base = (uint32_t)(q_base / kQsSlice) * pp_waves_per_launch();
         }
-        hipLaunchKernelGGL((u8_gemm_qs16_kernel<MODE, LOW>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
+        hipLaunchKernelGGL((u8_gemm_qs16_kernel<MODE, LOW, JT>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
                            b->frag.as<uint4>() + (q_base / 16) * nkb * 128, b->offsets.as<float>() + q_base,
                            (MODE == 1 || MODE == 2) ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,
                            (uint32_t)round_up((uint64_t)nq, 64), (uint32_t)h->meta.actual_dim,
@@ -1910,8 +1910,13 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
     const bool wide = b->frag_nkb <= 9;  // 128 resident rows fit (rows of up to 1152 B), else 96
-    if (b->frag16 && MODE == 0) return launch_gemm_qs16_cfg<0, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
-    if (b->frag16 && MODE == 3) return launch_gemm_qs16_cfg<3, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    const bool tall = b->frag_nkb <= 8;  // 16x16x64 form: 128 resident rows of up to 1024 bytes, else 96
+    if (b->frag16 && MODE == 0)
+        return tall ? launch_gemm_qs16_cfg<0, false, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
+                    : launch_gemm_qs16_cfg<0, false, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    if (b->frag16 && MODE == 3)
+        return tall ? launch_gemm_qs16_cfg<3, false, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
+                    : launch_gemm_qs16_cfg<3, false, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
     if (MODE == 0)
         return wide ? launch_gemm_qs_cfg<0, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
                     : launch_gemm_qs_cfg<0, false, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
@@ -1929,9 +1934,12 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
         hipLaunchKernelGGL(qs_bounds_kernel<false>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
                            b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
     QAMD_HIP(hipGetLastError());
+    if (b->frag16 && tall)
+        return low ? launch_gemm_qs16_cfg<M, true, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
+                   : launch_gemm_qs16_cfg<M, false, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
     if (b->frag16)
-        return low ? launch_gemm_qs16_cfg<M, true>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
-                   : launch_gemm_qs16_cfg<M, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
+        return low ? launch_gemm_qs16_cfg<M, true, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
+                   : launch_gemm_qs16_cfg<M, false, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
     if (wide)
         return low ? launch_gemm_qs_cfg<M, true, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
                    : launch_gemm_qs_cfg<M, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
@@ -2258,7 +2266,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
             // 10M rows); the pivot is the r-th best of those: the r best sample rows of a query share a
             // block with probability ~ r^2 / (2 blocks), and a pivot that is a little off only moves the
             // candidate count (the filter pass, not the pivot, decides what is in the result)
-            const uint32_t rows_per_block = b->frag_nkb <= 9 ? 128 : 96, s_blocks = (S + rows_per_block - 1) / rows_per_block;
+            const uint32_t rows_per_block = (b->frag16 ? b->frag_nkb <= 8 : b->frag_nkb <= 9) ? 128 : 96, s_blocks = (S + rows_per_block - 1) / rows_per_block;
             BatchFilter fs{};
             fs.largest = largest;
             QAMD_TRY(launch_gemm_qs<3>(h, b, s_codes, s_offs, S, s_scores, s_blocks, fs, s));
