@@ -14,14 +14,16 @@
 // K index is only a summation index, so lane (r, h) simply takes bytes [32s + 16h, +16) of
 // query/row r in k-step s: fragments are plain 16-byte pieces, no transposition anywhere.
 //
-// Four kernels share the arithmetic, the integer pre-filter and the epilogue; launch_gemm picks by what
+// Five kernels share the arithmetic, the integer pre-filter and the epilogue; launch_gemm picks by what
 // is re-read and from where (DESIGN.md 3.3b has the table and the measurements):
 //   * u8_gemm_rs_kernel<MODE, LOW, MI, NT> -- row-streaming: up to 128 queries (and several 128-query
 //     tiles up to ~700): the query tile resident in LDS, every wave streams its own rows HBM ->
 //     registers (coalesced, nt) -> wave-private LDS transpose -> MFMA.  HBM-bound, no barriers.
-//   * u8_gemm_qs_kernel<MODE, LOW, MJ> -- query-streaming: many queries on rows of up to 1536 B: 128
-//     (96) store rows resident in LDS, the batch streamed from L2 in MFMA fragment order straight
-//     into operand registers.  Rows leave HBM once; the reuse needs no co-scheduling of workgroups.
+//   * u8_gemm_qs16_kernel<MODE, LOW, JT> / u8_gemm_qs_kernel<MODE, LOW, MJ> -- query-streaming: many queries on
+//     rows of up to 1536 B: 128 (96) store rows resident in LDS, the batch streamed from L2 in MFMA fragment
+//     order straight into operand registers.  Rows leave HBM once; the reuse needs no co-scheduling of
+//     workgroups.  qs16 (round 3, the default) runs on v_mfma_i32_16x16x64_i8, which this part clocks a fifth
+//     higher under load than the 32x32x32 instruction of the round-2 form (QAMD_QS16=0 selects that one).
 //   * u8_gemm_pp_kernel<MODE, LOW, MI, MJ> -- ping-pong (round 1): both operands through an LDS-DMA
 //     ring, two wave groups half a phase apart; now for what the two above do not take.
 //   * u8_gemm_kernel<MODE, TQ, TR, WQ, WR, BK> -- the first version (128-byte K slabs through
