@@ -1501,6 +1501,9 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
                 else load_step(a, c_next, j - nsteps);
             };
             lap(2);
+            // (the two waves of a SIMD take turns at priority chunk by chunk, as in u8_gemm_qs_kernel; without it the older
+            // wave wins every arbitration and idles a quarter of the block at the barrier; flipping every turn of three
+            // k-steps instead balances no better: both measured)
             if (((c >> 3) + ((uint32_t)wave >> 2)) & 1u) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
             // at entry Q0 = k-step 0 and Q1 = k-step 1 are on their way; sched_barrier: the four loads are issued HERE
