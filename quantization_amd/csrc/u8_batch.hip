@@ -19,7 +19,7 @@
 //   * u8_gemm_rs_kernel<MODE, LOW, MI, NT> -- row-streaming: up to 128 queries (and several 128-query
 //     tiles up to ~700): the query tile resident in LDS, every wave streams its own rows HBM ->
 //     registers (coalesced, nt) -> wave-private LDS transpose -> MFMA.  HBM-bound, no barriers.
-//   * u8_gemm_qs16_kernel<MODE, LOW, JT> / u8_gemm_qs_kernel<MODE, LOW, MJ> -- query-streaming: many queries on
+//   * u8_gemm_qs16_kernel<MODE, LOW, JT, IT> / u8_gemm_qs_kernel<MODE, LOW, MJ> -- query-streaming: many queries on
 //     rows of up to 1536 B: 128 (96) store rows resident in LDS, the batch streamed from L2 in MFMA fragment
 //     order straight into operand registers.  Rows leave HBM once; the reuse needs no co-scheduling of
 //     workgroups.  qs16 (round 3, the default) runs on v_mfma_i32_16x16x64_i8, which this part clocks a fifth
@@ -292,8 +292,12 @@ constexpr int PP_KT = 64;  // K-tile bytes per row
 //   rows of 1024 B, 7.5M:  192 q  2.22 / 2.21    257 q  3.41 / 2.74    385 q  4.76 / 3.25    704 q  8.61 / 4.89
 //   rows <= 1536 B: 12.5M x 1536: 256 q  pp 5.84 qs 6.34; 384 q  pp 10.3 qs 8.8; 640 q  pp 16.1 qs 13.8   (round 2)
 // i.e. from the third 128-query tile on (the fourth for rows of up to 384 bytes); the round-2 thresholds (960 / 704)
-// dated from before that round's block-change and epilogue work and this round's matrix instruction.
-inline uint64_t qs_min_queries(uint32_t nkb) { return nkb <= 3 ? 385 : nkb <= 9 ? 257 : 320; }
+// dated from before that round's block-change and epilogue work and this round's matrix instruction.  With chunks of 32
+// queries for batches of up to 256 (a chunk for every wave) the second tile goes the same way on rows past 768 bytes:
+//   rows of 768 B,  10M:   129 q  2.18 / 2.06    192 q  2.2-2.5 / 2.20    256 q  2.31 / 2.49     (kept on row-streaming)
+//   rows of 1024 B, 7.5M:  129 q  2.22 / 2.02    192 q  2.26 / 2.11       256 q  2.80 / 2.37
+//   rows of 1536 B, 12.5M: 129 q  5.44 / 4.88    192 q  5.53 / 5.23       256 q  6.87 / 5.90
+inline uint64_t qs_min_queries(uint32_t nkb) { return nkb <= 3 ? 385 : nkb <= 6 ? 257 : 129; }
 // Workgroup shapes (8 waves as 2 query groups x 4 row groups; a wave owns MI x MJ 32x32 tiles):
 //   <4,2>: 256 queries x 256 rows, ring of 4 x 32 KiB  -- more than 128 queries, MFMA-bound
 //   <2,4>: 128 queries x 512 rows, ring of 3 x 40 KiB  -- up to 128 queries: the store is streamed
@@ -1330,7 +1334,9 @@ __global__ __launch_bounds__(256) void swizzle_queries16_kernel(const uint8_t *_
     }
 }
 
-template <int MODE, bool LOW, int JT>
+// IT: 16-query tiles per wave and chunk: 4 (64 queries), or 2 for small batches - 129 .. 256 queries are 5 .. 8 chunks of 32,
+// one for each of the 8 waves, where chunks of 64 would leave half of them idle.
+template <int MODE, bool LOW, int JT, int IT>
 __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__restrict__ codes,
                                                           const float *__restrict__ v_offsets,
                                                           const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
@@ -1338,7 +1344,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
                                                           uint32_t n_queries, uint32_t q_pad, uint32_t ad,
                                                           float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
-    constexpr int IT = 4, KB = 128, QS_ROWS = 16 * JT, JH = JT / 2;  // 64 queries x 128 (96) rows per wave and chunk
+    constexpr int KB = 128, QS_ROWS = 16 * JT, JH = JT / 2, CQ = 16 * IT;  // CQ queries x 128 (96) rows per wave and chunk
     constexpr bool FILTER = MODE == 1 || MODE == 2;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1347,15 +1353,15 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
     const uint32_t per = ad / 16;                                              // 16-byte chunks per row
     const uint32_t PA = __builtin_amdgcn_readfirstlane(((per + 15) / 16) * 256);  // LDS pitch: whole 256-byte bank rows
     const uint32_t n_blocks = (n_rows + QS_ROWS - 1) / QS_ROWS;
-    const uint32_t live_chunks = (n_queries + 63) / 64;
+    const uint32_t live_chunks = (n_queries + CQ - 1) / CQ;
     float *voff_s = reinterpret_cast<float *>(lds_raw + (size_t)QS_ROWS * PA);  // [128]
     int *br_s = reinterpret_cast<int *>(voff_s + QS_ROWS);                       // [128]
     uint32_t *wcount_s = reinterpret_cast<uint32_t *>(br_s + QS_ROWS) + wave;
-    int *bq_s = reinterpret_cast<int *>(br_s + QS_ROWS) + 16;                    // [64 * live_chunks] integer query bounds
+    int *bq_s = reinterpret_cast<int *>(br_s + QS_ROWS) + 16;                    // [CQ * live_chunks] integer query bounds
     constexpr bool LARGEST = MODE == 1;
     if (FILTER && lane == 0) *wcount_s = 0;
     if (FILTER)
-        for (uint32_t i = t; i < 64 * live_chunks; i += 512) bq_s[i] = bq_all[i];
+        for (uint32_t i = t; i < CQ * live_chunks; i += 512) bq_s[i] = bq_all[i];
     const float never = (MODE == 3 ? filt.largest != 0 : LARGEST) ? -__builtin_huge_valf() : __builtin_huge_valf();
 
     // streamed operand: chunk c, k-step j (64 bytes of K: K-block j / 2, half j % 2) -> one 1 KiB piece per 16-query tile
@@ -1365,7 +1371,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
     const uint32_t nsteps = 2 * nkb;
     v4i Q0[IT], Q1[IT], Q2[IT];
     auto load_step = [&](v4i(&a)[IT], uint32_t c, uint32_t j) {
-        const uint4 *p = qfrag + ((uint64_t)(4 * c) * nkb * 2 + j) * 64 + lane;  // (tile 4c, K-block j / 2, half j % 2)
+        const uint4 *p = qfrag + ((uint64_t)(IT * c) * nkb * 2 + j) * 64 + lane;  // (tile IT c, K-block j / 2, half j % 2)
 #pragma unroll
         for (int it = 0; it < IT; it++) {
             const uint4 v = p[(uint64_t)it * nkb * 128];
@@ -1465,7 +1471,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
 #pragma unroll
                 for (int it = 0; it < IT; it++) {
                     v4i bq4 = {0, 0, 0, 0};
-                    if (FILTER) bq4 = *reinterpret_cast<const v4i *>(bq_s + 64 * c + 16 * it + 4 * g4);
+                    if (FILTER) bq4 = *reinterpret_cast<const v4i *>(bq_s + CQ * c + 16 * it + 4 * g4);
 #pragma unroll
                     for (int jt = 0; jt < JT; jt++)
 #pragma unroll
@@ -1548,7 +1554,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
                 for (int jt = 0; jt < JT; jt++) vo3[jt] = voff_s[jt * 16 + i_e];  // `never` for rows past the end
 #pragma unroll
                 for (int it = 0; it < IT; it++) {
-                    const uint32_t q = 64 * c_e + 16 * it + 4 * g_e;
+                    const uint32_t q = CQ * c_e + 16 * it + 4 * g_e;
                     const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
                     const float qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
 #pragma unroll
@@ -1571,7 +1577,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
                 uint4 *wave_list = FILTER ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave_e) * filt.wave_cap : nullptr;
 #pragma unroll
                 for (int it = 0; it < IT; it++) {
-                    const uint32_t q = 64 * c_e + 16 * it + 4 * g_e;  // first of this lane's four consecutive queries
+                    const uint32_t q = CQ * c_e + 16 * it + 4 * g_e;  // first of this lane's four consecutive queries
                     if (FILTER) {
                         // "some accumulator of these 8 tiles may pass" = the smallest is negative (LOW) / the largest is not
                         int ext = acc[it][0][0];
@@ -1874,18 +1880,19 @@ qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
 }
 
 // The same on v_mfma_i32_16x16x64_i8 (u8_gemm_qs16_kernel): rows of up to 1024 bytes, the batch's fragment copy in its order.
+constexpr uint64_t kQs16SmallBatch = 256;
 inline bool qs16_wanted(uint32_t nkb) {
     static const char *e = getenv("QAMD_QS16");  // developer A/B: 0 = the 32x32x32 kernel for every row length
     return nkb >= 1 && nkb <= 12 && !(e && e[0] == '0');
 }
 
-template <int MODE, bool LOW, int JT>
+template <int MODE, bool LOW, int JT, int IT>
 qamd_status launch_gemm_qs16_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                                  const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                                  const BatchFilter &filt, const int *bq, hipStream_t s) {
     static std::atomic<uint64_t> set_on{0};
     if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs16_kernel<MODE, LOW, JT>),
+        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs16_kernel<MODE, LOW, JT, IT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t nkb = b->frag_nkb;
     constexpr int QS_ROWS = 16 * JT;
@@ -1900,7 +1907,7 @@ qamd_status launch_gemm_qs16_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b,
             f.query_base = (uint32_t)q_base;
             f.wave_base = (uint32_t)(q_base / kQsSlice) * pp_waves_per_launch();
         }
-        hipLaunchKernelGGL((u8_gemm_qs16_kernel<MODE, LOW, JT>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
+        hipLaunchKernelGGL((u8_gemm_qs16_kernel<MODE, LOW, JT, IT>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,
                            b->frag.as<uint4>() + (q_base / 16) * nkb * 128, b->offsets.as<float>() + q_base,
                            (MODE == 1 || MODE == 2) ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,
                            (uint32_t)round_up((uint64_t)nq, 64), (uint32_t)h->meta.actual_dim,
@@ -1916,12 +1923,14 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
                            const BatchFilter &filt, hipStream_t s) {
     const bool wide = b->frag_nkb <= 9;  // 128 resident rows fit (rows of up to 1152 B), else 96
     const bool tall = b->frag_nkb <= 8;  // 16x16x64 form: 128 resident rows of up to 1024 bytes, else 96
-    if (b->frag16 && MODE == 0)
-        return tall ? launch_gemm_qs16_cfg<0, false, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
-                    : launch_gemm_qs16_cfg<0, false, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
-    if (b->frag16 && MODE == 3)
-        return tall ? launch_gemm_qs16_cfg<3, false, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
-                    : launch_gemm_qs16_cfg<3, false, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    const bool small = b->n_queries <= kQs16SmallBatch;  // chunks of 32 queries: a chunk for every wave
+#define QAMD_QS16(M_, LOW_, BQ_)                                                                                                  \
+    (tall ? (small ? launch_gemm_qs16_cfg<M_, LOW_, 8, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, BQ_, s)           \
+                   : launch_gemm_qs16_cfg<M_, LOW_, 8, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, BQ_, s))          \
+          : (small ? launch_gemm_qs16_cfg<M_, LOW_, 6, 2>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, BQ_, s)           \
+                   : launch_gemm_qs16_cfg<M_, LOW_, 6, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, BQ_, s)))
+    if (b->frag16 && MODE == 0) return QAMD_QS16(0, false, nullptr);
+    if (b->frag16 && MODE == 3) return QAMD_QS16(3, false, nullptr);
     if (MODE == 0)
         return wide ? launch_gemm_qs_cfg<0, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s)
                     : launch_gemm_qs_cfg<0, false, 3>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
@@ -1939,12 +1948,8 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
         hipLaunchKernelGGL(qs_bounds_kernel<false>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
                            b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
     QAMD_HIP(hipGetLastError());
-    if (b->frag16 && tall)
-        return low ? launch_gemm_qs16_cfg<M, true, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
-                   : launch_gemm_qs16_cfg<M, false, 8>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
-    if (b->frag16)
-        return low ? launch_gemm_qs16_cfg<M, true, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
-                   : launch_gemm_qs16_cfg<M, false, 6>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
+    if (b->frag16) return low ? QAMD_QS16(M, true, bq) : QAMD_QS16(M, false, bq);
+#undef QAMD_QS16
     if (wide)
         return low ? launch_gemm_qs_cfg<M, true, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
                    : launch_gemm_qs_cfg<M, false, 4>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);

@@ -356,8 +356,12 @@ print("ok")
 
 
 # ---- query-streaming kernels (u8_gemm_qs16_kernel on 16x16x64 MFMAs for rows of up to 1024 code bytes, u8_gemm_qs_kernel
-# on 32x32x32 up to 1536): from 385 / 257 / 320 queries (rows of up to 384 / 1152 / 1536 bytes: qs_min_queries)
+# on 32x32x32 up to 1536): from 385 / 257 / 129 queries (rows of up to 384 / 768 / 1536 bytes: qs_min_queries); batches of up
+# to 256 queries in chunks of 32 per wave
 @pytest.mark.parametrize("n,dim,nq", [
+    (33_000, 1024, 129),    # 5 chunks of 32 queries
+    (33_000, 1024, 256),    # 8 chunks of 32: the last batch size of the small-chunk form
+    (33_000, 1536, 200),    # 96 resident rows, chunks of 32
     (33_000, 768, 257),     # the first batch size past two row-streaming tiles: 5 query chunks, three waves idle
     (33_000, 768, 256),     # ... and the last one the row-streaming kernel keeps
     (33_000, 768, 385),
