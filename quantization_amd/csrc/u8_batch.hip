@@ -325,6 +325,17 @@ __device__ __forceinline__ void pp_glds16(const uint8_t *src, uint8_t *lds_dst) 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
+// The same instruction behind the compiler's back (wave-uniform base + 32-bit lane offset, nontemporal).  A kernel whose
+// LDS reads must not wait for the DMA needs it: with the builtin the compiler cannot tell the slab being filled from the
+// slab being read and puts s_waitcnt vmcnt(0) in front of every ds_read.  The caller orders the reads itself
+// (s_waitcnt vmcnt(0) + barrier before a slab is read).  m0 is saved and restored around it.
+__device__ __forceinline__ void glds16_nt_unordered(const uint8_t *base, uint32_t lane_offset, uint32_t lds_addr) {
+    uint32_t saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0)
+                 : "v"(lane_offset), "s"(base), "s"(lds_addr)
+                 : "memory");
+}
 __device__ __forceinline__ void pp_wait_vm(uint32_t n) {  // n is wave-uniform; rounded DOWN to a supported count
     if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -1662,6 +1673,275 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
     if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Queries in registers, rows through a double-buffered LDS slab (round 3; v_mfma_i32_16x16x64_i8).  For batches of a few
+// hundred queries the query-streaming kernel is bound by its synchronous row-block change (3.5 us per 128 rows against
+// 2-4 us of MFMAs), and that change cannot be overlapped there: `vmcnt` retires in order, every wave waits for its
+// streamed query fragments once per k-step, and such a wait also waits for an older row DMA.  Here the K loop has NO
+// vector-memory operation: a wave keeps its 32 queries' fragments for ALL k-steps in registers (NSTEPS x 2 x 4: 96 at
+// 768-byte rows - two 16 x 16 x 64 tiles need only 32 accumulator registers against 64 rows), loaded once per launch, so
+// the next 64-row slab can be asked for by LDS-DMA at the START of a block and arrive under this block's MFMAs; the
+// only wait is the one in front of the block-end barrier.  A launch serves 256 queries (8 waves x 32); a batch is cut
+// into passes, each of which streams the store once at close to the HBM rate (64 rows x 768 B per CU and ~1.9 us of
+// MFMAs).  Row layout, fragment order and epilogue as in u8_gemm_qs16_kernel; rows of 256 / 512 / 768 / 1024 bytes.
+template <int MODE, bool LOW, int NSTEPS>
+__global__ __launch_bounds__(512) void u8_gemm_qr16_kernel(const uint8_t *__restrict__ codes,
+                                                          const float *__restrict__ v_offsets,
+                                                          const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
+                                                          const int *__restrict__ bq_all, float multiplier, uint32_t n_rows,
+                                                          uint32_t n_queries, uint32_t ad,
+                                                          float *__restrict__ out, uint64_t out_pitch, BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr int IT = 2, JT = 4, QR_ROWS = 16 * JT;  // 32 queries x 64 rows per wave and block
+    constexpr bool FILTER = MODE == 1 || MODE == 2;
+    constexpr bool LARGEST = MODE == 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
+    const uint32_t nkb = __builtin_amdgcn_readfirstlane(ad / 128);  // rows of whole 256 bytes: nkb even, NSTEPS == 2 nkb
+    const uint32_t per = ad / 16, PA = ad;                           // chunks per row; LDS pitch = the row (whole bank rows)
+    const uint32_t SLAB = QR_ROWS * PA;
+    const uint32_t n_blocks = (n_rows + QR_ROWS - 1) / QR_ROWS;
+    float *voff_s = reinterpret_cast<float *>(lds_raw + 2 * (size_t)SLAB);  // [2][64]
+    int *br_s = reinterpret_cast<int *>(voff_s + 2 * QR_ROWS);              // [2][64]
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(br_s + 2 * QR_ROWS) + wave;
+    if (FILTER && lane == 0) *wcount_s = 0;
+    const float never = (MODE == 3 ? filt.largest != 0 : LARGEST) ? -__builtin_huge_valf() : __builtin_huge_valf();
+    const bool live = (uint32_t)wave * 32u < n_queries;  // this wave's 32 queries exist (wave-uniform)
+
+    // row DMA: LDS position p (16-byte units) of a slab = row p / per, place p % per, filled with the row's chunk
+    // place ^ (row & 15); instruction k covers positions [64 k, 64 k + 64), wave w issues k = w, w + 8, ... (per in all)
+    const uint32_t d_pos0 = (uint32_t)wave * 64u + (uint32_t)lane;
+    const uint32_t d_row0 = d_pos0 / per, d_place0 = d_pos0 % per;
+    const uint32_t d_dr = __builtin_amdgcn_readfirstlane(512u / per), d_dc = __builtin_amdgcn_readfirstlane(512u % per);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_raw;
+    float vo_pf = 0.0f;
+    // One DMA instruction occupies the CU's address path for its 1 KiB and holds the issuing wave meanwhile (48 of them at
+    // the start of a block cost every wave ~1300 cycles): the pieces are issued ONE AT A TIME between k-steps, under MFMAs.
+    const uint8_t *d_src = codes;
+    uint32_t d_dst = 0, d_row = 0, d_place = 0, d_i = 0;
+    auto dma_begin = [&](uint32_t blk, uint32_t par) {
+        d_src = codes + (uint64_t)blk * QR_ROWS * ad;
+        d_dst = lds_base + par * SLAB + (uint32_t)wave * 1024u;
+        d_row = d_row0, d_place = d_place0, d_i = 0;
+        vo_pf = v_offsets[(uint64_t)blk * QR_ROWS + (t < QR_ROWS ? t : 0)];  // padded like codes[]
+    };
+    auto dma_piece = [&]() {  // piece d_i of this wave (per <= 64 instructions of 1 KiB per slab: at most 8 per wave)
+        if ((uint32_t)wave + 8u * d_i < per)
+            glds16_nt_unordered(d_src, d_row * ad + ((d_place ^ (d_row & 15u)) * 16u), __builtin_amdgcn_readfirstlane(d_dst + d_i * 8192u));
+        d_row += d_dr;
+        d_place += d_dc;
+        if (d_place >= per) {
+            d_place -= per;
+            d_row++;
+        }
+        d_i++;
+    };
+    auto dma_request = [&](uint32_t blk, uint32_t par) {  // all pieces at once (the first block; waves without queries)
+        dma_begin(blk, par);
+        for (int i = 0; i < 8; i++) dma_piece();
+    };
+    auto tables_write = [&](uint64_t row0, uint32_t par) {
+        if (t < QR_ROWS) {
+            const bool ok = row0 + t < n_rows;
+            const float vo = vo_pf;
+            voff_s[par * QR_ROWS + t] = ok ? vo : never;
+            if (FILTER) br_s[par * QR_ROWS + t] = ok ? pp_bound<LOW>(-vo, fabsf(vo), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+        }
+    };
+    const uint32_t first_blk = blockIdx.x < n_blocks ? blockIdx.x : 0u;
+    dma_request(first_blk, 0u);
+    // this wave's queries: tiles 2 wave and 2 wave + 1, every k-step, for the whole launch
+    v4i Qr[NSTEPS][IT];
+    {
+        const uint4 *p = qfrag + ((uint64_t)(IT * wave) * nkb * 2) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < NSTEPS; j++)
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (live && (uint32_t)j < 2 * nkb) v = p[((uint64_t)it * nkb * 2 + j) * 64];
+                Qr[j][it] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            }
+    }
+    // per-query constants of this lane: queries 32 wave + 16 it + 4 g4 + e
+    v4i bq4[IT];
+    float qo[IT][4];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const uint32_t q = 32u * wave + 16u * it + 4u * g4;
+        bq4[it] = v4i{0, 0, 0, 0};
+        if (FILTER && live) bq4[it] = *reinterpret_cast<const v4i *>(bq_all + q);
+        float4 q4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (live) q4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+        qo[it][0] = q4.x, qo[it][1] = q4.y, qo[it][2] = q4.z, qo[it][3] = q4.w;
+    }
+    const uint32_t b_row = i16 * PA, b_gi = (g4 ^ i16) * 16u;  // see u8_gemm_qs16_kernel
+    unsigned long long *stamps = QAMD_GEMM_STAMPS();
+    const bool timed = stamps != nullptr;
+    unsigned long long tm_prev = timed ? __builtin_amdgcn_s_memtime() : 0ull, tm_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tm_first = tm_prev, rt_first = timed ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto lap = [&](int slot) {
+        if (timed) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tm_acc[slot] += now - tm_prev;
+            tm_prev = now;
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tables_write((uint64_t)first_blk * QR_ROWS, 0u);
+    __syncthreads();
+    uint32_t par = 0;
+    uint4 *wave_list = FILTER ? filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave) * filt.wave_cap : nullptr;
+
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t row0 = (uint64_t)blk * QR_ROWS;
+        const uint32_t next_blk = blk + gridDim.x < n_blocks ? blk + gridDim.x : blk;  // past the end: re-request (harmless)
+        // the next slab arrives under this block's MFMAs: nothing below waits for vector memory
+        if (live) dma_begin(next_blk, par ^ 1u);
+        else dma_request(next_blk, par ^ 1u);
+        lap(5);
+        if (live) {
+            const float *voff_cur = voff_s + par * QR_ROWS;
+            const int *br_cur = br_s + par * QR_ROWS;
+            v4i acc[IT][JT];
+            {
+                int br[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; jt++) br[jt] = FILTER ? br_cur[jt * 16 + i16] : 0;
+#pragma unroll
+                for (int it = 0; it < IT; it++)
+#pragma unroll
+                    for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[it][jt][e] = FILTER ? -(bq4[it][e] + br[jt]) : 0;
+            }
+            lap(2);
+            // the two waves of a SIMD (w, w + 4) take turns at priority block by block (see u8_gemm_qs_kernel)
+            if ((((blk - blockIdx.x) / gridDim.x) + ((uint32_t)wave >> 2)) & 1u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+            const uint32_t slab_addr = par * SLAB;
+#pragma unroll
+            for (int j = 0; j < NSTEPS; j++) {  // NSTEPS == 2 nkb exactly (fully unrolled: Qr[] must stay in registers)
+                if (j < 8) dma_piece();
+                uint32_t lane_addr = slab_addr + b_row + (b_gi ^ ((uint32_t)(j & 3) * 64u)) + (uint32_t)(j >> 2) * 256u;
+                asm volatile("" : "+v"(lane_addr));
+                v4i bf[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; jt++) bf[jt] = *reinterpret_cast<const v4i *>(lds_raw + lane_addr + (uint32_t)jt * 16u * PA);
+#pragma unroll
+                for (int it = 0; it < IT; it++)
+#pragma unroll
+                    for (int jt = 0; jt < JT; jt++)
+                        acc[it][jt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qr[j][it], bf[jt], acc[it][jt], 0, 0, 0);
+            }
+            if (NSTEPS < 8) {  // short rows: fewer k-steps than pieces
+#pragma unroll
+                for (int i = NSTEPS; i < 8; i++) dma_piece();
+            }
+            __builtin_amdgcn_s_setprio(0);
+            lap(3);
+            // ---- epilogue: lane (i16, g4) holds, per (it, jt), queries 32 wave + 16 it + 4 g4 + e against row 16 jt + i16
+            if (MODE == 3) {
+                const bool lg = filt.largest != 0;
+                float vo3[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; jt++) vo3[jt] = voff_cur[jt * 16 + i16];
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const uint32_t q = 32u * wave + 16u * it + 4u * g4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float best = never;
+#pragma unroll
+                        for (int jt = 0; jt < JT; jt++) {
+                            const float sc = (multiplier * (float)acc[it][jt][e] + qo[it][e]) + vo3[jt];
+                            best = lg ? fmaxf(best, sc) : fminf(best, sc);
+                        }
+#pragma unroll
+                        for (int d = 8; d >= 1; d >>= 1) {
+                            const float o = __shfl_xor(best, d);
+                            best = lg ? fmaxf(best, o) : fminf(best, o);
+                        }
+                        if (i16 == 0 && q + e < n_queries) out[(uint64_t)(q + e) * out_pitch + blk] = best;
+                    }
+                }
+            } else {
+                bool any = true;
+                if (FILTER) {  // "some accumulator of the 8 tiles may pass" = the smallest is negative (LOW) / the largest is not
+                    int ext = acc[0][0][0];
+#pragma unroll
+                    for (int it = 0; it < IT; it++)
+#pragma unroll
+                        for (int jt = 0; jt < JT; jt++) {
+                            ext = LOW ? min(min(ext, acc[it][jt][0]), acc[it][jt][1]) : max(max(ext, acc[it][jt][0]), acc[it][jt][1]);
+                            ext = LOW ? min(min(ext, acc[it][jt][2]), acc[it][jt][3]) : max(max(ext, acc[it][jt][2]), acc[it][jt][3]);
+                        }
+                    any = __builtin_amdgcn_readfirstlane(__ballot(LOW ? ext < 0 : ext >= 0) != 0);
+                }
+                if (any) {
+#pragma unroll
+                    for (int it = 0; it < IT; it++) {
+                        const uint32_t q = 32u * wave + 16u * it + 4u * g4;
+#pragma unroll
+                        for (int jt = 0; jt < JT; jt++) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const uint64_t row = row0 + jt * 16 + i16;
+                            const bool row_ok = row < n_rows;
+                            if (!FILTER) {
+                                const float v_off = voff_cur[jt * 16 + i16];
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const float sc = (multiplier * (float)acc[it][jt][e] + qo[it][e]) + v_off;
+                                    if (row_ok && q + e < n_queries) out[(uint64_t)(q + e) * out_pitch + row] = sc;
+                                }
+                            } else {
+                                const int a0 = acc[it][jt][0], a1 = acc[it][jt][1], a2 = acc[it][jt][2], a3 = acc[it][jt][3];
+                                const bool may_pass = LOW ? ((a0 | a1 | a2 | a3) < 0) : ((a0 & a1 & a2 & a3) >= 0);
+                                if (may_pass) {
+                                    const float v_off = voff_cur[jt * 16 + i16];
+                                    const float4 pv4 = *reinterpret_cast<const float4 *>(filt.pivot_scores + q);
+                                    const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+                                    const int av[4] = {a0, a1, a2, a3};
+                                    const int brj = br_cur[jt * 16 + i16];
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) {
+                                        const int s_int = av[e] + bq4[it][e] + brj;  // the plain integer dot product
+                                        const float sc = (multiplier * (float)s_int + qo[it][e]) + v_off;
+                                        const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
+                                        if (d >= 0.0f) {
+                                            const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                            if (pos < filt.wave_cap)
+                                                wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row,
+                                                                            filt.query_base + q + e, 0u);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            lap(4);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next slab (and its row offsets) has landed
+        tables_write((uint64_t)next_blk * QR_ROWS, par ^ 1u);
+        lap(1);
+        __syncthreads();  // ... and so has everybody's; every wave is done with this block's slab
+        lap(0);
+        par ^= 1u;
+    }
+    if (timed && lane == 0 && blockIdx.x < kStampBlocks) {
+        unsigned long long *o = stamps + ((uint64_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 6; i++) o[i] = tm_acc[i];
+        o[6] = __builtin_amdgcn_s_memtime() - tm_first;
+        o[7] = __builtin_amdgcn_s_memrealtime() - rt_first;
+        o[15] = 1;
+    }
+    if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+}
+
 }  // namespace
 
 struct qamd_u8_query_batch {
@@ -1830,7 +2110,9 @@ qamd_status launch_gemm_rs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
 }
 
 // Queries per launch slice of the kernel that serves this batch (wave-list bookkeeping).
+bool qr_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode);
 inline uint32_t gemm_launches(const qamd_u8 *h, const qamd_u8_query_batch *b, bool rs, bool qs) {
+    if (qs && qr_selected(h, b, true)) return (uint32_t)((b->n_queries + 255) / 256);  // passes of the queries-in-registers form
     if (qs) return (uint32_t)((b->n_queries + 2048 - 1) / 2048);
     if (!rs) return pp_launches(b->n_queries);
     const uint64_t per = (uint64_t)std::max(1, device_info().cu_count / 8) * 32 * rs_frags(b->n_queries, h->meta.actual_dim);
@@ -1917,10 +2199,93 @@ qamd_status launch_gemm_qs16_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b,
     return QAMD_OK;
 }
 
+// Queries in registers, rows through a double-buffered LDS slab (u8_gemm_qr16_kernel): batches cut into passes of 256
+// queries.  QAMD_GEMM_CFG=g forces it where it can run (developer A/B); QAMD_QR_MIN / QAMD_QR_MAX move its range.
+// Measured (profiles/r03_qs_experiments.txt §7), whole topk_batch(30) ms, row-streaming passes / this kernel:
+//   10M x 768:    129 q 2.17 / 1.65   192 q 2.21 / 1.75   256 q 2.26 / 1.91     (two passes: 512 q 3.81 against 3.66 query-streaming)
+//   7.5M x 1024:   65 q 1.52 / 1.23   129 q 2.18 / 1.55   256 q 2.75 / 1.84
+//   15M x 512:    129 q 2.28 / 1.76   256 q 2.41 / 2.08       30M x 256:  129 q 2.68 / 2.44   256 q 2.84 / 2.55
+// -> one pass only: 129 .. 256 queries (from 65 on 1024-byte rows, where the row-streaming kernel needs two 64-query tiles).
+constexpr uint64_t kQrQueries = 256;
+inline bool qr_possible(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
+    const float m = h->meta.multiplier;
+    if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
+    const uint64_t ad = h->meta.actual_dim;
+    return b->frag.ptr && b->frag16 && ad % 256 == 0 && ad <= 1024;
+}
+bool qr_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
+    static const char *cfg = getenv("QAMD_GEMM_CFG");
+    static const char *lo = getenv("QAMD_QR_MIN"), *hi = getenv("QAMD_QR_MAX");
+    if (cfg && cfg[0] != 'g') return false;
+    if (!qr_possible(h, b, filter_mode)) return false;
+    if (cfg) return true;
+    const uint64_t q_min = lo ? (uint64_t)atoll(lo) : (h->meta.actual_dim == 1024 ? 65 : 129);
+    const uint64_t q_max = hi ? (uint64_t)atoll(hi) : kQrQueries;
+    return b->n_queries >= q_min && b->n_queries <= q_max;
+}
+
+template <int MODE, bool LOW>
+qamd_status launch_gemm_qr_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                               const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                               const BatchFilter &filt, const int *bq, hipStream_t s) {
+    const uint32_t nkb = b->frag_nkb;
+    const uint64_t ad = h->meta.actual_dim;
+    const size_t lds_bytes = 2 * (size_t)64 * ad + 4 * 64 * 4 + 64;
+    const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
+    for (uint64_t q_base = 0; q_base < b->n_queries; q_base += kQrQueries) {
+        const uint32_t nq = (uint32_t)std::min<uint64_t>(kQrQueries, b->n_queries - q_base);
+        BatchFilter f = filt;
+        if (MODE == 1 || MODE == 2) {
+            f.pivot_scores += q_base;
+            f.query_base = (uint32_t)q_base;
+            f.wave_base = (uint32_t)(q_base / kQrQueries) * pp_waves_per_launch();
+        }
+#define QAMD_QR(NS_)                                                                                                          \
+    do {                                                                                                                     \
+        static std::atomic<uint64_t> set_on{0};                                                                              \
+        if (first_use_on_device(set_on))                                                                                     \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qr16_kernel<MODE, LOW, NS_>),               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                           \
+        hipLaunchKernelGGL((u8_gemm_qr16_kernel<MODE, LOW, NS_>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,     \
+                           b->frag.as<uint4>() + (q_base / 16) * nkb * 128, b->offsets.as<float>() + q_base,                 \
+                           (MODE == 1 || MODE == 2) ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,       \
+                           (uint32_t)ad, (MODE == 0 || MODE == 3) ? out + q_base * out_pitch : out, out_pitch, f);           \
+    } while (0)
+        if (nkb == 2) QAMD_QR(4);
+        else if (nkb == 4) QAMD_QR(8);
+        else if (nkb == 6) QAMD_QR(12);
+        else QAMD_QR(16);
+#undef QAMD_QR
+        QAMD_HIP(hipGetLastError());
+    }
+    return QAMD_OK;
+}
+
+template <int MODE>
+qamd_status launch_gemm_qr(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
+                           const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
+                           const BatchFilter &filt, hipStream_t s) {
+    if (MODE == 0) return launch_gemm_qr_cfg<0, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    if (MODE == 3) return launch_gemm_qr_cfg<3, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, nullptr, s);
+    constexpr int M = (MODE == 1 || MODE == 2) ? MODE : 1;
+    const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
+    int *bq = filt.query_bounds;  // per-query integer bounds of the pre-filter, behind the pivots in stream order
+    if (low)
+        hipLaunchKernelGGL(qs_bounds_kernel<true>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
+                           b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
+    else
+        hipLaunchKernelGGL(qs_bounds_kernel<false>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
+                           b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
+    QAMD_HIP(hipGetLastError());
+    return low ? launch_gemm_qr_cfg<M, true>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s)
+               : launch_gemm_qr_cfg<M, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
+}
+
 template <int MODE>
 qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
+    if (qr_selected(h, b, MODE != 0)) return launch_gemm_qr<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     const bool wide = b->frag_nkb <= 9;  // 128 resident rows fit (rows of up to 1152 B), else 96
     const bool tall = b->frag_nkb <= 8;  // 16x16x64 form: 128 resident rows of up to 1024 bytes, else 96
     const bool small = b->n_queries <= kQs16SmallBatch;  // chunks of 32 queries: a chunk for every wave
@@ -1961,6 +2326,7 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
 // the batch, enough queries to keep the 8 waves of a workgroup busy (64 queries per wave and turn).
 bool qs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
     static const char *cfg = getenv("QAMD_GEMM_CFG");
+    if (qr_selected(h, b, filter_mode)) return true;  // a form of it (launch_gemm_qs dispatches)
     if (cfg && cfg[0] != 'q') return false;
     const float m = h->meta.multiplier;
     if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
@@ -2239,7 +2605,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
         const bool cached = S <= rows_all && sample_store(h, rows_all, s, &s_codes, &s_offs) == QAMD_OK;
         const size_t o_codes = reserve(cached ? 16 : (uint64_t)(S + 512) * ad);  // + one (largest) tile of zero rows
         const size_t o_offs = reserve(cached ? 16 : (uint64_t)(S + 512) * 4);
-        const size_t o_scores = reserve(qs ? Q * ((uint64_t)S / 96 + 2) * 4 : Q * (uint64_t)S * 4);  // sample scores, or block bests
+        const size_t o_scores = reserve(qs ? Q * ((uint64_t)S / 64 + 2) * 4 : Q * (uint64_t)S * 4);  // sample scores, or block bests
         const size_t o_cand = reserve(Q * (uint64_t)kBatchCap * 8);
         const size_t o_status = reserve((Q + 1) * 4);  // per-query status, then the wave-list overflow flag
         const size_t o_bounds = reserve(b->q_pad * 4);
@@ -2276,7 +2642,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
             // 10M rows); the pivot is the r-th best of those: the r best sample rows of a query share a
             // block with probability ~ r^2 / (2 blocks), and a pivot that is a little off only moves the
             // candidate count (the filter pass, not the pivot, decides what is in the result)
-            const uint32_t rows_per_block = (b->frag16 ? b->frag_nkb <= 8 : b->frag_nkb <= 9) ? 128 : 96, s_blocks = (S + rows_per_block - 1) / rows_per_block;
+            const uint32_t rows_per_block = qr_selected(h, b, true) ? 64 : (b->frag16 ? b->frag_nkb <= 8 : b->frag_nkb <= 9) ? 128 : 96, s_blocks = (S + rows_per_block - 1) / rows_per_block;
             BatchFilter fs{};
             fs.largest = largest;
             QAMD_TRY(launch_gemm_qs<3>(h, b, s_codes, s_offs, S, s_scores, s_blocks, fs, s));

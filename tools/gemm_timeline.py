@@ -44,7 +44,7 @@ torch.cuda.synchronize()
 L.qamd_dev_gemm_stamps(None)
 print(f"topk_batch with stamps: {e0.elapsed_time(e1):.2f} ms")
 st = stamps.cpu().numpy().reshape(4096, WAVES, 16)
-if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "q":
+if os.environ.get("QAMD_GEMM_CFG", "p")[0] in "qg":  # g: the queries-in-registers form (BLK_ROWS=64, CHUNK_Q=32)
     # query-streaming kernel: per wave, cycles summed over its row blocks
     n_wg, blk_rows = 256, int(os.environ.get("BLK_ROWS", 128))  # BLK_ROWS=96: rows of 1153-1536 bytes
     blk = st[:n_wg]
@@ -58,7 +58,8 @@ if os.environ.get("QAMD_GEMM_CFG", "p")[0] == "q":
         x = blk[:, :, i]
         print(f"  {nm:46s} {x.mean():12.0f}  {100 * x.mean() / tot:5.1f} %   (p10 {np.percentile(x, 10):10.0f}, p90 {np.percentile(x, 90):10.0f})")
     n_blocks = (n + blk_rows - 1) // blk_rows / n_wg
-    mf = n_blocks * ((nq + 63) // 64) / WAVES * ((enc.metadata["actual_dim"] + 127) // 128) * (blk_rows // 4)
+    chunk_q = int(os.environ.get("CHUNK_Q", 64))
+    mf = n_blocks * ((nq + chunk_q - 1) // chunk_q) / WAVES * ((enc.metadata["actual_dim"] + 127) // 128) * (blk_rows // 4) * chunk_q / 64
     print(f"  MFMAs per wave {mf:.0f}: K loop cycles per MFMA {blk[:, :, 3].mean() / mf:.1f} (two waves share a SIMD: 64 nominal)")
     if blk[:, :, 7].mean() > 0:
         print(f"  kernel {blk[:, :, 7].mean() / 100:.1f} us per wave (10 ns ticks), shader clock while it ran "
