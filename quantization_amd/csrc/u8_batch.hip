@@ -14,7 +14,7 @@
 // K index is only a summation index, so lane (r, h) simply takes bytes [32s + 16h, +16) of
 // query/row r in k-step s: fragments are plain 16-byte pieces, no transposition anywhere.
 //
-// Five kernels share the arithmetic, the integer pre-filter and the epilogue; launch_gemm picks by what
+// Six kernels share the arithmetic, the integer pre-filter and the epilogue; launch_gemm picks by what
 // is re-read and from where (DESIGN.md 3.3b has the table and the measurements):
 //   * u8_gemm_rs_kernel<MODE, LOW, MI, NT> -- row-streaming: up to 128 queries (and several 128-query
 //     tiles up to ~700): the query tile resident in LDS, every wave streams its own rows HBM ->
@@ -24,6 +24,9 @@
 //     order straight into operand registers.  Rows leave HBM once; the reuse needs no co-scheduling of
 //     workgroups.  qs16 (round 3, the default) runs on v_mfma_i32_16x16x64_i8, which this part clocks a fifth
 //     higher under load than the 32x32x32 instruction of the round-2 form (QAMD_QS16=0 selects that one).
+//   * u8_gemm_qr16_kernel<MODE, LOW, NSTEPS> -- 129 .. 256 queries on rows of 256 / 512 / 768 / 1024 B (round 3): a wave's 32
+//     queries in registers for all k-steps, the rows through a double-buffered 64-row LDS slab filled by LDS-DMA under
+//     the MFMAs; no vector-memory wait in the K loop, one barrier per block.
 //   * u8_gemm_pp_kernel<MODE, LOW, MI, MJ> -- ping-pong (round 1): both operands through an LDS-DMA
 //     ring, two wave groups half a phase apart; now for what the two above do not take.
 //   * u8_gemm_kernel<MODE, TQ, TR, WQ, WR, BK> -- the first version (128-byte K slabs through
