@@ -6,7 +6,7 @@ TAG=${1:-r03}
 COMMIT=${2:-unknown}
 echo "== collect.sh (bench under rocprofv3, PMC traffic)"; bash profiles/collect.sh "$TAG" "$COMMIT" > "gpurun_out/${TAG}_collect.log" 2>&1; tail -3 "gpurun_out/${TAG}_collect.log"
 echo "== per-kernel bench"; python3 tools/bench_all.py u8 bin pq topk ids encode 2>/dev/null > "gpurun_out/${TAG}_per_kernel_bench.jsonl"; wc -l "gpurun_out/${TAG}_per_kernel_bench.jsonl"
-echo "== batch sizes"; BATCH_NQ=16,64,128,256,385,512,640,768,1024,2048 python3 tools/bench_all.py batch 2>/dev/null > "gpurun_out/${TAG}_bench_topk_batch_by_queries.jsonl"; wc -l "gpurun_out/${TAG}_bench_topk_batch_by_queries.jsonl"
+echo "== batch sizes"; BATCH_NQ=16,64,128,129,192,256,257,385,512,768,1024,2048 python3 tools/bench_all.py batch 2>/dev/null > "gpurun_out/${TAG}_bench_topk_batch_by_queries.jsonl"; wc -l "gpurun_out/${TAG}_bench_topk_batch_by_queries.jsonl"
 echo "== bench lines"; bash profiles/collect_lines.sh "$TAG" > "gpurun_out/${TAG}_lines.log" 2>&1; tail -2 "gpurun_out/${TAG}_lines.log"
 echo "== single-process sharded bench (two logical shards on this one GPU)"
 python3 bench.py --single-process --gpus 2 --devices 0,0 2>/dev/null | tail -1 > "gpurun_out/${TAG}_bench_line_single_process_2shards.json"; cut -c1-200 "gpurun_out/${TAG}_bench_line_single_process_2shards.json"
