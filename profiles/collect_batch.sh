@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): evidence for the many-queries-at-once kernels of csrc/u8_batch.hip.
 #   profiles/collect_batch.sh <round tag, e.g. r02>
 # Writes under gpurun_out/ (copy what is to be judged into profiles/):
-#   <tag>_batch_kernel_stats.txt     per-kernel times of topk_batch(30) at 16 / 128 / 1024 queries, 10M x 768
+#   <tag>_batch_kernel_stats.txt     per-kernel times of topk_batch(30) at 16 / 128 / 256 / 1024 queries, 10M x 768
 #   <tag>_batch_counters_1024.txt    PMC counters of the 1024-query main kernel (separate --pmc passes, kernel trace only)
 #   <tag>_mfma_int8_ceiling.txt      back-to-back MFMA issue rate of this box (dev library)
 #   <tag>_row_stream_patterns.txt    pure-load access-pattern sweep behind the row-streaming kernel (dev library)
@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/${TAG}_batch_prof
 mkdir -p "$OUT"
 : > "gpurun_out/${TAG}_batch_kernel_stats.txt"
-for NQ in 16 128 1024; do
+for NQ in 16 128 256 1024; do
     rm -rf "$OUT/stats_$NQ"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$NQ" -o k -- python3 tools/time_batch.py $NQ \
         > "$OUT/stats_$NQ.log" 2>&1 || { tail -5 "$OUT/stats_$NQ.log"; exit 1; }
@@ -42,7 +42,7 @@ for CTRS in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_C
 done
 set -- $CSVS
 FIRST=$1; shift
-python3 profiles/summarize.py counters "$FIRST" u8_gemm_qs_kernel\<1 "gpurun_out/${TAG}_batch_counters_1024.txt" "$@"
+python3 profiles/summarize.py counters "$FIRST" "${QS_KERNEL:-u8_gemm_qs16_kernel<1}" "gpurun_out/${TAG}_batch_counters_1024.txt" "$@"
 export QAMD_LIB_PATH=$PWD/tools/lib/libquantization_amd_dev.so
 python3 tools/mfma_peak.py 2>&1 | grep -v amdgpu.ids > "gpurun_out/${TAG}_mfma_int8_ceiling.txt"
 python3 tools/tune_stream.py 2>&1 | grep -v amdgpu.ids > "gpurun_out/${TAG}_row_stream_patterns.txt"
