@@ -24,7 +24,7 @@
 //     order straight into operand registers.  Rows leave HBM once; the reuse needs no co-scheduling of
 //     workgroups.  qs16 (round 3, the default) runs on v_mfma_i32_16x16x64_i8, which this part clocks a fifth
 //     higher under load than the 32x32x32 instruction of the round-2 form (QAMD_QS16=0 selects that one).
-//   * u8_gemm_qr16_kernel<MODE, LOW, NSTEPS> -- 129 .. 256 queries on rows of 256 / 512 / 768 / 1024 B (round 3): a wave's 32
+//   * u8_gemm_qr16_kernel<MODE, LOW, NSTEPS> -- 129 .. 256 queries on rows of 256 / 384 / 512 / 768 / 1024 B (round 3): a wave's 32
 //     queries in registers for all k-steps, the rows through a double-buffered 64-row LDS slab filled by LDS-DMA under
 //     the MFMAs; no vector-memory wait in the K loop, one barrier per block.
 //   * u8_gemm_pp_kernel<MODE, LOW, MI, MJ> -- ping-pong (round 1): both operands through an LDS-DMA
@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(512) void u8_gemm_qs16_kernel(const uint8_t *__rest
 // the next 64-row slab can be asked for by LDS-DMA at the START of a block and arrive under this block's MFMAs; the
 // only wait is the one in front of the block-end barrier.  A launch serves 256 queries (8 waves x 32); a batch is cut
 // into passes, each of which streams the store once at close to the HBM rate (64 rows x 768 B per CU and ~1.9 us of
-// MFMAs).  Row layout, fragment order and epilogue as in u8_gemm_qs16_kernel; rows of 256 / 512 / 768 / 1024 bytes.
+// MFMAs).  Row layout, fragment order and epilogue as in u8_gemm_qs16_kernel; rows of 256 / 384 / 512 / 768 / 1024 bytes.
 template <int MODE, bool LOW, int NSTEPS>
 __global__ __launch_bounds__(512) void u8_gemm_qr16_kernel(const uint8_t *__restrict__ codes,
                                                           const float *__restrict__ v_offsets,
@@ -1702,8 +1702,9 @@ __global__ __launch_bounds__(512) void u8_gemm_qr16_kernel(const uint8_t *__rest
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
-    const uint32_t nkb = __builtin_amdgcn_readfirstlane(ad / 128);  // rows of whole 256 bytes: nkb even, NSTEPS == 2 nkb
-    const uint32_t per = ad / 16, PA = ad;                           // chunks per row; LDS pitch = the row (whole bank rows)
+    const uint32_t nkb = __builtin_amdgcn_readfirstlane(ad / 128);  // rows of whole 128 bytes, NSTEPS == 2 nkb
+    const uint32_t per = ad / 16;                                    // chunks per row
+    const uint32_t pp = ((per + 15) / 16) * 16, PA = pp * 16;        // places per row in LDS: whole 256-byte bank rows (384-byte rows: 512)
     const uint32_t SLAB = QR_ROWS * PA;
     const uint32_t n_blocks = (n_rows + QR_ROWS - 1) / QR_ROWS;
     float *voff_s = reinterpret_cast<float *>(lds_raw + 2 * (size_t)SLAB);  // [2][64]
@@ -1716,8 +1717,8 @@ __global__ __launch_bounds__(512) void u8_gemm_qr16_kernel(const uint8_t *__rest
     // row DMA: LDS position p (16-byte units) of a slab = row p / per, place p % per, filled with the row's chunk
     // place ^ (row & 15); instruction k covers positions [64 k, 64 k + 64), wave w issues k = w, w + 8, ... (per in all)
     const uint32_t d_pos0 = (uint32_t)wave * 64u + (uint32_t)lane;
-    const uint32_t d_row0 = d_pos0 / per, d_place0 = d_pos0 % per;
-    const uint32_t d_dr = __builtin_amdgcn_readfirstlane(512u / per), d_dc = __builtin_amdgcn_readfirstlane(512u % per);
+    const uint32_t d_row0 = d_pos0 / pp, d_place0 = d_pos0 % pp;
+    const uint32_t d_dr = __builtin_amdgcn_readfirstlane(512u / pp), d_dc = __builtin_amdgcn_readfirstlane(512u % pp);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_raw;
     float vo_pf = 0.0f;
     // One DMA instruction occupies the CU's address path for its 1 KiB and holds the issuing wave meanwhile (48 of them at
@@ -1730,13 +1731,17 @@ __global__ __launch_bounds__(512) void u8_gemm_qr16_kernel(const uint8_t *__rest
         d_row = d_row0, d_place = d_place0, d_i = 0;
         vo_pf = v_offsets[(uint64_t)blk * QR_ROWS + (t < QR_ROWS ? t : 0)];  // padded like codes[]
     };
-    auto dma_piece = [&]() {  // piece d_i of this wave (per <= 64 instructions of 1 KiB per slab: at most 8 per wave)
-        if ((uint32_t)wave + 8u * d_i < per)
-            glds16_nt_unordered(d_src, d_row * ad + ((d_place ^ (d_row & 15u)) * 16u), __builtin_amdgcn_readfirstlane(d_dst + d_i * 8192u));
+    auto dma_piece = [&]() {  // piece d_i of this wave (pp <= 64 instructions of 1 KiB per slab: at most 8 per wave)
+        if ((uint32_t)wave + 8u * d_i < pp) {
+            // a place past the row's last chunk (pitch > row: 384-byte rows) is never multiplied with a non-zero query
+            // byte; it is filled with the row's last chunk (any readable bytes would do)
+            const uint32_t c = d_place ^ (d_row & 15u);
+            glds16_nt_unordered(d_src, d_row * ad + (c < per ? c : per - 1) * 16u, __builtin_amdgcn_readfirstlane(d_dst + d_i * 8192u));
+        }
         d_row += d_dr;
         d_place += d_dc;
-        if (d_place >= per) {
-            d_place -= per;
+        if (d_place >= pp) {
+            d_place -= pp;
             d_row++;
         }
         d_i++;
@@ -2214,7 +2219,7 @@ inline bool qr_possible(const qamd_u8 *h, const qamd_u8_query_batch *b, bool fil
     const float m = h->meta.multiplier;
     if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
     const uint64_t ad = h->meta.actual_dim;
-    return b->frag.ptr && b->frag16 && ad % 256 == 0 && ad <= 1024;
+    return b->frag.ptr && b->frag16 && (ad == 256 || ad == 384 || ad == 512 || ad == 768 || ad == 1024);
 }
 bool qr_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
     static const char *cfg = getenv("QAMD_GEMM_CFG");
@@ -2233,7 +2238,7 @@ qamd_status launch_gemm_qr_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
                                const BatchFilter &filt, const int *bq, hipStream_t s) {
     const uint32_t nkb = b->frag_nkb;
     const uint64_t ad = h->meta.actual_dim;
-    const size_t lds_bytes = 2 * (size_t)64 * ad + 4 * 64 * 4 + 64;
+    const size_t lds_bytes = 2 * (size_t)64 * round_up(ad, 256) + 4 * 64 * 4 + 64;
     const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
     for (uint64_t q_base = 0; q_base < b->n_queries; q_base += kQrQueries) {
         const uint32_t nq = (uint32_t)std::min<uint64_t>(kQrQueries, b->n_queries - q_base);
@@ -2255,6 +2260,7 @@ qamd_status launch_gemm_qr_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
                            (uint32_t)ad, (MODE == 0 || MODE == 3) ? out + q_base * out_pitch : out, out_pitch, f);           \
     } while (0)
         if (nkb == 2) QAMD_QR(4);
+        else if (nkb == 3) QAMD_QR(6);
         else if (nkb == 4) QAMD_QR(8);
         else if (nkb == 6) QAMD_QR(12);
         else QAMD_QR(16);

@@ -363,6 +363,7 @@ print("ok")
     (70_001, 768, 256),     # ... all eight waves busy, several row blocks per workgroup, ragged tail
     (33_000, 512, 200),
     (33_000, 256, 129),
+    (33_000, 384, 250),     # 384-byte rows on a 512-byte LDS pitch (places past the row's last chunk are filler)
     (33_000, 1024, 70),     # (from 65 queries on 1024-byte rows)
     (33_000, 1024, 129),
     (33_000, 1024, 256),    # 8 chunks of 32: the last batch size of the small-chunk form
