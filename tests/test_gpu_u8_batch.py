@@ -359,6 +359,8 @@ print("ok")
 # on 32x32x32 up to 1536): from 385 / 257 / 129 queries (rows of up to 384 / 768 / 1536 bytes: qs_min_queries); batches of up
 # to 256 queries in chunks of 32 per wave
 @pytest.mark.parametrize("n,dim,nq", [
+    (140_000, 768, 300),    # stores of 131072+ rows take the query-streaming kernels by default: 5 chunks of 64 queries
+    (140_000, 1536, 200),   # ... 96 resident rows, chunks of 32 queries
     (33_000, 768, 130),     # queries in registers (u8_gemm_qr16_kernel): 129 .. 256 queries on rows of 256 / 512 / 768 / 1024 bytes
     (70_001, 768, 256),     # ... all eight waves busy, several row blocks per workgroup, ragged tail
     (33_000, 512, 200),
