@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E vendor peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 LDS_B32_PEAK_GBPS = 75000.0  # ds_read_b32, every CU streaming at ~2.4 GHz (MI355X_MICROARCH.md, LDS section)
 MFMA_INT8_PEAK_TOPS = 5000.0  # dense int8 (the guide's ~5 POP/s; vendor figures with sparsity are not used)
+MFMA_FP4_PEAK_TOPS = 10000.0  # dense fp4 through the f8f6f4 MFMAs (2 x the fp8 rate): binary batches of 129+ queries run there
 
 
 def parse_args():
@@ -538,21 +539,25 @@ def main():
             is_bin = args.quantizer == "binary"
             ad = dim if is_bin else enc.metadata["actual_dim"]  # binary: one 0/1 operand byte per bit on the matrix cores
             ops = 2.0 * Q * n * ad  # per GPU and step
+            # binary batches of 129+ queries on rows of 512 / 1024 bits take the fp4 matrix-core kernel (csrc/bin.hip)
+            bin_fp4 = is_bin and Q >= 129 and ad in (512, 1024) and os.environ.get("QAMD_BIN4", "1") != "0"
+            mfma_peak = MFMA_FP4_PEAK_TOPS if bin_fp4 else MFMA_INT8_PEAK_TOPS
             per_gpu_tops = ops * args.steps / elapsed / 1e12
             print(json.dumps({
                 "metric": f"(query, vector) pairs scored/sec, {Q} queries x {total_rows}x{dim} {args.quantizer} dot, top-{k} each",
                 "value": float(Q) * total_rows * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": scaling_field, "vs_baseline": None,
-                "dtype": "1-bit x 1-bit -> i32 (bits expanded to 0/1 bytes, MFMA int8)" if is_bin else "u8 x u8 -> i32 (MFMA int8)",
+                "dtype": ("1-bit x 1-bit -> exact count (bits as E2M1 0/1 nibbles, MFMA fp4 -> f32)" if bin_fp4 else
+                          "1-bit x 1-bit -> i32 (bits expanded to 0/1 bytes, MFMA int8)") if is_bin else "u8 x u8 -> i32 (MFMA int8)",
                 "data": "synthetic",
                 "config": {"workload": f"{Q} queries x {total_rows} x {dim} {'binary' if is_bin else 'scalar-u8'} rows ({n} on rank 0), per step: "
                                        f"topk_batch over the shard + all-gather of world*Q*k pairs + per-query merge "
                                        f"on the GPU",
                            "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows, **dist_info},
-                "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": MFMA_INT8_PEAK_TOPS, "unit": "TFLOP/s",
-                             "frac": per_gpu_tops / MFMA_INT8_PEAK_TOPS, "traffic": None,
-                             "note": "int8 op/s per GPU over the whole step (sample pass, filter GEMM, scatter, "
+                "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": mfma_peak, "unit": "TFLOP/s",
+                             "frac": per_gpu_tops / mfma_peak, "traffic": None,
+                             "note": ("fp4" if bin_fp4 else "int8") + " op/s per GPU over the whole step (sample pass, filter GEMM, scatter, "
                                      "sort, exchange); algorithmic ops = 2 * actual_dim per (query, row) pair"},
             }), flush=True)
         if use_dist:

@@ -1179,6 +1179,296 @@ __global__ __launch_bounds__(512) void bin_gemm_rs_kernel(const uint8_t *__restr
     if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Many queries on the FP4 matrix cores (round 3).  popcount(q AND v) is a dot product of 0/1 values, and 0 and 1 are
+// exact in every MFMA input format: as E2M1 nibbles (0b0010 = 1.0) through v_mfma_scale_f32_16x16x128_f8f6f4 (both
+// scales 2^0) a k-step covers 128 BITS per instruction and the part runs it at 8.85 POP/s and 2.35 GHz in a bare loop
+// (the int8 instructions: 3.6-4.4 POP/s at 1.85-2.2 GHz); the f32 accumulators hold the exact counts (< 2^24).  What made
+// bin_gemm_rs_kernel vector-ALU-bound was expanding every row's bits once per 64-query tile in every wave; here the
+// structure is u8_gemm_qs16_kernel's (csrc/u8_batch.hip): a workgroup expands a block of 128 rows ONCE into LDS
+// (nibbles: 4 x the row bytes, pitch = whole 256-byte bank rows, 16-byte chunks XOR (row & 15)) and streams the whole
+// batch past it - up to 2048 queries per launch, their nibble image prepared once per call in fragment order
+// (bin_frag4_kernel: per 16 queries and 128-bit k-step one 1 KiB piece, lane (i, g) = bits [128 s + 32 g, +32) of query
+// i).  Same epilogue arithmetic as bin_gemm_rs_kernel: the scores are the reference's bit for bit.  Rows of 512 / 1024 bits.
+constexpr uint64_t kQs4Slice = 2048, kQs4MinQueries = 129;  // queries per launch of bin_gemm_qs4_kernel; from where it is used
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+// 8 bits -> 8 E2M1 nibbles (1.0 where set), bit j of the low nibble at nibble 2j, of the high nibble at 2j + 1 (any fixed
+// order does: rows and queries use the same one)
+__device__ __forceinline__ uint32_t nib8(uint32_t b8) {
+    const uint32_t lo = __umul24(b8 & 0xFu, 0x00204081u) & 0x01010101u, hi = __umul24((b8 >> 4) & 0xFu, 0x00204081u) & 0x01010101u;
+    return (lo | (hi << 4)) << 1;
+}
+__device__ __forceinline__ uint4 nib32(uint32_t w) {
+    return make_uint4(nib8(w & 255u), nib8((w >> 8) & 255u), nib8((w >> 16) & 255u), nib8(w >> 24));
+}
+
+// out[(t16 * nsteps + s) * 64 + lane] = nibbles of bits [128 s + 32 g, +32) of query 16 t16 + i (lane = 16 g + i); also the
+// query's offset and, given its pivot, the integer bound of the pre-filter (as bin_gemm_rs_kernel computes them per tile)
+template <bool LOW>
+__global__ __launch_bounds__(256) void bin_frag4_kernel(const uint8_t *__restrict__ qbits, uint32_t q_stride, uint32_t n_queries,
+                                                       uint32_t q_pad, uint32_t nsteps, float dim_f, int zx, int largest,
+                                                       const float *__restrict__ pivots, uint4 *__restrict__ out,
+                                                       float *__restrict__ q_off, int *__restrict__ bq) {
+    const uint64_t total = (uint64_t)(q_pad / 16) * nsteps * 64;
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+        const uint32_t lane = (uint32_t)(idx & 63u);
+        const uint64_t ts = idx >> 6;
+        const uint32_t sx = (uint32_t)(ts % nsteps), t16 = (uint32_t)(ts / nsteps);
+        const uint32_t q = 16u * t16 + (lane & 15u), g = lane >> 4;
+        uint32_t w = 0;
+        if (q < n_queries) w = *reinterpret_cast<const uint32_t *>(qbits + (uint64_t)q * q_stride + 16u * sx + 4u * g);
+        out[idx] = nib32(w);
+    }
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q < q_pad) {
+        uint32_t pq = 0;
+        if (q < n_queries)
+            for (uint32_t w = 0; w < nsteps * 4; w++) pq += __popc(*reinterpret_cast<const uint32_t *>(qbits + (uint64_t)q * q_stride + w * 4));
+        const float qo = zx ? dim_f - 2.0f * (float)pq : 2.0f * (float)pq - dim_f;
+        const float multiplier = zx ? 4.0f : -4.0f;
+        const bool lg = largest != 0;
+        const float pv = q < n_queries ? pivots[q] : (lg ? __builtin_huge_valf() : -__builtin_huge_valf());
+        int b = pp_bound<LOW>(pv - qo, fabsf(pv) + fabsf(qo), multiplier, 1);
+        if (__builtin_isinf(pv)) b = ((pv > 0.0f) == lg) == LOW ? -(int)kPpLim : (int)kPpLim;
+        q_off[q] = qo;
+        bq[q] = b;
+    }
+}
+
+// IT: 16-query tiles per wave and chunk - 4 (64 queries), 2 for batches of up to 256 queries, 1 up to 128 (a chunk for every wave)
+template <int MODE, bool LOW, int IT>  // MODE 1 / 2: filter for the largest / smallest scores
+__global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__restrict__ rows, uint32_t ds,
+                                                          const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
+                                                          const int *__restrict__ bq_all, int zx, uint32_t n_rows,
+                                                          uint32_t n_queries, BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr int JT = 8, JH = 4, QS_ROWS = 16 * JT, CQ = 16 * IT;
+    constexpr bool LARGEST = MODE == 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
+    const uint32_t nsteps = __builtin_amdgcn_readfirstlane(ds / 16);  // k-steps of 128 bits
+    const uint32_t PA = ds * 4;                                       // LDS pitch of a row's nibble image (ds % 64 == 0)
+    const float multiplier = zx ? 4.0f : -4.0f;
+    const uint32_t n_blocks = (n_rows + QS_ROWS - 1) / QS_ROWS;
+    const uint32_t live_chunks = (n_queries + CQ - 1) / CQ;
+    // TWO row blocks in LDS (a block of 128 rows is only 16 KiB of bits: the cost of changing blocks is latency, and with a
+    // single slab it was 3.9 us per block whatever the batch): the next block's bits are requested into 8 registers when
+    // this block starts, expanded into the other slab when this block's chunks are done - one barrier per block
+    const uint32_t SLAB = QS_ROWS * PA;
+    float *voff_s = reinterpret_cast<float *>(lds_raw + 2 * (size_t)SLAB);  // [2][128]
+    int *br_s = reinterpret_cast<int *>(voff_s + 2 * QS_ROWS);              // [2][128]
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(br_s + 2 * QS_ROWS) + wave;
+    int *bq_s = reinterpret_cast<int *>(br_s + 2 * QS_ROWS) + 16;           // [CQ * live_chunks]
+    // (expanding through a 256-entry byte -> nibbles table in LDS instead of the multiplies was measured: no faster)
+    if (lane == 0) *wcount_s = 0;
+    // the "always" / "never" sentinels of the bounds (+-2^29) are brought to +-2^23: still far beyond any count, and the
+    // accumulators (count - bound, f32) stay exact integers
+    for (uint32_t i = t; i < CQ * live_chunks; i += 512) bq_s[i] = max(min(bq_all[i], 1 << 23), -(1 << 23));
+
+    v4i Q0[IT], Q1[IT], Q2[IT];
+    auto load_step = [&](v4i(&a)[IT], uint32_t c, uint32_t j) {
+        const uint4 *p = qfrag + ((uint64_t)(IT * c) * nsteps + j) * 64 + lane;
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const uint4 v = p[(uint64_t)it * nsteps * 64];
+            a[it] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        }
+    };
+    const uint32_t b_row = i16 * PA, b_gi = (g4 ^ i16) * 16u;
+    // Row-block fill: the block is 128 * ds contiguous bytes of the store; thread t takes the 16-byte (128-bit) pieces
+    // t, t + 512, ... (ds / 16 * 128 / 512 = ds / 64 of them: 2 at 1024 bits), requested before the barrier that frees the
+    // LDS rows, expanded and written after it: piece pc of row r = nibble chunks 4 pc .. 4 pc + 3, each at place
+    // chunk ^ (r & 15).  The row's popcount (its offset in the score) is the sum over its ds / 16 pieces, which sit in
+    // adjacent lanes.
+    const uint32_t per = ds / 16;                                       // pieces per row: 4, 8, 12 or 16
+    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane(per / 4);  // per thread: 128 * per / 512
+    constexpr int MAXP = 4;
+    uint4 st[MAXP];
+    auto fill_request = [&](uint32_t blk) {
+        const uint8_t *p = rows + (uint64_t)blk * QS_ROWS * ds + (size_t)t * 16;
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;  // wave-uniform
+            st[i] = ld_nt(reinterpret_cast<const uint4 *>(p + (size_t)ii * 8192));
+        }
+    };
+    auto fill_write = [&](uint64_t row0, uint32_t par) {
+        uint8_t *slab = lds_raw + par * SLAB;
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            if ((uint32_t)i >= n_pieces) break;
+            const uint32_t piece = (uint32_t)t + 512u * i, row = piece / per, pc = piece % per;
+            const uint32_t w[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t chunk = 4u * pc + k;
+                *reinterpret_cast<uint4 *>(slab + row * PA + ((chunk ^ (row & 15u)) * 16u)) = nib32(w[k]);
+            }
+            // popcount of the row: pieces of a row are in `per` adjacent lanes of this round (per divides 64)
+            uint32_t pop = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
+            for (uint32_t d = 1; d < per; d <<= 1) pop += (uint32_t)__shfl_xor((int)pop, (int)d);  // per = 4, 8 or 16 (the launcher's condition)
+            if (pc == 0) {
+                const bool ok = row0 + row < n_rows;
+                const float v_off = zx ? -2.0f * (float)pop : 2.0f * (float)pop;
+                voff_s[par * QS_ROWS + row] = v_off;
+                br_s[par * QS_ROWS + row] = ok ? pp_bound<LOW>(-v_off, fabsf(v_off), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+            }
+        }
+    };
+    const uint32_t my_first = wave;
+    const uint32_t first_blk = blockIdx.x < n_blocks ? blockIdx.x : 0u;
+    fill_request(first_blk);
+    fill_write((uint64_t)first_blk * QS_ROWS, 0u);
+    if (my_first < live_chunks) {
+        load_step(Q0, my_first, 0);
+        load_step(Q1, my_first, 1);
+    }
+    __syncthreads();
+    uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave) * filt.wave_cap;
+    uint32_t par = 0;
+
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t row0 = (uint64_t)blk * QS_ROWS;
+        const uint32_t next_blk = blk + gridDim.x < n_blocks ? blk + gridDim.x : blk;
+        fill_request(next_blk);  // lands under this block's MFMAs (past the end: re-request, harmless)
+        const uint8_t *slab = lds_raw + par * SLAB;
+        const float *voff_cur = voff_s + par * QS_ROWS;
+        const int *br_cur = br_s + par * QS_ROWS;
+        for (uint32_t c = wave; c < live_chunks; c += 8) {
+            const uint32_t c_next = c + 8 < live_chunks ? c + 8 : my_first;
+            v4f_t acc[IT][JT];
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const v4i bq4 = *reinterpret_cast<const v4i *>(bq_s + CQ * c + 16 * it + 4 * g4);
+#pragma unroll
+                for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[it][jt][e] = -(float)bq4[e];  // |bound| <= dim or the 2^29 sentinel: exact
+            }
+            auto compute = [&](const v4i(&a)[IT], uint32_t j) {
+                uint32_t lane_addr = b_row + (b_gi ^ ((j & 3u) * 64u)) + (j >> 2) * 256u;
+                asm volatile("" : "+v"(lane_addr));
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    v4i bf[JH];
+#pragma unroll
+                    for (int j4 = 0; j4 < JH; j4++)
+                        bf[j4] = *reinterpret_cast<const v4i *>(slab + lane_addr + (uint32_t)(JH * hf + j4) * 16u * PA);
+#pragma unroll
+                    for (int it = 0; it < IT; it++) {
+                        const v8i_t a8 = {a[it].x, a[it].y, a[it].z, a[it].w, 0, 0, 0, 0};
+#pragma unroll
+                        for (int j4 = 0; j4 < JH; j4++) {
+                            const v8i_t b8 = {bf[j4].x, bf[j4].y, bf[j4].z, bf[j4].w, 0, 0, 0, 0};
+                            acc[it][JH * hf + j4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[it][JH * hf + j4], 4, 4, 0, 127, 0, 127);
+                        }
+                    }
+                }
+            };
+            auto request = [&](v4i(&a)[IT], uint32_t j) {
+                if (j < nsteps) load_step(a, c, j);
+                else load_step(a, c_next, j - nsteps);
+            };
+            if (((c >> 3) + ((uint32_t)wave >> 2)) & 1u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+            uint32_t j = 0;
+            for (; j + 2 < nsteps; j += 3) {
+                request(Q2, j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q0, j);
+                __builtin_amdgcn_sched_barrier(0);
+                request(Q0, j + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q1, j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                request(Q1, j + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q2, j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const uint32_t left = nsteps - j;
+            if (left >= 1) {
+                request(Q2, j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q0, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (left == 2) {
+                request(Q0, j + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Q1, j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            // ---- epilogue: lane (i16, g4) holds, per (it, jt), queries CQ c + 16 it + 4 g4 + e against row 16 jt + i16
+            uint32_t c_e = c, lane_e = (uint32_t)lane;
+            asm volatile("" : "+s"(c_e), "+v"(lane_e));
+            const uint32_t i_e = lane_e & 15u, g_e = lane_e >> 4;
+            // "some accumulator may pass": acc = count - query bound; the row bound decides (as in bin_gemm_rs_kernel)
+            bool any_lane = false;
+#pragma unroll
+            for (int jt = 0; jt < JT; jt++) {
+                const float brf = (float)br_cur[jt * 16 + i_e];
+                float ext = acc[0][jt][0];
+#pragma unroll
+                for (int it = 0; it < IT; it++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ext = LOW ? fminf(ext, acc[it][jt][e]) : fmaxf(ext, acc[it][jt][e]);
+                any_lane |= LOW ? ext < brf : ext >= brf;
+            }
+            if (__builtin_amdgcn_readfirstlane(__ballot(any_lane) != 0)) {
+#pragma unroll
+                for (int jt = 0; jt < JT; jt++) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint64_t row = row0 + jt * 16 + i_e;
+                    const int br = br_cur[jt * 16 + i_e];
+                    const float v_off = voff_cur[jt * 16 + i_e];
+#pragma unroll
+                    for (int it = 0; it < IT; it++) {
+                        const uint32_t q = CQ * c_e + 16 * it + 4 * g_e;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int av = (int)acc[it][jt][e];
+                            if (LOW ? av < br : av >= br) {  // may pass: the exact f32 comparison decides
+                                const float qo = q_offsets[q + e];
+                                const float pvt = filt.pivot_scores[q + e];
+                                const float sc = (multiplier * (float)(av + bq_s[q + e]) + qo) + v_off;
+                                const float d = LARGEST ? sc - pvt : pvt - sc;
+                                if (d >= 0.0f) {
+                                    const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                    if (pos < filt.wave_cap)
+                                        wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row, filt.query_base + q + e, 0u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (left == 1) {
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    Q0[it] = Q1[it];
+                    Q1[it] = Q2[it];
+                }
+            } else if (left == 2) {
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const v4i k1 = Q0[it];
+                    Q0[it] = Q2[it];
+                    Q1[it] = k1;
+                }
+            }
+        }
+        fill_write((uint64_t)next_blk * QS_ROWS, par ^ 1u);  // the other slab: last read a block ago, a barrier has passed since
+        __syncthreads();
+        par ^= 1u;
+    }
+    if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+}
+
 // Sample rows for the pivots (rows only; the golden-ratio scatter of topk.hip), then `pad` zero rows.
 __global__ __launch_bounds__(256) void bin_gather_rows_kernel(const uint4 *__restrict__ rows, uint32_t row_chunks, uint64_t n_rows,
                                                              uint32_t n, uint32_t pad, uint4 *__restrict__ out) {
@@ -1277,8 +1567,12 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
             h->sample_count = rows_all;
         }
     }
-    const uint32_t n_lists = pp_waves_per_launch();
-    const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, TQ) / (double)n_lists;
+    // rows of 512 / 1024 / 2048 bits, enough queries: the FP4 query-streaming form (QAMD_BIN4=0 / QAMD_BIN4_MIN: developer A/B)
+    static const char *e4 = getenv("QAMD_BIN4"), *e4min = getenv("QAMD_BIN4_MIN");
+    const bool qs4 = (h->ds == 64 || h->ds == 128) && !(e4 && e4[0] == '0') &&
+                     Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries);
+    const uint32_t n_lists = pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
+    const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, qs4 ? kQs4Slice : TQ) / (double)pp_waves_per_launch();
     // (at least 1024 slots: queries of one batch can be near-duplicates, and then a passing row appends to every
     // query's list at once - 64 entries in one wave's list per such row)
     const uint32_t wave_cap = (uint32_t)std::min<double>(1u << 20, std::max<double>(1024.0, 16.0 * per_wave));
@@ -1320,6 +1614,65 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     f.wave_cap = wave_cap;
     f.wave_cand = wave_cand;
     f.wave_counts = wave_counts;
+    if (qs4) {  // ONE pass over the rows for up to 2048 queries (bin_gemm_qs4_kernel), then one scatter
+        const bool zx = (h->vp.distance_type == QAMD_DOT) != (h->vp.invert != 0);
+        const bool low = (!zx) != (largest == 0);  // multiplier = zx ? +4 : -4; MODE 2 (smallest) flips
+        const uint32_t nsteps = (uint32_t)(h->ds / 16);
+        StreamBuf prep;
+        const size_t frag_bytes = (size_t)q_pad * h->ds * 4;
+        QAMD_TRY(prep.alloc(frag_bytes + q_pad * 8, s));
+        uint4 *frag = prep.as<uint4>();
+        float *q_off = reinterpret_cast<float *>(prep.as<char>() + frag_bytes);
+        int *bq = reinterpret_cast<int *>(q_off + q_pad);
+        const unsigned pgrid = (unsigned)std::max<uint64_t>((q_pad + 255) / 256, std::min<uint64_t>(2048, (frag_bytes / 16 + 255) / 256));
+        if (low)
+            hipLaunchKernelGGL(bin_frag4_kernel<true>, dim3(pgrid), dim3(256), 0, s, b->bits.as<uint8_t>(), (uint32_t)b->q_stride, (uint32_t)Q,
+                               (uint32_t)q_pad, nsteps, (float)h->vp.dim, zx ? 1 : 0, largest, pivots, frag, q_off, bq);
+        else
+            hipLaunchKernelGGL(bin_frag4_kernel<false>, dim3(pgrid), dim3(256), 0, s, b->bits.as<uint8_t>(), (uint32_t)b->q_stride, (uint32_t)Q,
+                               (uint32_t)q_pad, nsteps, (float)h->vp.dim, zx ? 1 : 0, largest, pivots, frag, q_off, bq);
+        const size_t lds = 2 * (size_t)128 * h->ds * 4 + 4 * 128 * 4 + 64 + kQs4Slice * 4;
+        const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
+        for (uint64_t q_base = 0; q_base < Q; q_base += kQs4Slice) {
+            const uint32_t nq = (uint32_t)std::min<uint64_t>(kQs4Slice, Q - q_base);
+            BatchFilter fs = f;
+            fs.pivot_scores = pivots + q_base;
+            fs.query_base = (uint32_t)q_base;
+            fs.wave_base = (uint32_t)(q_base / kQs4Slice) * pp_waves_per_launch();
+#define QAMD_QS4_IT(M_, LOW_, IT_)                                                                                          \
+    do {                                                                                                                   \
+        static std::atomic<uint64_t> set_on{0};                                                                            \
+        if (first_use_on_device(set_on))                                                                                   \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gemm_qs4_kernel<M_, LOW_, IT_>),              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+        hipLaunchKernelGGL((bin_gemm_qs4_kernel<M_, LOW_, IT_>), dim3(grid), dim3(512), lds, s, h->rows.as<uint8_t>(),     \
+                           (uint32_t)h->ds, frag + (q_base / 16) * nsteps * 64, q_off + q_base, bq + q_base, zx ? 1 : 0,   \
+                           (uint32_t)n, nq, fs);                                                                           \
+    } while (0)
+#define QAMD_QS4(M_, LOW_)                                                                                                  \
+    do {                                                                                                                   \
+        if (Q <= 128) QAMD_QS4_IT(M_, LOW_, 1);                                                                            \
+        else if (Q <= 256) QAMD_QS4_IT(M_, LOW_, 2);                                                                       \
+        else QAMD_QS4_IT(M_, LOW_, 4);                                                                                     \
+    } while (0)
+            if (largest) {
+                if (low) QAMD_QS4(1, true);
+                else QAMD_QS4(1, false);
+            } else {
+                if (low) QAMD_QS4(2, true);
+                else QAMD_QS4(2, false);
+            }
+#undef QAMD_QS4
+#undef QAMD_QS4_IT
+            QAMD_HIP(hipGetLastError());
+        }
+        if (Q <= 4096)
+            hipLaunchKernelGGL(wave_scatter_grouped_kernel, dim3(std::min<uint32_t>(n_lists, 128)), dim3(1024), (size_t)Q * 8, s, wave_cand,
+                               wave_counts, wave_cap, n_lists, (uint32_t)Q, counters, cand, overflow_dev);
+        else
+            hipLaunchKernelGGL(wave_scatter_kernel, dim3(n_lists), dim3(256), 0, s, wave_cand, wave_counts, wave_cap, counters, cand,
+                               overflow_dev);
+    } else
     for (uint32_t q0 = 0; q0 < Q; q0 += TQ) {  // one pass over the rows per query tile; its lists are scattered right away
         if (largest) QAMD_TRY(launch_bin_gemm<1>(h, b, h->rows.as<uint8_t>(), n, q0, mi, nullptr, 0, f, s));
         else QAMD_TRY(launch_bin_gemm<2>(h, b, h->rows.as<uint8_t>(), n, q0, mi, nullptr, 0, f, s));

@@ -94,10 +94,16 @@ def test_batch_edge_cases():
     (2304, 40_000, 16),     # 18 K-blocks: three register passes per row
     (4992, 33_000, 33),     # 39 K-blocks: only a 32-query tile fits in LDS
     (640, 50_000, 300),     # five tiles
+    (1024, 70_001, 130),    # 129+ queries on rows of 512 / 1024 bits: the FP4 kernel (bin_gemm_qs4_kernel), chunks of 32 queries
+    (1024, 70_001, 600),    # ... chunks of 64 queries, several row blocks per workgroup, ragged tail
+    (512, 50_000, 257),     # 512-bit rows: four k-steps
+    (1000, 50_000, 200),    # pad bits inside a 1024-bit row
+    (1024, 40_000, 2100),   # two launch slices of 2048 queries
 ])
 def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
-    """12 queries and more on 32k rows and more take bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
-    registers, int8 MFMA, u8-style epilogue with integer operands): every list must equal the single-query
+    """12 queries and more on 32k rows and more take the matrix cores - bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
+    registers, int8 MFMA, u8-style epilogue with integer operands), and from 129 queries on rows of 512 / 1024 bits
+    bin_gemm_qs4_kernel (bits as E2M1 nibbles, FP4 MFMA, exact f32 counts): every list must equal the single-query
     top-k AND the oracle's restatement of the caller loop (score_point for every row,
     encoded_vectors_binary.rs:293-300 -> calculate_metric :219-253, then a stable best-k: ties to the
     lower id), for the four metric variants and both directions."""
