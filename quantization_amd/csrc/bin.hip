@@ -1277,6 +1277,22 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
             a[it] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
         }
     };
+    // Small batches (IT < 4: at most one chunk per wave): the wave's query fragments for all (at most 8) k-steps stay in
+    // registers for the whole launch.  Streamed, a chunk of 16 or 32 queries is 8 short k-steps behind an L2 round trip
+    // each - a 4 us floor per row block whatever the batch.
+    constexpr bool QREG = IT < 4;
+    v4i Qr[QREG ? 8 : 1][IT];
+    if (QREG) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int it = 0; it < IT; it++) Qr[j][it] = v4i{0, 0, 0, 0};
+        if ((uint32_t)wave < live_chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((uint32_t)j < nsteps) load_step(Qr[j], (uint32_t)wave, (uint32_t)j);
+        }
+    }
     const uint32_t b_row = i16 * PA, b_gi = (g4 ^ i16) * 16u;
     // Row-block fill: the block is 128 * ds contiguous bytes of the store; thread t takes the 16-byte (128-bit) pieces
     // t, t + 512, ... (ds / 16 * 128 / 512 = ds / 64 of them: 2 at 1024 bits), requested before the barrier that frees the
@@ -1285,9 +1301,13 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     // adjacent lanes.
     const uint32_t per = ds / 16;                                       // pieces per row: 4, 8, 12 or 16
     const uint32_t n_pieces = __builtin_amdgcn_readfirstlane(per / 4);  // per thread: 128 * per / 512
-    constexpr int MAXP = 4;
-    uint4 st[MAXP];
-    auto fill_request = [&](uint32_t blk) {
+    constexpr int MAXP = 2;  // rows of up to 1024 bits
+    // TWO register sets: a block's bits are requested one block before they are expanded.  `vmcnt` retires in order and
+    // the K loop waits for its query fragments at every k-step, so a request in front of a K loop stalls it for an HBM
+    // round trip (measured: a 3.9 us floor per block); the request is placed behind the last query loads of the wave's
+    // last chunk instead, and the data is not needed before the END of the following block.
+    uint4 stA[MAXP], stB[MAXP];
+    auto fill_request = [&](uint4(&st)[MAXP], uint32_t blk) {
         const uint8_t *p = rows + (uint64_t)blk * QS_ROWS * ds + (size_t)t * 16;
 #pragma unroll
         for (int i = 0; i < MAXP; i++) {
@@ -1295,7 +1315,7 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
             st[i] = ld_nt(reinterpret_cast<const uint4 *>(p + (size_t)ii * 8192));
         }
     };
-    auto fill_write = [&](uint64_t row0, uint32_t par) {
+    auto fill_write = [&](const uint4(&st)[MAXP], uint64_t row0, uint32_t par) {
         uint8_t *slab = lds_raw + par * SLAB;
 #pragma unroll
         for (int i = 0; i < MAXP; i++) {
@@ -1320,20 +1340,23 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     };
     const uint32_t my_first = wave;
     const uint32_t first_blk = blockIdx.x < n_blocks ? blockIdx.x : 0u;
-    fill_request(first_blk);
-    fill_write((uint64_t)first_blk * QS_ROWS, 0u);
-    if (my_first < live_chunks) {
+    auto clamp_blk = [&](uint32_t blk) { return blk < n_blocks ? blk : first_blk; };  // past the end: a harmless re-read
+    fill_request(stA, first_blk);
+    fill_write(stA, (uint64_t)first_blk * QS_ROWS, 0u);
+    fill_request(stA, clamp_blk(first_blk + gridDim.x));  // the second block's bits: expanded at the end of the first block
+    if (!QREG && my_first < live_chunks) {
         load_step(Q0, my_first, 0);
         load_step(Q1, my_first, 1);
     }
     __syncthreads();
     uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave) * filt.wave_cap;
-    uint32_t par = 0;
 
-    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    // one row block: slab `par` holds it, st_use the next block's bits (requested a block ago), st_req takes the bits of
+    // the block after that
+    auto block_body = [&](uint32_t blk, uint32_t par, const uint4(&st_use)[MAXP], uint4(&st_req)[MAXP]) {
         const uint64_t row0 = (uint64_t)blk * QS_ROWS;
-        const uint32_t next_blk = blk + gridDim.x < n_blocks ? blk + gridDim.x : blk;
-        fill_request(next_blk);  // lands under this block's MFMAs (past the end: re-request, harmless)
+        const uint32_t next_blk = clamp_blk(blk + gridDim.x), next2_blk = clamp_blk(blk + 2 * gridDim.x);
+        bool requested = false;
         const uint8_t *slab = lds_raw + par * SLAB;
         const float *voff_cur = voff_s + par * QS_ROWS;
         const int *br_cur = br_s + par * QS_ROWS;
@@ -1375,7 +1398,13 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
             if (((c >> 3) + ((uint32_t)wave >> 2)) & 1u) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
             uint32_t j = 0;
-            for (; j + 2 < nsteps; j += 3) {
+            if (QREG) {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if ((uint32_t)jj < nsteps) compute(Qr[jj], (uint32_t)jj);
+                j = nsteps;
+            }
+            for (; !QREG && j + 2 < nsteps; j += 3) {
                 request(Q2, j + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(Q0, j);
@@ -1389,7 +1418,7 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
                 compute(Q2, j + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const uint32_t left = nsteps - j;
+            const uint32_t left = QREG ? 0u : nsteps - j;
             if (left >= 1) {
                 request(Q2, j + 2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1403,6 +1432,10 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_setprio(0);
+            if (c + 8 >= live_chunks) {  // this wave's last chunk of the block: no wait for younger loads follows before the block ends
+                fill_request(st_req, next2_blk);
+                requested = true;
+            }
             // ---- epilogue: lane (i16, g4) holds, per (it, jt), queries CQ c + 16 it + 4 g4 + e against row 16 jt + i16
             uint32_t c_e = c, lane_e = (uint32_t)lane;
             asm volatile("" : "+s"(c_e), "+v"(lane_e));
@@ -1462,9 +1495,14 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
                 }
             }
         }
-        fill_write((uint64_t)next_blk * QS_ROWS, par ^ 1u);  // the other slab: last read a block ago, a barrier has passed since
+        if (!requested) fill_request(st_req, next2_blk);  // a wave without chunks
+        fill_write(st_use, (uint64_t)next_blk * QS_ROWS, par ^ 1u);  // the other slab: last read a block ago, a barrier has passed since
         __syncthreads();
-        par ^= 1u;
+    };
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += 2 * gridDim.x) {
+        block_body(blk, 0u, stA, stB);
+        if (blk + gridDim.x >= n_blocks) break;
+        block_body(blk + gridDim.x, 1u, stB, stA);
     }
     if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
