@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(512) void bin_gemm_rs_kernel(const uint8_t *__restr
 // (nibbles: 4 x the row bytes, pitch = whole 256-byte bank rows, 16-byte chunks XOR (row & 15)) and streams the whole
 // batch past it - up to 2048 queries per launch, their nibble image prepared once per call in fragment order
 // (bin_frag4_kernel: per 16 queries and 128-bit k-step one 1 KiB piece, lane (i, g) = bits [128 s + 32 g, +32) of query
-// i).  Same epilogue arithmetic as bin_gemm_rs_kernel: the scores are the reference's bit for bit.  Rows of 512 / 1024 bits.
+// i).  Same epilogue arithmetic as bin_gemm_rs_kernel: the scores are the reference's bit for bit.  Rows of 512 / 768 / 1024 bits.
 constexpr uint64_t kQs4Slice = 2048, kQs4MinQueries = 129;  // queries per launch of bin_gemm_qs4_kernel; from where it is used
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
@@ -1250,7 +1250,9 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
     const uint32_t nsteps = __builtin_amdgcn_readfirstlane(ds / 16);  // k-steps of 128 bits
-    const uint32_t PA = ds * 4;                                       // LDS pitch of a row's nibble image (ds % 64 == 0)
+    const uint32_t PA = ((ds * 4 + 255) / 256) * 256;                 // LDS pitch of a row's nibble image: whole 256-byte bank rows
+                                                                      // (768-bit rows: 384 bytes of nibbles on a 512-byte pitch; the
+                                                                      // places past the image are only multiplied with zero nibbles)
     const float multiplier = zx ? 4.0f : -4.0f;
     const uint32_t n_blocks = (n_rows + QS_ROWS - 1) / QS_ROWS;
     const uint32_t live_chunks = (n_queries + CQ - 1) / CQ;
@@ -1299,8 +1301,9 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     // LDS rows, expanded and written after it: piece pc of row r = nibble chunks 4 pc .. 4 pc + 3, each at place
     // chunk ^ (r & 15).  The row's popcount (its offset in the score) is the sum over its ds / 16 pieces, which sit in
     // adjacent lanes.
-    const uint32_t per = ds / 16;                                       // pieces per row: 4, 8, 12 or 16
-    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane(per / 4);  // per thread: 128 * per / 512
+    const uint32_t per = ds / 16;                        // 128-bit pieces per row: 4, 6 or 8
+    const uint32_t sper = per <= 4 ? 4u : 8u;            // lanes per row (a power of two: the row's popcount is a butterfly sum)
+    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane(sper / 4);  // rounds: 128 rows * sper lanes / 512 threads
     constexpr int MAXP = 2;  // rows of up to 1024 bits
     // TWO register sets: a block's bits are requested one block before they are expanded.  `vmcnt` retires in order and
     // the K loop waits for its query fragments at every k-step, so a request in front of a K loop stalls it for an HBM
@@ -1308,11 +1311,12 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     // last chunk instead, and the data is not needed before the END of the following block.
     uint4 stA[MAXP], stB[MAXP];
     auto fill_request = [&](uint4(&st)[MAXP], uint32_t blk) {
-        const uint8_t *p = rows + (uint64_t)blk * QS_ROWS * ds + (size_t)t * 16;
+        const uint8_t *p = rows + (uint64_t)blk * QS_ROWS * ds;
 #pragma unroll
         for (int i = 0; i < MAXP; i++) {
             const uint32_t ii = (uint32_t)i < n_pieces ? (uint32_t)i : n_pieces - 1;  // wave-uniform
-            st[i] = ld_nt(reinterpret_cast<const uint4 *>(p + (size_t)ii * 8192));
+            const uint32_t slot = (uint32_t)t + 512u * ii, row = slot / sper, pc = slot % sper;
+            st[i] = pc < per ? ld_nt(reinterpret_cast<const uint4 *>(p + (size_t)row * ds + (size_t)pc * 16)) : make_uint4(0, 0, 0, 0);
         }
     };
     auto fill_write = [&](const uint4(&st)[MAXP], uint64_t row0, uint32_t par) {
@@ -1320,16 +1324,18 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
 #pragma unroll
         for (int i = 0; i < MAXP; i++) {
             if ((uint32_t)i >= n_pieces) break;
-            const uint32_t piece = (uint32_t)t + 512u * i, row = piece / per, pc = piece % per;
+            const uint32_t slot = (uint32_t)t + 512u * i, row = slot / sper, pc = slot % sper;
             const uint32_t w[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+            if (pc < per) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t chunk = 4u * pc + k;
-                *reinterpret_cast<uint4 *>(slab + row * PA + ((chunk ^ (row & 15u)) * 16u)) = nib32(w[k]);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t chunk = 4u * pc + k;
+                    *reinterpret_cast<uint4 *>(slab + row * PA + ((chunk ^ (row & 15u)) * 16u)) = nib32(w[k]);
+                }
             }
             // popcount of the row: pieces of a row are in `per` adjacent lanes of this round (per divides 64)
             uint32_t pop = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
-            for (uint32_t d = 1; d < per; d <<= 1) pop += (uint32_t)__shfl_xor((int)pop, (int)d);  // per = 4, 8 or 16 (the launcher's condition)
+            for (uint32_t d = 1; d < sper; d <<= 1) pop += (uint32_t)__shfl_xor((int)pop, (int)d);  // (lanes past the row's pieces hold zeros)
             if (pc == 0) {
                 const bool ok = row0 + row < n_rows;
                 const float v_off = zx ? -2.0f * (float)pop : 2.0f * (float)pop;
@@ -1607,7 +1613,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     }
     // rows of 512 / 1024 / 2048 bits, enough queries: the FP4 query-streaming form (QAMD_BIN4=0 / QAMD_BIN4_MIN: developer A/B)
     static const char *e4 = getenv("QAMD_BIN4"), *e4min = getenv("QAMD_BIN4_MIN");
-    const bool qs4 = (h->ds == 64 || h->ds == 128) && !(e4 && e4[0] == '0') &&
+    const bool qs4 = (h->ds == 64 || h->ds == 96 || h->ds == 128) && !(e4 && e4[0] == '0') &&
                      Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries);
     const uint32_t n_lists = pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
     const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, qs4 ? kQs4Slice : TQ) / (double)pp_waves_per_launch();
@@ -1669,7 +1675,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
         else
             hipLaunchKernelGGL(bin_frag4_kernel<false>, dim3(pgrid), dim3(256), 0, s, b->bits.as<uint8_t>(), (uint32_t)b->q_stride, (uint32_t)Q,
                                (uint32_t)q_pad, nsteps, (float)h->vp.dim, zx ? 1 : 0, largest, pivots, frag, q_off, bq);
-        const size_t lds = 2 * (size_t)128 * h->ds * 4 + 4 * 128 * 4 + 64 + kQs4Slice * 4;
+        const size_t lds = 2 * (size_t)128 * round_up(h->ds * 4, 256) + 4 * 128 * 4 + 64 + kQs4Slice * 4;
         const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
         for (uint64_t q_base = 0; q_base < Q; q_base += kQs4Slice) {
             const uint32_t nq = (uint32_t)std::min<uint64_t>(kQs4Slice, Q - q_base);

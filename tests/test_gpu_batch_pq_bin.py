@@ -98,6 +98,8 @@ def test_batch_edge_cases():
     (1024, 70_001, 600),    # ... chunks of 64 queries, several row blocks per workgroup, ragged tail
     (512, 50_000, 257),     # 512-bit rows: four k-steps
     (1000, 50_000, 200),    # pad bits inside a 1024-bit row
+    (768, 60_000, 300),     # 768-bit rows: six k-steps, 384 bytes of nibbles on a 512-byte LDS pitch
+    (700, 40_000, 140),     # ... with pad bits, chunks of 32 queries in registers
     (1024, 40_000, 2100),   # two launch slices of 2048 queries
 ])
 def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
