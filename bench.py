@@ -539,8 +539,8 @@ def main():
             is_bin = args.quantizer == "binary"
             ad = dim if is_bin else enc.metadata["actual_dim"]  # binary: one 0/1 operand byte per bit on the matrix cores
             ops = 2.0 * Q * n * ad  # per GPU and step
-            # binary batches of 129+ queries on rows of 4 / 6 / 8 128-bit words take the fp4 matrix-core kernel (csrc/bin.hip)
-            bin_fp4 = is_bin and Q >= 129 and (ad + 127) // 128 in (4, 6, 8) and os.environ.get("QAMD_BIN4", "1") != "0"
+            # binary batches of 129+ queries on rows of 4 / 6 / 8 / 12 128-bit words take the fp4 matrix-core kernel (csrc/bin.hip)
+            bin_fp4 = is_bin and Q >= 129 and (ad + 127) // 128 in (4, 6, 8, 12) and os.environ.get("QAMD_BIN4", "1") != "0"
             mfma_peak = MFMA_FP4_PEAK_TOPS if bin_fp4 else MFMA_INT8_PEAK_TOPS
             per_gpu_tops = ops * args.steps / elapsed / 1e12
             print(json.dumps({

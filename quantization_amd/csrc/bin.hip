@@ -1189,7 +1189,8 @@ __global__ __launch_bounds__(512) void bin_gemm_rs_kernel(const uint8_t *__restr
 // (nibbles: 4 x the row bytes, pitch = whole 256-byte bank rows, 16-byte chunks XOR (row & 15)) and streams the whole
 // batch past it - up to 2048 queries per launch, their nibble image prepared once per call in fragment order
 // (bin_frag4_kernel: per 16 queries and 128-bit k-step one 1 KiB piece, lane (i, g) = bits [128 s + 32 g, +32) of query
-// i).  Same epilogue arithmetic as bin_gemm_rs_kernel: the scores are the reference's bit for bit.  Rows of 512 / 768 / 1024 bits.
+// i).  Same epilogue arithmetic as bin_gemm_rs_kernel: the scores are the reference's bit for bit.  Rows of 512 / 768 / 1024 /
+// 1536 bits.
 constexpr uint64_t kQs4Slice = 2048, kQs4MinQueries = 129;  // queries per launch of bin_gemm_qs4_kernel; from where it is used
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
@@ -1238,13 +1239,14 @@ __global__ __launch_bounds__(256) void bin_frag4_kernel(const uint8_t *__restric
 }
 
 // IT: 16-query tiles per wave and chunk - 4 (64 queries), 2 for batches of up to 256 queries, 1 up to 128 (a chunk for every wave)
-template <int MODE, bool LOW, int IT>  // MODE 1 / 2: filter for the largest / smallest scores
+// JT: 16-row tiles per block - 8 (128 rows; rows of up to 1024 bits), 6 (96 rows of 1536 bits: two 72 KiB slabs)
+template <int MODE, bool LOW, int IT, int JT>  // MODE 1 / 2: filter for the largest / smallest scores
 __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__restrict__ rows, uint32_t ds,
                                                           const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
                                                           const int *__restrict__ bq_all, int zx, uint32_t n_rows,
                                                           uint32_t n_queries, BatchFilter filt) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
-    constexpr int JT = 8, JH = 4, QS_ROWS = 16 * JT, CQ = 16 * IT;
+    constexpr int JH = JT / 2, QS_ROWS = 16 * JT, CQ = 16 * IT, MAXSTEPS = JT == 8 ? 8 : 12;
     constexpr bool LARGEST = MODE == 1;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1283,15 +1285,15 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     // registers for the whole launch.  Streamed, a chunk of 16 or 32 queries is 8 short k-steps behind an L2 round trip
     // each - a 4 us floor per row block whatever the batch.
     constexpr bool QREG = IT < 4;
-    v4i Qr[QREG ? 8 : 1][IT];
+    v4i Qr[QREG ? MAXSTEPS : 1][IT];
     if (QREG) {
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+        for (int j = 0; j < MAXSTEPS; j++)
 #pragma unroll
             for (int it = 0; it < IT; it++) Qr[j][it] = v4i{0, 0, 0, 0};
         if ((uint32_t)wave < live_chunks) {
 #pragma unroll
-            for (int j = 0; j < 8; j++)
+            for (int j = 0; j < MAXSTEPS; j++)
                 if ((uint32_t)j < nsteps) load_step(Qr[j], (uint32_t)wave, (uint32_t)j);
         }
     }
@@ -1301,10 +1303,10 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     // LDS rows, expanded and written after it: piece pc of row r = nibble chunks 4 pc .. 4 pc + 3, each at place
     // chunk ^ (r & 15).  The row's popcount (its offset in the score) is the sum over its ds / 16 pieces, which sit in
     // adjacent lanes.
-    const uint32_t per = ds / 16;                        // 128-bit pieces per row: 4, 6 or 8
-    const uint32_t sper = per <= 4 ? 4u : 8u;            // lanes per row (a power of two: the row's popcount is a butterfly sum)
-    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane(sper / 4);  // rounds: 128 rows * sper lanes / 512 threads
-    constexpr int MAXP = 2;  // rows of up to 1024 bits
+    const uint32_t per = ds / 16;                        // 128-bit pieces per row: 4, 6, 8 or 12
+    const uint32_t sper = per <= 4 ? 4u : per <= 8 ? 8u : 16u;  // lanes per row (a power of two: the row's popcount is a butterfly sum)
+    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane(QS_ROWS * sper / 512);  // rounds: rows * sper lanes / 512 threads
+    constexpr int MAXP = JT == 8 ? 2 : 3;  // 128 rows x 8 lanes / 512; 96 x 16 / 512
     // TWO register sets: a block's bits are requested one block before they are expanded.  `vmcnt` retires in order and
     // the K loop waits for its query fragments at every k-step, so a request in front of a K loop stalls it for an HBM
     // round trip (measured: a 3.9 us floor per block); the request is placed behind the last query loads of the wave's
@@ -1406,7 +1408,7 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
             uint32_t j = 0;
             if (QREG) {
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++)
+                for (int jj = 0; jj < MAXSTEPS; jj++)
                     if ((uint32_t)jj < nsteps) compute(Qr[jj], (uint32_t)jj);
                 j = nsteps;
             }
@@ -1613,7 +1615,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     }
     // rows of 512 / 1024 / 2048 bits, enough queries: the FP4 query-streaming form (QAMD_BIN4=0 / QAMD_BIN4_MIN: developer A/B)
     static const char *e4 = getenv("QAMD_BIN4"), *e4min = getenv("QAMD_BIN4_MIN");
-    const bool qs4 = (h->ds == 64 || h->ds == 96 || h->ds == 128) && !(e4 && e4[0] == '0') &&
+    const bool qs4 = (h->ds == 64 || h->ds == 96 || h->ds == 128 || h->ds == 192) && !(e4 && e4[0] == '0') &&
                      Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries);
     const uint32_t n_lists = pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
     const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, qs4 ? kQs4Slice : TQ) / (double)pp_waves_per_launch();
@@ -1675,7 +1677,8 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
         else
             hipLaunchKernelGGL(bin_frag4_kernel<false>, dim3(pgrid), dim3(256), 0, s, b->bits.as<uint8_t>(), (uint32_t)b->q_stride, (uint32_t)Q,
                                (uint32_t)q_pad, nsteps, (float)h->vp.dim, zx ? 1 : 0, largest, pivots, frag, q_off, bq);
-        const size_t lds = 2 * (size_t)128 * round_up(h->ds * 4, 256) + 4 * 128 * 4 + 64 + kQs4Slice * 4;
+        const size_t qs_rows = h->ds > 128 ? 96 : 128;
+        const size_t lds = 2 * qs_rows * round_up(h->ds * 4, 256) + 4 * qs_rows * 4 + 64 + kQs4Slice * 4;
         const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
         for (uint64_t q_base = 0; q_base < Q; q_base += kQs4Slice) {
             const uint32_t nq = (uint32_t)std::min<uint64_t>(kQs4Slice, Q - q_base);
@@ -1683,15 +1686,20 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
             fs.pivot_scores = pivots + q_base;
             fs.query_base = (uint32_t)q_base;
             fs.wave_base = (uint32_t)(q_base / kQs4Slice) * pp_waves_per_launch();
-#define QAMD_QS4_IT(M_, LOW_, IT_)                                                                                          \
+#define QAMD_QS4_JT(M_, LOW_, IT_, JT_)                                                                                     \
     do {                                                                                                                   \
         static std::atomic<uint64_t> set_on{0};                                                                            \
         if (first_use_on_device(set_on))                                                                                   \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gemm_qs4_kernel<M_, LOW_, IT_>),              \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gemm_qs4_kernel<M_, LOW_, IT_, JT_>),         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
-        hipLaunchKernelGGL((bin_gemm_qs4_kernel<M_, LOW_, IT_>), dim3(grid), dim3(512), lds, s, h->rows.as<uint8_t>(),     \
+        hipLaunchKernelGGL((bin_gemm_qs4_kernel<M_, LOW_, IT_, JT_>), dim3(grid), dim3(512), lds, s, h->rows.as<uint8_t>(), \
                            (uint32_t)h->ds, frag + (q_base / 16) * nsteps * 64, q_off + q_base, bq + q_base, zx ? 1 : 0,   \
                            (uint32_t)n, nq, fs);                                                                           \
+    } while (0)
+#define QAMD_QS4_IT(M_, LOW_, IT_)                                                                                          \
+    do {                                                                                                                   \
+        if (h->ds > 128) QAMD_QS4_JT(M_, LOW_, IT_, 6);                                                                    \
+        else QAMD_QS4_JT(M_, LOW_, IT_, 8);                                                                                \
     } while (0)
 #define QAMD_QS4(M_, LOW_)                                                                                                  \
     do {                                                                                                                   \
@@ -1708,6 +1716,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
             }
 #undef QAMD_QS4
 #undef QAMD_QS4_IT
+#undef QAMD_QS4_JT
             QAMD_HIP(hipGetLastError());
         }
         if (Q <= 4096)

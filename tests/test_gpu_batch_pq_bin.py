@@ -100,6 +100,8 @@ def test_batch_edge_cases():
     (1000, 50_000, 200),    # pad bits inside a 1024-bit row
     (768, 60_000, 300),     # 768-bit rows: six k-steps, 384 bytes of nibbles on a 512-byte LDS pitch
     (700, 40_000, 140),     # ... with pad bits, chunks of 32 queries in registers
+    (1536, 40_000, 300),    # 1536-bit rows: 96-row blocks, twelve k-steps
+    (1500, 35_000, 100 + 60),  # ... pad bits, chunks of 32 queries in registers (12 k-steps x 2 tiles)
     (1024, 40_000, 2100),   # two launch slices of 2048 queries
 ])
 def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
