@@ -13,6 +13,11 @@
 // Scan mapping: as the u8 scan — G lanes read one row in 16-byte pieces, one wave-load covers
 // 64/G consecutive rows — with v_xor + v_bcnt_u32_b32 instead of v_dot4.  All integer, exact;
 // the f32 metric (:219-253) is exact for dim < 2^23.
+//
+// Many queries at once run on the matrix cores, where popcount(q AND v) is a dot product of 0/1 values: from 12 queries
+// bin_gemm_rs_kernel (bits expanded to bytes in registers, int8 MFMA), from 129 queries on rows of 512 / 768 / 1024 / 1536
+// bits bin_gemm_qs4_kernel (bits expanded once per row block to E2M1 nibbles in LDS, FP4 MFMA with exact f32 counts, the
+// batch streamed past the block).  Both end in the reference's calculate_metric on the integer count: bit-identical.
 #include <algorithm>
 #include <memory>
 #include <vector>
