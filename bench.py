@@ -488,7 +488,8 @@ def main():
         del rows
         queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
         bytes_per_row = m
-        kernel_name = "pq_scan_fast_kernel"
+        pq_skew = m % 32 == 0 and m <= 96 and os.environ.get("QAMD_PQ_SKEW", "1")[:1] != "0"  # csrc/pq.hip skew_capable()
+        kernel_name = "pq_scan_skew_kernel" if pq_skew else "pq_scan_fast_kernel"
     args.no_cpu_baseline = args.no_cpu_baseline or args.quantizer != "u8"
     scaling_field = "weak" if (world == 1 or scaling == "weak") else "strong"
     # (at N = 1 there is nothing to scale; the contract's field keeps its default)
@@ -679,11 +680,19 @@ def main():
             # The PQ scan reads only m bytes per row from HBM; its limiter is the LDS gather (one
             # ds_read_b32 per chunk and row, bank-conflicting by construction: DESIGN 3.3).
             lds = 4.0 * bytes_per_row * n / (kern_ms * 1e-3) / 1e9
-            roofline.update({"bound": "lds", "achieved": lds, "peak": LDS_B32_PEAK_GBPS, "frac": lds / LDS_B32_PEAK_GBPS,
-                             "hbm_achieved_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBPS,
-                             "note": "achieved = 4 B x m LUT gathers per row (ds_read_b32) against the conflict-free "
-                                     "LDS rate of all CUs; random 8-bit codes give ~3.5-way bank conflicts, i.e. a "
-                                     "practical ceiling near 0.29 of that peak"})
+            if pq_skew:
+                # pq_scan_skew_kernel (m = 32 / 64 / 96): transposed LUT + quads skewed in time, no bank conflicts
+                # (SQ_LDS_BANK_CONFLICT = 0): the nominal bound, HBM reads of m bytes per row, is the roofline again
+                roofline.update({"lds_gather_GBps": lds, "lds_gather_frac_of_conflict_free_peak": lds / LDS_B32_PEAK_GBPS,
+                                 "note": "m code bytes per row from HBM; per chunk and row one ds_read_u8 (code), one "
+                                         "ds_read_b32 (table entry) and two vector-ALU operations, all conflict-free: the "
+                                         "kernel is bound by instruction issue (LDS pipe 62 %, vector ALU 47 % busy)"})
+            else:
+                roofline.update({"bound": "lds", "achieved": lds, "peak": LDS_B32_PEAK_GBPS, "frac": lds / LDS_B32_PEAK_GBPS,
+                                 "hbm_achieved_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBPS,
+                                 "note": "achieved = 4 B x m LUT gathers per row (ds_read_b32) against the conflict-free "
+                                         "LDS rate of all CUs; random 8-bit codes give ~3.5-way bank conflicts, i.e. a "
+                                         "practical ceiling near 0.29 of that peak"})
         traffic, source = pmc_traffic(args.quantizer, n, bytes_per_row)
         if traffic is not None:
             roofline["traffic"] = traffic

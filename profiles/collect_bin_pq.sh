@@ -42,7 +42,7 @@ for r in list(csv.DictReader(open(f)))[:14]:
     print(f'{name:90s} calls {r["Calls"]:>4s}  avg_us {float(r["AverageNs"])/1e3:9.1f}  min_us {float(r["MinNs"])/1e3:9.1f}')
 PY
 } > "$RES"
-for K in "bin_scan_kernel" "bin_scan_multi_kernel" "bin_gemm_rs_kernel" "pq_scan_fast_kernel"; do
+for K in "bin_scan_kernel" "bin_scan_multi_kernel" "bin_gemm_rs_kernel" "pq_scan_fast_kernel" "pq_scan_skew_kernel"; do
   echo >> "$RES"; echo "== $K" >> "$RES"
   python3 profiles/summarize.py counters "$FIRST" "$K" "$OUT/tmp_$K.txt" "$@" > /dev/null
   cat "$OUT/tmp_$K.txt" >> "$RES"

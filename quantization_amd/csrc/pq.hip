@@ -314,6 +314,170 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
     }
 }
 
+// The same scan with the LDS gathers free of bank conflicts (m = 32, 64 or 96; one slice).
+//
+// pq_scan_fast_kernel's 32 lanes of a `ds_read_b32` group read 8 rows' independent codes out of only four chunk tables:
+// 3.5 distinct addresses per bank on average, 6.9 LDS cycles per gather against 2 (profiles/r01_pmc_bin_pq_scans.txt).
+// Here the LUT sits in LDS TRANSPOSED, [code][chunk]: entry (chunk c, code) is at float code * m + c, so with m % 32 == 0
+// its bank is c % 32 whatever the code.  The eight quads of a lane group then only have to be at eight different chunk
+// groups at the same moment, which a skew in TIME gives: quad q runs r = 8 - (q & 7) chunk groups behind, lane (q, k)
+// reads chunk 4 (u - r) + k at step u, and the 32 lanes of a group hit 32 different banks (SQ_LDS_BANK_CONFLICT = 0).
+// A lane's sum still walks chunks k, k + 4, ... of its row in order (the reference's SSE lane sum, :405-440) - the skew
+// only moves WHEN it does so.  For that a quad needs its rows as one continuous byte stream: a wave copies each block of
+// 16 consecutive rows (coalesced 16-byte loads, registers, `ds_write_b128`) into a two-slot ring of its own in LDS, quad q
+// owns row q of every block, and lane (q, k) fetches its code bytes from the ring with `ds_read_u8` at 4 (u - r) + k - no
+// cross-lane moves and no bit-field extraction, two vector-ALU operations per gather (address, add).  During the first
+// r steps of a row time a quad is still finishing its row of the previous block (the ring's other slot); that slot is
+// refilled at step 8.  The ring reads are conflict-free too: rows are packed back to back (m / 4 dwords), so the eight
+// quads of a group start (m / 4 + 1) q dwords apart, an odd stride.  Result bits are those of pq_scan_fast_kernel.
+__global__ __launch_bounds__(kBlock) void pq_lut_transpose_kernel(const float *__restrict__ lut, uint32_t m,
+                                                                 float *__restrict__ lut_t) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // = code * m + c
+    if (i < m * kCentroids) lut_t[i] = lut[(size_t)(i % m) * kCentroids + i / m];
+}
+
+__device__ __forceinline__ uint32_t code_address(uint32_t code, uint32_t pitch, uint32_t base) { return __umul24(code, pitch) + base; }
+
+constexpr uint32_t kSkewLdsLead = 128;  // bytes in front of the LUT: a lane's base offset 4 k - 16 r + lead is never negative
+constexpr size_t skew_lds_bytes(uint32_t m) { return kSkewLdsLead + (size_t)m * kCentroids * 4 + (kScanBlock / 64) * 32u * m; }
+
+template <int NV, bool FILTER>
+__global__ __launch_bounds__(kScanBlock) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
+                                                                 const float *__restrict__ lut_t_g, uint32_t n_rows,
+                                                                 float *__restrict__ out, TopkFilter filt) {
+    constexpr int M = 16 * NV, S = 4 * NV;
+    constexpr int D = 4;  // blocks of codes in flight per wave (registers)
+    static_assert(M % 32 == 0 && S >= 8, "shape");
+    constexpr uint32_t kLut0 = kSkewLdsLead, kStage0 = kLut0 + 4u * M * kCentroids, kSlot = 16u * M;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(lut_t_g);
+        float4 *dst = reinterpret_cast<float4 *>(lds_raw + kLut0);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kScanBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = lane & 3, q = lane >> 2, r = 8u - (q & 7u);
+    const uint32_t gw = blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kScanBlock / 64);
+    const uint32_t n_blocks = (n_rows + 15) / 16;  // blocks of 16 rows; this wave: gw, gw + n_waves, ...
+    if (gw >= n_blocks) return;
+    const uint32_t J = (n_blocks - gw + n_waves - 1) / n_waves;
+    const uint32_t stage = kStage0 + (threadIdx.x >> 6) * 2u * kSlot;
+    // LUT byte offset of chunk 4 (u - r) + k without the code (step u adds 16 u as an immediate); steps u < r belong to
+    // the previous row (chunk group u - r + S): one table row (4 M bytes) further
+    const uint32_t off_cur = kLut0 + 4u * k - 16u * r, off_new = off_cur + 4u * M;
+    // ring byte address of step u's code without 4 u: even row times have the current block in slot 0, odd ones in slot 1
+    const uint32_t rd0 = stage + q * M + k - 4u * r;
+    uint32_t rd_even[8], rd_odd[8], lut_base[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const bool lag = (int)r > u;
+        rd_even[u] = rd0 + (lag ? kSlot + 4u * S : 0u);
+        rd_odd[u] = rd0 + (lag ? 4u * S : kSlot);
+        lut_base[u] = lag ? off_new : off_cur;
+    }
+    uint32_t pivot = 0;
+    if (FILTER) pivot = *filt.pivot_key;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, FILTER ? 0 : n_rows * 4u, 0x00020000);
+
+    // A block is 16 M contiguous bytes: 1024 of them go as one 16-byte piece per lane, the other 512 (M = 32: the only
+    // 512, M = 96: the second round) as 8 bytes per lane - every lane loads and writes in every round, so the refill has no
+    // branch (a branch would cut the loop body into basic blocks, and a code byte that crosses one is masked to 8 bits again)
+    constexpr bool kWide = M >= 64, kHalf = (M % 64) != 0;
+    struct Held {
+        uint4 wide;
+        uint2 half;
+    };
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(gw), n_waves_u = __builtin_amdgcn_readfirstlane(n_waves);
+    const uint32_t J_u = __builtin_amdgcn_readfirstlane(J);
+    const uint8_t *rows_b = reinterpret_cast<const uint8_t *>(rows4);
+    auto request = [&](Held &h, uint32_t j) {  // block j of this wave (past the end: its last block again, unused)
+        const uint8_t *p = rows_b + (size_t)(wave_u + (j < J_u ? j : J_u - 1) * n_waves_u) * (16u * M);  // wave-uniform
+        if (kWide) h.wide = ld_nt(reinterpret_cast<const uint4 *>(p) + lane);
+        if (kHalf) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p + (kWide ? 1024 : 0)) + lane);
+            h.half = make_uint2(t.x, t.y);
+        }
+    };
+    auto refill = [&](const Held &h, uint32_t slot) {
+        uint8_t *d = lds_raw + stage + slot * kSlot;
+        if (kWide) *reinterpret_cast<uint4 *>(d + 16u * lane) = h.wide;
+        if (kHalf) *reinterpret_cast<uint2 *>(d + (kWide ? 1024u : 0u) + 8u * lane) = h.half;
+    };
+    Held buf[D];  // buf[j % D] = block j
+#pragma unroll
+    for (int j = 0; j < D; j++) request(buf[j], j);
+    refill(buf[0], 0);
+    request(buf[0], D);
+    // A step is two dependent LDS round trips (code byte, table entry) and an add.  Steps go in groups of eight through a
+    // three-stage pipeline kept in this order by scheduling barriers - A(G + 1): ask for the next group's code bytes,
+    // C(G - 1): add the previous group's table entries, B(G): addresses and gathers of this group - so a wave always has
+    // reads in flight while it computes (left to itself the compiler emits read, wait, compute, read, wait, ...).
+    constexpr int GR = S / 8, NG = D * GR;  // groups per row time; groups per trip of the loop (D row times)
+    auto ring_addr = [&](int jj, int u) { return u < 8 ? ((jj & 1) ? rd_odd[u] : rd_even[u]) : rd0 + ((jj & 1) ? kSlot : 0u); };
+    uint32_t codes[2][8];
+    float vals[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        codes[0][e] = lds_raw[ring_addr(0, e) + 4 * e];  // A(0)
+        vals[1][e] = 0.0f;
+    }
+    float acc = 0.0f, done = 0.0f;
+    for (uint32_t j0 = 0; j0 < J + 2; j0 += D) {
+#pragma unroll
+        for (int G = 0; G < NG; G++) {
+            const int jj = G / GR, g = G % GR;
+            if (g == 0) {  // the slot of block j - 1 is free (its last reads went out with A of this group): block j + 1
+                           // goes there, and its registers take block j + 1 + D
+                refill(buf[(jj + 1) % D], (jj + 1) & 1);
+                request(buf[(jj + 1) % D], j0 + jj + 1 + D);
+            }
+            {  // A(G + 1)
+                const int Gn = (G + 1) % NG, jjn = Gn / GR, gn = Gn % GR;
+#pragma unroll
+                for (int e = 0; e < 8; e++) codes[(G + 1) & 1][e] = lds_raw[ring_addr(jjn, 8 * gn + e) + 4 * (8 * gn + e)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {  // B(G)
+                const int u = 8 * g + e;
+                const uint32_t base = u < 8 ? lut_base[u] : off_cur;
+                                vals[G & 1][e] = *reinterpret_cast<const float *>(lds_raw + code_address(codes[G & 1][e], 4u * M, base) + 16 * u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {  // C(G - 1)
+                const int Gp = (G + NG - 1) % NG, jjp = Gp / GR, gp = Gp % GR;
+                const uint32_t jp = G == 0 ? j0 - 1u : j0 + (uint32_t)jjp;  // its row time
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    acc += vals[(G + 1) & 1][e];
+                    if (gp == 0) {  // step u = e < 8; quads r = u + 1: that was the last chunk group of their previous row
+                        const bool fin = (int)r == e + 1;
+                        done = fin ? acc : done;
+                        acc = fin ? 0.0f : acc;
+                    }
+                }
+                if (gp == 0) {  // every quad's row of block jp - 1 is complete:  (l0 + l2) + (l1 + l3)  (:430-432)
+                    const float a = done + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(done), 0x4E, 0xF, 0xF, false));
+                    const float sc = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));
+                    const uint32_t row = (gw + (jp - 1) * n_waves) * 16u + q;
+                    const bool live = jp >= 1 && jp <= J && row < n_rows;
+                    if (FILTER) {
+                        if (k == 0 && live) topk_offer(filt, pivot, sc, row);
+                    } else {
+                        // all four lanes of the quad hold the same bits (f32 addition commutes): they store the same word;
+                        // a buffer store drops the lanes whose offset is out of range, so there is no branch here either
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), out_rsrc, live ? row * 4u : 0xFFFFFFFFu, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ encode
 // encode_vector (:237-265): a thread owns one (row, chunk) and walks the 256 centroids in
 // index order with the reference's strict '<', so ties and NaNs resolve identically.  The
@@ -432,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void pq_encode_cs_kernel(const float *__res
 __global__ __launch_bounds__(kBlock) void pq_lut_kernel(const float *__restrict__ query, uint32_t dim,
                                                        uint32_t chunk_size, uint32_t m,
                                                        const float *__restrict__ centroids, int distance,
-                                                       int invert, float *__restrict__ lut) {
+                                                       int invert, float *__restrict__ lut, float *__restrict__ lut_t) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= m * kCentroids) return;
     const uint32_t c = i / kCentroids, kc = i % kCentroids;
@@ -446,13 +610,14 @@ __global__ __launch_bounds__(kBlock) void pq_lut_kernel(const float *__restrict_
     else
         for (uint32_t j = 0; j < len; j++) s += (a[j] - b[j]) * (a[j] - b[j]);
     lut[i] = invert ? -s : s;
+    if (lut_t) lut_t[kc * m + c] = invert ? -s : s;  // [code][chunk] for pq_scan_skew_kernel
 }
 
 // encode_query for a block of queries: blockIdx.y = query, same arithmetic as pq_lut_kernel.
 __global__ __launch_bounds__(kBlock) void pq_lut_batch_kernel(const float *__restrict__ queries, uint32_t dim,
                                                              uint32_t chunk_size, uint32_t m,
                                                              const float *__restrict__ centroids, int distance,
-                                                             int invert, float *__restrict__ luts) {
+                                                             int invert, float *__restrict__ luts, float *__restrict__ luts_t) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= m * kCentroids) return;
     const uint32_t c = i / kCentroids, kc = i % kCentroids;
@@ -466,6 +631,7 @@ __global__ __launch_bounds__(kBlock) void pq_lut_batch_kernel(const float *__res
     else
         for (uint32_t j = 0; j < len; j++) s += (a[j] - b[j]) * (a[j] - b[j]);
     luts[(size_t)blockIdx.y * m * kCentroids + i] = invert ? -s : s;
+    if (luts_t) luts_t[(size_t)blockIdx.y * m * kCentroids + kc * m + c] = invert ? -s : s;
 }
 
 // score_internal (:566-593): decode both rows to centroid sub-vectors, sequential f32.
@@ -861,7 +1027,9 @@ struct qamd_pq {
 struct qamd_pq_query {
     int device = 0;
     uint64_t m = 0;
-    DevBuf lut;  // m*256 f32
+    DevBuf lut;  // m*256 f32, chunk-major; when the store takes pq_scan_skew_kernel the [code][chunk] copy follows it
+    bool transposed = false;
+    const float *lut_t() const { return transposed ? lut.as<float>() + m * kCentroids : nullptr; }
     ReadyEvent ready;  // the last encode_query
 };
 
@@ -889,14 +1057,48 @@ bool fast_capable(const qamd_pq *h, uint64_t n) {
 
 // One slice (at most 9 pieces: 144 chunks, 144 KiB of LUT) when the row fits, else line-sized slices (kMaxSlicePieces above).
 
+// pq_scan_skew_kernel: whole rows of 32, 64 or 96 chunks on their natural pitch (QAMD_PQ_SKEW=0: the older kernel).
+bool skew_capable(const qamd_pq *h) {
+    static const bool on = [] { const char *e = getenv("QAMD_PQ_SKEW"); return !(e && e[0] == '0'); }();
+    // (scores leave through one buffer resource: 32-bit byte offsets)
+    return on && h->m % 32 == 0 && h->m <= 96 && h->ds == h->m && skew_lds_bytes((uint32_t)h->m) <= kLdsBudget && h->count < (1ull << 30);
+}
+
 template <bool FILTER>
 qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, const TopkFilter *filt,
-                        hipStream_t s) {
+                        hipStream_t s, const float *lut_t_dev) {
     const uint32_t m = (uint32_t)h->m, pitch_pieces = (uint32_t)(h->ds / 16), pieces = (uint32_t)valid_pieces(m);
     const uint32_t per = pieces <= kMaxSlicePieces ? pieces : kSlicePiecesAligned;
     const uint32_t n_slices = (pieces + per - 1) / per;
     const uint64_t n = h->count;
     const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
+    if (skew_capable(h)) {
+        // the LUT as [code][chunk]: encode_query leaves that copy behind the chunk-major one; a caller without it pays a
+        // transposing launch (96 KiB, L2-resident)
+        const float *lut_t = lut_t_dev;
+        float *ws = nullptr;
+        if (!lut_t) {
+            QAMD_TRY(thread_ws_acquire(WS_PARTIAL, (size_t)m * kCentroids * sizeof(float), s, reinterpret_cast<void **>(&ws)));
+            hipLaunchKernelGGL(pq_lut_transpose_kernel, dim3((m * kCentroids + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lut_dev, m, ws);
+            lut_t = ws;
+        }
+        const size_t lds = skew_lds_bytes(m);
+#define QAMD_PQ_SKEW(NVV)                                                                                    \
+    case NVV: {                                                                                             \
+        static std::atomic<uint64_t> set_on{0};                                                             \
+        if (first_use_on_device(set_on))                                                                    \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NVV, FILTER>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));     \
+        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER>), dim3(grid), dim3(kScanBlock), lds, s,         \
+                           h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev, filt ? *filt : TopkFilter{});    \
+        break;                                                                                              \
+    }
+        switch (m / 16) { QAMD_PQ_SKEW(2) QAMD_PQ_SKEW(4) QAMD_PQ_SKEW(6) }
+#undef QAMD_PQ_SKEW
+        if (ws) thread_ws_release(WS_PARTIAL, s);
+        QAMD_HIP(hipGetLastError());
+        return QAMD_OK;
+    }
     float *partial = nullptr;
     if (n_slices > 1) {
         const uint64_t padded = round_up(n, kRowPad) + kRowPad;
@@ -938,7 +1140,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
 }
 
 qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *ids_dev, uint64_t n,
-                        float *out_dev, hipStream_t s, const TopkFilter *filt = nullptr) {
+                        float *out_dev, hipStream_t s, const TopkFilter *filt = nullptr, const float *lut_t_dev = nullptr) {
     if (n == 0) return QAMD_OK;
     const uint32_t m = (uint32_t)h->m, row_words = (uint32_t)(h->ds / 4);
     const size_t lds = (size_t)m * kCentroids * sizeof(float);
@@ -949,7 +1151,7 @@ qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *
     hipLaunchKernelGGL((pq_scan_kernel<LDSF, V16>), dim3(GRID), dim3(kScanBlock), SH, s, h->rows.as<uint32_t>(), \
                        lut_dev, ids_dev, n, (uint32_t)h->count, m, row_words, out_dev)
     if (!ids_dev && fast_capable(h, n)) {
-        return filt ? launch_fast<true>(h, lut_dev, out_dev, filt, s) : launch_fast<false>(h, lut_dev, out_dev, filt, s);
+        return filt ? launch_fast<true>(h, lut_dev, out_dev, filt, s, lut_t_dev) : launch_fast<false>(h, lut_dev, out_dev, filt, s, lut_t_dev);
     } else if (in_lds) {
         static std::atomic<uint64_t> set_on{0};  // opt in to > 64 KiB dynamic LDS once per kernel and device
         if (first_use_on_device(set_on)) {
@@ -1445,9 +1647,11 @@ qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t 
         q->device = h->device;
     }
     const size_t n = (size_t)h->m * kCentroids;
-    if (q->m != h->m || !q->lut.ptr) {
-        QAMD_TRY(q->lut.alloc(std::max<size_t>(n, 4) * sizeof(float)));
+    const bool with_t = skew_capable(h);
+    if (q->m != h->m || !q->lut.ptr || q->transposed != with_t) {
+        QAMD_TRY(q->lut.alloc(std::max<size_t>(n, 4) * sizeof(float) * (with_t ? 2 : 1)));
         q->m = h->m;
+        q->transposed = with_t;
     }
     if (n) {
         DevBuf qtmp;
@@ -1459,7 +1663,7 @@ qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t 
         }
         hipLaunchKernelGGL(pq_lut_kernel, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, qd,
                            (uint32_t)h->vp.dim, (uint32_t)h->chunk_size, (uint32_t)h->m, h->centroids.as<float>(),
-                           h->vp.distance_type, h->vp.invert, q->lut.as<float>());
+                           h->vp.distance_type, h->vp.invert, q->lut.as<float>(), with_t ? q->lut.as<float>() + n : nullptr);
         QAMD_HIP(hipGetLastError());
         if (query_mem == QAMD_MEM_HOST) QAMD_HIP(hipStreamSynchronize(s));  // qtmp is freed on return
     }
@@ -1491,10 +1695,10 @@ qamd_status qamd_pq_score_all(const qamd_pq *h, const qamd_pq_query *q, float *o
     QAMD_ON_DEVICE(h->device);
     hipStream_t s = as_stream(stream);
     QAMD_TRY(q->ready.wait(s));
-    if (out_mem == QAMD_MEM_DEVICE) return scan_launch(h, q->lut.as<float>(), nullptr, h->count, out, s);
+    if (out_mem == QAMD_MEM_DEVICE) return scan_launch(h, q->lut.as<float>(), nullptr, h->count, out, s, nullptr, q->lut_t());
     float *tmp = nullptr;  // per-thread workspace: no hipMalloc / hipFree per query
     QAMD_TRY(thread_ws_acquire(WS_SCORES, h->count * 4, s, reinterpret_cast<void **>(&tmp)));
-    qamd_status st = scan_launch(h, q->lut.as<float>(), nullptr, h->count, tmp, s);
+    qamd_status st = scan_launch(h, q->lut.as<float>(), nullptr, h->count, tmp, s, nullptr, q->lut_t());
     if (st == QAMD_OK) st = copy_out(out, QAMD_MEM_HOST, tmp, h->count * 4, s);
     thread_ws_release(WS_SCORES, s, st == QAMD_OK);  // the download synchronised the stream
     return st;
@@ -1632,9 +1836,10 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
         return st;
     }
     FusedScan scan;
-    scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_launch(h, lut, nullptr, h->count, scores, st); };
+    const float *lut_t = q->lut_t();
+    scan.scan_scores = [&](float *scores, hipStream_t st) { return scan_launch(h, lut, nullptr, h->count, scores, st, nullptr, lut_t); };
     scan.scan_filter = [&](const TopkFilter &f, hipStream_t st) {
-        return scan_launch(h, lut, nullptr, h->count, nullptr, st, &f);
+        return scan_launch(h, lut, nullptr, h->count, nullptr, st, &f, lut_t);
     };
     scan.score_ids = [&](const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
         return scan_launch(h, lut, ids, n_ids, out, st);
@@ -1819,7 +2024,9 @@ void qamd_pq_encoder_abort(qamd_pq_encoder *e) {
 struct qamd_pq_query_batch {
     int device = 0;
     uint64_t m = 0, n_queries = 0;
-    DevBuf luts;  // [n_queries][m * 256] f32
+    DevBuf luts;  // [n_queries][m * 256] f32, chunk-major; `transposed`: the [code][chunk] copies follow, same order
+    bool transposed = false;
+    const float *lut_t(uint64_t q) const { return transposed ? luts.as<float>() + (n_queries + q) * m * kCentroids : nullptr; }
 };
 
 extern "C" {
@@ -1840,10 +2047,12 @@ qamd_status qamd_pq_encode_query_batch(const qamd_pq *h, const float *queries, u
         b = fresh.get();
         b->device = h->device;
     }
-    const size_t per = (size_t)h->m * kCentroids, need = std::max<size_t>(per * n_queries, 4) * sizeof(float);
+    const bool with_t = skew_capable(h);
+    const size_t per = (size_t)h->m * kCentroids, need = std::max<size_t>(per * n_queries, 4) * sizeof(float) * (with_t ? 2 : 1);
     if (b->luts.bytes < need) QAMD_TRY(b->luts.alloc(need));
     b->m = h->m;
     b->n_queries = n_queries;
+    b->transposed = with_t;
     if (per && n_queries) {
         DevBuf qtmp;
         const void *qd = nullptr;
@@ -1851,7 +2060,8 @@ qamd_status qamd_pq_encode_query_batch(const qamd_pq *h, const float *queries, u
         QAMD_TRY(local_view(queries, queries_mem, n_queries * qdim * 4, qtmp, s, &qd, &staged));
         hipLaunchKernelGGL(pq_lut_batch_kernel, dim3((uint32_t)((per + kBlock - 1) / kBlock), (uint32_t)n_queries),
                            dim3(kBlock), 0, s, static_cast<const float *>(qd), (uint32_t)h->vp.dim, (uint32_t)h->chunk_size,
-                           (uint32_t)h->m, h->centroids.as<float>(), h->vp.distance_type, h->vp.invert, b->luts.as<float>());
+                           (uint32_t)h->m, h->centroids.as<float>(), h->vp.distance_type, h->vp.invert, b->luts.as<float>(),
+                           with_t ? b->luts.as<float>() + per * n_queries : nullptr);
         QAMD_HIP(hipGetLastError());
         if (staged) QAMD_HIP(hipStreamSynchronize(s));  // qtmp is freed on return
     }
@@ -1910,7 +2120,7 @@ qamd_status qamd_pq_score_batch(const qamd_pq *h, const qamd_pq_query_batch *b, 
         out_dev = tmp.as<float>();
     }
     for (uint64_t q = 0; q < b->n_queries; q++)
-        QAMD_TRY(scan_launch(h, b->luts.as<float>() + q * per, nullptr, h->count, out_dev + q * h->count, s));
+        QAMD_TRY(scan_launch(h, b->luts.as<float>() + q * per, nullptr, h->count, out_dev + q * h->count, s, nullptr, b->lut_t(q)));
     if (out_mem == QAMD_MEM_HOST) return copy_out(out, QAMD_MEM_HOST, out_dev, b->n_queries * h->count * 4, s);
     return QAMD_OK;
 }
@@ -1926,10 +2136,10 @@ qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_batch *b, u
     BatchScan scan;
     scan.filter_capable = fast_capable(h, h->count);
     scan.scan_scores = [&](uint32_t q, float *scores, hipStream_t st) {
-        return scan_launch(h, luts + q * per, nullptr, h->count, scores, st);
+        return scan_launch(h, luts + q * per, nullptr, h->count, scores, st, nullptr, b->lut_t(q));
     };
     scan.scan_filter = [&](uint32_t q, const TopkFilter &f, hipStream_t st) {
-        return scan_launch(h, luts + q * per, nullptr, h->count, nullptr, st, &f);
+        return scan_launch(h, luts + q * per, nullptr, h->count, nullptr, st, &f, b->lut_t(q));
     };
     scan.score_ids = [&](uint32_t q, const uint32_t *ids, uint64_t n_ids, float *out, hipStream_t st) {
         return scan_launch(h, luts + q * per, ids, n_ids, out, st);

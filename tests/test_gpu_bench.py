@@ -20,7 +20,7 @@ def _last_json(out: str) -> dict:
 
 
 @pytest.mark.parametrize("extra", [[], ["--quantizer", "binary", "--dim", "1024"], ["--quantizer", "pq"],
-                                   ["--distance", "l2"]])
+                                   ["--quantizer", "pq", "--pq-chunk", "4"], ["--distance", "l2"]])
 def test_bench_single_gpu_line(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--rows-per-gpu", "300000",
            "--cpu-sample-rows", "50000"] + extra
@@ -32,10 +32,14 @@ def test_bench_single_gpu_line(extra):
         assert key in j, key
     assert j["n_gpus"] == 1 and j["steps"] == 5 and j["value"] > 0
     rf = j["roofline"]
-    assert rf["bound"] == ("lds" if "pq" in extra else "hbm") and 0 < rf["frac"] < 1.2
+    # PQ: m = 96 takes the conflict-free scan (HBM is its roofline again); m = 192 the sliced one, bound by LDS bank conflicts
+    gather_bound = "--pq-chunk" in extra
+    assert rf["bound"] == ("lds" if gather_bound else "hbm") and 0 < rf["frac"] < 1.2
     assert rf["kernel_ms_min"] <= rf["kernel_ms_median"] and rf["kernel_ms_mean"] == rf["kernel_ms"]
-    if "pq" in extra:
-        assert 0 < rf["hbm_frac"] < 1.2
+    if gather_bound:
+        assert 0 < rf["hbm_frac"] < 1.2 and rf["kernel"] == "pq_scan_fast_kernel"
+    elif "pq" in extra:
+        assert rf["kernel"] == "pq_scan_skew_kernel" and 0 < rf["lds_gather_frac_of_conflict_free_peak"] < 1.0
     if not extra:
         cb = j["cpu_baseline"]
         assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("reference", "port")

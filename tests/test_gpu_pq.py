@@ -156,3 +156,27 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
         assert_bits_equal(enc.score_all(q), want, f"m={m}")
         ids = np.array([0, n - 1, 17], dtype=np.uint32)
         assert_bits_equal(enc.score_ids(q, ids), want[ids], "ids kernel")
+
+
+@pytest.mark.parametrize("m,chunk,n", [(96, 8, 300_001), (96, 8, 4097), (64, 4, 70_003), (32, 2, 50_000), (96, 1, 6007)])
+def test_pq_skewed_scan_shapes(qo, m, chunk, n):
+    """m = 32 / 64 / 96 whole-store scans take pq_scan_skew_kernel (transposed LUT, quads skewed in time, rows through a
+    per-wave LDS ring): same bits as the oracle's score_point_sse order for row counts that are not multiples of 16, waves
+    with one block and with many, zero and negative-zero table entries, and the same top-k as the scores."""
+    dim = m * chunk
+    rng = np.random.default_rng(m * 131 + n)
+    cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)
+    cen[rng.integers(0, 256, size=40)] = 0.0  # whole zero centroids: +0.0 / -0.0 entries (invert) in every chunk table
+    rows = rng.integers(0, 256, size=(n, m), dtype=np.uint8)
+    query = (rng.random(dim, dtype=np.float32) - 0.5).astype(np.float32)
+    for dist, invert in ((D.Dot, False), (D.Dot, True), (D.L2, False)):
+        enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, dist, invert), chunk, cen)
+        lut = qo.pq_encode_query(query, chunk, cen, int(dist), invert)
+        want = qo.pq_score_all(rows, lut, order=qo.ORDER_SSE)
+        q = enc.encode_query(query)
+        assert_bits_equal(enc.score_all(q), want, f"m={m} n={n}")
+        for largest in (True, False):
+            ids, sc = enc.topk(q, 30, largest=largest)
+            order = np.lexsort((np.arange(n), -want if largest else want))[:30]
+            assert_bits_equal(sc, want[order], "top-k scores")
+            assert np.array_equal(np.sort(want[ids]), np.sort(want[order]))
