@@ -488,7 +488,7 @@ def main():
         del rows
         queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
         bytes_per_row = m
-        pq_skew = m % 32 == 0 and m <= 96 and os.environ.get("QAMD_PQ_SKEW", "1")[:1] != "0"  # csrc/pq.hip skew_capable()
+        pq_skew = m % 32 == 0 and m <= 128 and os.environ.get("QAMD_PQ_SKEW", "1")[:1] != "0"  # csrc/pq.hip skew_capable()
         kernel_name = "pq_scan_skew_kernel" if pq_skew else "pq_scan_fast_kernel"
     args.no_cpu_baseline = args.no_cpu_baseline or args.quantizer != "u8"
     scaling_field = "weak" if (world == 1 or scaling == "weak") else "strong"
@@ -681,7 +681,7 @@ def main():
             # ds_read_b32 per chunk and row, bank-conflicting by construction: DESIGN 3.3).
             lds = 4.0 * bytes_per_row * n / (kern_ms * 1e-3) / 1e9
             if pq_skew:
-                # pq_scan_skew_kernel (m = 32 / 64 / 96): transposed LUT + quads skewed in time, no bank conflicts
+                # pq_scan_skew_kernel (m = 32 / 64 / 96 / 128): transposed LUT + quads skewed in time, no bank conflicts
                 # (SQ_LDS_BANK_CONFLICT = 0): the nominal bound, HBM reads of m bytes per row, is the roofline again
                 roofline.update({"lds_gather_GBps": lds, "lds_gather_frac_of_conflict_free_peak": lds / LDS_B32_PEAK_GBPS,
                                  "note": "m code bytes per row from HBM; per chunk and row one ds_read_u8 (code), one "

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
     }
 }
 
-// The same scan with the LDS gathers free of bank conflicts (m = 32, 64 or 96; one slice).
+// The same scan with the LDS gathers free of bank conflicts (m = 32, 64, 96 or 128; one slice).
 //
 // pq_scan_fast_kernel's 32 lanes of a `ds_read_b32` group read 8 rows' independent codes out of only four chunk tables:
 // 3.5 distinct addresses per bank on average, 6.9 LDS cycles per gather against 2 (profiles/r01_pmc_bin_pq_scans.txt).
@@ -338,28 +338,31 @@ __global__ __launch_bounds__(kBlock) void pq_lut_transpose_kernel(const float *_
 
 __device__ __forceinline__ uint32_t code_address(uint32_t code, uint32_t pitch, uint32_t base) { return __umul24(code, pitch) + base; }
 
-constexpr uint32_t kSkewLdsLead = 128;  // bytes in front of the LUT: a lane's base offset 4 k - 16 r + lead is never negative
-constexpr size_t skew_lds_bytes(uint32_t m) { return kSkewLdsLead + (size_t)m * kCentroids * 4 + (kScanBlock / 64) * 32u * m; }
+// LDS: the waves' rings first (so that a lane's LUT base offset 4 k - 16 r, relative to the LUT, is never a negative
+// address), then the LUT.  m = 128 fills the CU's 160 KiB exactly with 8 waves (32 KiB of rings + 128 KiB of LUT).
+constexpr int skew_waves(uint32_t m) { return m > 96 ? 8 : 16; }
+constexpr size_t skew_lds_bytes(uint32_t m) { return (size_t)skew_waves(m) * 32u * m + (size_t)m * kCentroids * 4; }
 
 template <int NV, bool FILTER>
-__global__ __launch_bounds__(kScanBlock) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
+__global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
                                                                  const float *__restrict__ lut_t_g, uint32_t n_rows,
                                                                  float *__restrict__ out, TopkFilter filt) {
     constexpr int M = 16 * NV, S = 4 * NV;
     constexpr int D = 4;  // blocks of codes in flight per wave (registers)
     static_assert(M % 32 == 0 && S >= 8, "shape");
-    constexpr uint32_t kLut0 = kSkewLdsLead, kStage0 = kLut0 + 4u * M * kCentroids, kSlot = 16u * M;
+    constexpr int kWaves = skew_waves(M), kThreads = 64 * kWaves;
+    constexpr uint32_t kSlot = 16u * M, kStage0 = 0, kLut0 = kWaves * 2u * kSlot;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     {
         const float4 *src = reinterpret_cast<const float4 *>(lut_t_g);
         float4 *dst = reinterpret_cast<float4 *>(lds_raw + kLut0);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kScanBlock) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads) dst[i] = src[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = lane & 3, q = lane >> 2, r = 8u - (q & 7u);
-    const uint32_t gw = blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kScanBlock / 64);
+    const uint32_t gw = blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * kWaves;
     const uint32_t n_blocks = (n_rows + 15) / 16;  // blocks of 16 rows; this wave: gw, gw + n_waves, ...
     if (gw >= n_blocks) return;
     const uint32_t J = (n_blocks - gw + n_waves - 1) / n_waves;
@@ -367,14 +370,17 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_skew_kernel(const uint4 *_
     // LUT byte offset of chunk 4 (u - r) + k without the code (step u adds 16 u as an immediate); steps u < r belong to
     // the previous row (chunk group u - r + S): one table row (4 M bytes) further
     const uint32_t off_cur = kLut0 + 4u * k - 16u * r, off_new = off_cur + 4u * M;
-    // ring byte address of step u's code without 4 u: even row times have the current block in slot 0, odd ones in slot 1
-    const uint32_t rd0 = stage + q * M + k - 4u * r;
+    // ring byte address of step u's code: even row times have the current block in slot 0, odd ones in slot 1.  Steps
+    // u >= 8 (every quad in its current row): rd8 plus the immediate 4 (u - 8); steps u < 8: a register per step (a
+    // lagging quad reads the other slot).  No register holds a negative address (wave 0's ring starts at LDS byte 0).
+    const uint32_t rd8 = stage + q * M + k + 4u * (8u - r);
     uint32_t rd_even[8], rd_odd[8], lut_base[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const bool lag = (int)r > u;
-        rd_even[u] = rd0 + (lag ? kSlot + 4u * S : 0u);
-        rd_odd[u] = rd0 + (lag ? 4u * S : kSlot);
+        const uint32_t at = stage + q * M + k + (lag ? 4u * (u + S - r) : 4u * (u - r));
+        rd_even[u] = at + (lag ? kSlot : 0u);
+        rd_odd[u] = at + (lag ? 0u : kSlot);
         lut_base[u] = lag ? off_new : off_cur;
     }
     uint32_t pivot = 0;
@@ -384,9 +390,10 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_skew_kernel(const uint4 *_
     // A block is 16 M contiguous bytes: 1024 of them go as one 16-byte piece per lane, the other 512 (M = 32: the only
     // 512, M = 96: the second round) as 8 bytes per lane - every lane loads and writes in every round, so the refill has no
     // branch (a branch would cut the loop body into basic blocks, and a code byte that crosses one is masked to 8 bits again)
-    constexpr bool kWide = M >= 64, kHalf = (M % 64) != 0;
+    constexpr int kWide = 16 * M / 1024;             // rounds of 16 bytes per lane: 0 (M = 32), 1, 1, 2 (M = 128)
+    constexpr bool kHalf = (16 * M) % 1024 != 0;     // one more round of 8 bytes per lane (M = 32, 96)
     struct Held {
-        uint4 wide;
+        uint4 wide[kWide > 0 ? kWide : 1];
         uint2 half;
     };
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(gw), n_waves_u = __builtin_amdgcn_readfirstlane(n_waves);
@@ -394,17 +401,19 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_skew_kernel(const uint4 *_
     const uint8_t *rows_b = reinterpret_cast<const uint8_t *>(rows4);
     auto request = [&](Held &h, uint32_t j) {  // block j of this wave (past the end: its last block again, unused)
         const uint8_t *p = rows_b + (size_t)(wave_u + (j < J_u ? j : J_u - 1) * n_waves_u) * (16u * M);  // wave-uniform
-        if (kWide) h.wide = ld_nt(reinterpret_cast<const uint4 *>(p) + lane);
+#pragma unroll
+        for (int i = 0; i < kWide; i++) h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
         if (kHalf) {
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p + (kWide ? 1024 : 0)) + lane);
+            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p + 1024 * kWide) + lane);
             h.half = make_uint2(t.x, t.y);
         }
     };
     auto refill = [&](const Held &h, uint32_t slot) {
         uint8_t *d = lds_raw + stage + slot * kSlot;
-        if (kWide) *reinterpret_cast<uint4 *>(d + 16u * lane) = h.wide;
-        if (kHalf) *reinterpret_cast<uint2 *>(d + (kWide ? 1024u : 0u) + 8u * lane) = h.half;
+#pragma unroll
+        for (int i = 0; i < kWide; i++) *reinterpret_cast<uint4 *>(d + 1024u * i + 16u * lane) = h.wide[i];
+        if (kHalf) *reinterpret_cast<uint2 *>(d + 1024u * kWide + 8u * lane) = h.half;
     };
     Held buf[D];  // buf[j % D] = block j
 #pragma unroll
@@ -416,12 +425,14 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_skew_kernel(const uint4 *_
     // C(G - 1): add the previous group's table entries, B(G): addresses and gathers of this group - so a wave always has
     // reads in flight while it computes (left to itself the compiler emits read, wait, compute, read, wait, ...).
     constexpr int GR = S / 8, NG = D * GR;  // groups per row time; groups per trip of the loop (D row times)
-    auto ring_addr = [&](int jj, int u) { return u < 8 ? ((jj & 1) ? rd_odd[u] : rd_even[u]) : rd0 + ((jj & 1) ? kSlot : 0u); };
+    auto ring_addr = [&](int jj, int u) {  // byte address of step u's code in row time jj
+        return u < 8 ? ((jj & 1) ? rd_odd[u] : rd_even[u]) : rd8 + (uint32_t)(4 * (u - 8)) + ((jj & 1) ? kSlot : 0u);
+    };
     uint32_t codes[2][8];
     float vals[2][8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        codes[0][e] = lds_raw[ring_addr(0, e) + 4 * e];  // A(0)
+        codes[0][e] = lds_raw[ring_addr(0, e)];  // A(0)
         vals[1][e] = 0.0f;
     }
     float acc = 0.0f, done = 0.0f;
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_skew_kernel(const uint4 *_
             {  // A(G + 1)
                 const int Gn = (G + 1) % NG, jjn = Gn / GR, gn = Gn % GR;
 #pragma unroll
-                for (int e = 0; e < 8; e++) codes[(G + 1) & 1][e] = lds_raw[ring_addr(jjn, 8 * gn + e) + 4 * (8 * gn + e)];
+                for (int e = 0; e < 8; e++) codes[(G + 1) & 1][e] = lds_raw[ring_addr(jjn, 8 * gn + e)];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1057,11 +1068,11 @@ bool fast_capable(const qamd_pq *h, uint64_t n) {
 
 // One slice (at most 9 pieces: 144 chunks, 144 KiB of LUT) when the row fits, else line-sized slices (kMaxSlicePieces above).
 
-// pq_scan_skew_kernel: whole rows of 32, 64 or 96 chunks on their natural pitch (QAMD_PQ_SKEW=0: the older kernel).
+// pq_scan_skew_kernel: whole rows of 32, 64, 96 or 128 chunks on their natural pitch (QAMD_PQ_SKEW=0: the older kernel).
 bool skew_capable(const qamd_pq *h) {
     static const bool on = [] { const char *e = getenv("QAMD_PQ_SKEW"); return !(e && e[0] == '0'); }();
     // (scores leave through one buffer resource: 32-bit byte offsets)
-    return on && h->m % 32 == 0 && h->m <= 96 && h->ds == h->m && skew_lds_bytes((uint32_t)h->m) <= kLdsBudget && h->count < (1ull << 30);
+    return on && h->m % 32 == 0 && h->m <= 128 && h->ds == h->m && h->count < (1ull << 30);
 }
 
 template <bool FILTER>
@@ -1088,12 +1099,12 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         static std::atomic<uint64_t> set_on{0};                                                             \
         if (first_use_on_device(set_on))                                                                    \
             QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NVV, FILTER>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));     \
-        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER>), dim3(grid), dim3(kScanBlock), lds, s,         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NVV))); \
+        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), lds, s, \
                            h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev, filt ? *filt : TopkFilter{});    \
         break;                                                                                              \
     }
-        switch (m / 16) { QAMD_PQ_SKEW(2) QAMD_PQ_SKEW(4) QAMD_PQ_SKEW(6) }
+        switch (m / 16) { QAMD_PQ_SKEW(2) QAMD_PQ_SKEW(4) QAMD_PQ_SKEW(6) QAMD_PQ_SKEW(8) }
 #undef QAMD_PQ_SKEW
         if (ws) thread_ws_release(WS_PARTIAL, s);
         QAMD_HIP(hipGetLastError());

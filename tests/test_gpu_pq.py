@@ -158,9 +158,10 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
         assert_bits_equal(enc.score_ids(q, ids), want[ids], "ids kernel")
 
 
-@pytest.mark.parametrize("m,chunk,n", [(96, 8, 300_001), (96, 8, 4097), (64, 4, 70_003), (32, 2, 50_000), (96, 1, 6007)])
+@pytest.mark.parametrize("m,chunk,n", [(96, 8, 300_001), (96, 8, 4097), (64, 4, 70_003), (32, 2, 50_000), (96, 1, 6007),
+                                       (128, 8, 200_003), (128, 2, 4100)])
 def test_pq_skewed_scan_shapes(qo, m, chunk, n):
-    """m = 32 / 64 / 96 whole-store scans take pq_scan_skew_kernel (transposed LUT, quads skewed in time, rows through a
+    """m = 32 / 64 / 96 / 128 whole-store scans take pq_scan_skew_kernel (transposed LUT, quads skewed in time, rows through a
     per-wave LDS ring): same bits as the oracle's score_point_sse order for row counts that are not multiples of 16, waves
     with one block and with many, zero and negative-zero table entries, and the same top-k as the scores."""
     dim = m * chunk
