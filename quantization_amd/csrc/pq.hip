@@ -343,10 +343,19 @@ __device__ __forceinline__ uint32_t code_address(uint32_t code, uint32_t pitch, 
 constexpr int skew_waves(uint32_t m) { return m > 96 ? 8 : 16; }
 constexpr size_t skew_lds_bytes(uint32_t m) { return (size_t)skew_waves(m) * 32u * m + (size_t)m * kCentroids * 4; }
 
-template <int NV, bool FILTER>
+// SLICED: this launch handles chunks [chunk0, chunk0 + 16 NV) of rows of m_total chunks on a pitch of `pitch` bytes (a LUT
+// larger than the LDS: pq_scan_fast_kernel's slicing, same `partial` buffer of lane sums between the launches).  A lane's
+// sum for a row then starts from partial[row][k] instead of 0 (unless first) and goes back there (unless last).
+struct SkewSlice {
+    uint32_t pitch, chunk0, m_total;
+    int first, last;
+    float *partial;
+};
+
+template <int NV, bool FILTER, bool SLICED>
 __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
                                                                  const float *__restrict__ lut_t_g, uint32_t n_rows,
-                                                                 float *__restrict__ out, TopkFilter filt) {
+                                                                 float *__restrict__ out, TopkFilter filt, SkewSlice sl) {
     constexpr int M = 16 * NV, S = 4 * NV;
     constexpr int D = 4;  // blocks of codes in flight per wave (registers)
     static_assert(M % 32 == 0 && S >= 8, "shape");
@@ -354,9 +363,14 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     constexpr uint32_t kSlot = 16u * M, kStage0 = 0, kLut0 = kWaves * 2u * kSlot;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     {
-        const float4 *src = reinterpret_cast<const float4 *>(lut_t_g);
         float4 *dst = reinterpret_cast<float4 *>(lds_raw + kLut0);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads) dst[i] = src[i];
+        if (SLICED) {  // the slice's columns of the [code][m_total] table
+            for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads)
+                dst[i] = *reinterpret_cast<const float4 *>(lut_t_g + (size_t)(i / (M / 4)) * sl.m_total + sl.chunk0 + 4u * (i % (M / 4)));
+        } else {
+            const float4 *src = reinterpret_cast<const float4 *>(lut_t_g);
+            for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads) dst[i] = src[i];
+        }
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;
@@ -386,6 +400,8 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     uint32_t pivot = 0;
     if (FILTER) pivot = *filt.pivot_key;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, FILTER ? 0 : n_rows * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t partial_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(SLICED ? sl.partial : nullptr, 0, SLICED ? n_rows * 16u : 0, 0x00020000);
 
     // A block is 16 M contiguous bytes: 1024 of them go as one 16-byte piece per lane, the other 512 (M = 32: the only
     // 512, M = 96: the second round) as 8 bytes per lane - every lane loads and writes in every round, so the refill has no
@@ -395,19 +411,33 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     struct Held {
         uint4 wide[kWide > 0 ? kWide : 1];
         uint2 half;
+        float init;  // SLICED: the lane's sum so far for its row of the block
     };
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(gw), n_waves_u = __builtin_amdgcn_readfirstlane(n_waves);
     const uint32_t J_u = __builtin_amdgcn_readfirstlane(J);
     const uint8_t *rows_b = reinterpret_cast<const uint8_t *>(rows4);
+    const uint32_t pitch = SLICED ? sl.pitch : (uint32_t)M;
     auto request = [&](Held &h, uint32_t j) {  // block j of this wave (past the end: its last block again, unused)
-        const uint8_t *p = rows_b + (size_t)(wave_u + (j < J_u ? j : J_u - 1) * n_waves_u) * (16u * M);  // wave-uniform
+        const uint32_t blk = wave_u + (j < J_u ? j : J_u - 1) * n_waves_u;  // wave-uniform
+        const uint8_t *p = rows_b + (size_t)blk * 16u * pitch + (SLICED ? sl.chunk0 : 0u);
 #pragma unroll
-        for (int i = 0; i < kWide; i++) h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
+        for (int i = 0; i < kWide; i++) {
+            if (SLICED) {  // byte `at` of the block's ring image = byte at % M of row at / M's slice
+                const uint32_t at = 1024u * i + 16u * lane;
+                h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + (size_t)(at / M) * pitch + at % M));
+            } else {
+                h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
+            }
+        }
         if (kHalf) {
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p + 1024 * kWide) + lane);
+            const uint32_t at = 1024u * kWide + 8u * lane;
+            const u32x2 t = __builtin_nontemporal_load(
+                reinterpret_cast<const u32x2 *>(SLICED ? p + (size_t)(at / M) * pitch + at % M : p + at));
             h.half = make_uint2(t.x, t.y);
         }
+        h.init = 0.0f;
+        if (SLICED && !sl.first) h.init = sl.partial[((size_t)blk * 16u + q) * 4u + k];
     };
     auto refill = [&](const Held &h, uint32_t slot) {
         uint8_t *d = lds_raw + stage + slot * kSlot;
@@ -416,9 +446,12 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         if (kHalf) *reinterpret_cast<uint2 *>(d + 1024u * kWide + 8u * lane) = h.half;
     };
     Held buf[D];  // buf[j % D] = block j
+    float init_of[2];  // the initial sums of the blocks in the ring's slots
 #pragma unroll
     for (int j = 0; j < D; j++) request(buf[j], j);
     refill(buf[0], 0);
+    init_of[0] = buf[0].init;
+    init_of[1] = 0.0f;
     request(buf[0], D);
     // A step is two dependent LDS round trips (code byte, table entry) and an add.  Steps go in groups of eight through a
     // three-stage pipeline kept in this order by scheduling barriers - A(G + 1): ask for the next group's code bytes,
@@ -440,9 +473,11 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
 #pragma unroll
         for (int G = 0; G < NG; G++) {
             const int jj = G / GR, g = G % GR;
+            float init_new = 0.0f;
             if (g == 0) {  // the slot of block j - 1 is free (its last reads went out with A of this group): block j + 1
                            // goes there, and its registers take block j + 1 + D
                 refill(buf[(jj + 1) % D], (jj + 1) & 1);
+                init_new = buf[(jj + 1) % D].init;
                 request(buf[(jj + 1) % D], j0 + jj + 1 + D);
             }
             {  // A(G + 1)
@@ -467,7 +502,7 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
                     if (gp == 0) {  // step u = e < 8; quads r = u + 1: that was the last chunk group of their previous row
                         const bool fin = (int)r == e + 1;
                         done = fin ? acc : done;
-                        acc = fin ? 0.0f : acc;
+                        acc = fin ? (SLICED ? init_of[jjp & 1] : 0.0f) : acc;  // their row of block jp starts
                     }
                 }
                 if (gp == 0) {  // every quad's row of block jp - 1 is complete:  (l0 + l2) + (l1 + l3)  (:430-432)
@@ -475,7 +510,9 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
                     const float sc = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));
                     const uint32_t row = (gw + (jp - 1) * n_waves) * 16u + q;
                     const bool live = jp >= 1 && jp <= J && row < n_rows;
-                    if (FILTER) {
+                    if (SLICED && !sl.last) {  // the lane sums go back to `partial` for the next slice
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done), partial_rsrc, live ? (row * 4u + k) * 4u : 0xFFFFFFFFu, 0, 0);
+                    } else if (FILTER) {
                         if (k == 0 && live) topk_offer(filt, pivot, sc, row);
                     } else {
                         // all four lanes of the quad hold the same bits (f32 addition commutes): they store the same word;
@@ -485,6 +522,7 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) init_of[(jj + 1) & 1] = init_new;  // (after C: with one group per row time C still used the slot's old value)
         }
     }
 }
@@ -1069,8 +1107,18 @@ bool fast_capable(const qamd_pq *h, uint64_t n) {
 // One slice (at most 9 pieces: 144 chunks, 144 KiB of LUT) when the row fits, else line-sized slices (kMaxSlicePieces above).
 
 // pq_scan_skew_kernel: whole rows of 32, 64, 96 or 128 chunks on their natural pitch (QAMD_PQ_SKEW=0: the older kernel).
-bool skew_capable(const qamd_pq *h) {
+bool skew_enabled() {
     static const bool on = [] { const char *e = getenv("QAMD_PQ_SKEW"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// rows of several LUT slices (m > 144) with m % 32 == 0: slices of 128 chunks and a last one of 32 / 64 / 96 / 128 - all
+// shapes of pq_scan_skew_kernel<.., SLICED> (m = 192: 128 + 64; the reference bench's m = 512: four of 128)
+bool skew_sliced_capable(const qamd_pq *h) {
+    return skew_enabled() && valid_pieces(h->m) > kMaxSlicePieces && h->m % 32 == 0 && h->ds == round_up(h->m, 128) &&
+           h->count < (1ull << 28);
+}
+bool skew_capable(const qamd_pq *h) {
+    const bool on = skew_enabled();
     // (scores leave through one buffer resource: 32-bit byte offsets)
     return on && h->m % 32 == 0 && h->m <= 128 && h->ds == h->m && h->count < (1ull << 30);
 }
@@ -1098,10 +1146,10 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     case NVV: {                                                                                             \
         static std::atomic<uint64_t> set_on{0};                                                             \
         if (first_use_on_device(set_on))                                                                    \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NVV, FILTER>), \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NVV, FILTER, false>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NVV))); \
-        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), lds, s, \
-                           h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev, filt ? *filt : TopkFilter{});    \
+        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER, false>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), lds, s, \
+                           h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev, filt ? *filt : TopkFilter{}, SkewSlice{}); \
         break;                                                                                              \
     }
         switch (m / 16) { QAMD_PQ_SKEW(2) QAMD_PQ_SKEW(4) QAMD_PQ_SKEW(6) QAMD_PQ_SKEW(8) }
@@ -1115,9 +1163,27 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         const uint64_t padded = round_up(n, kRowPad) + kRowPad;
         QAMD_TRY(thread_ws_acquire(WS_PARTIAL, padded * 16, s, reinterpret_cast<void **>(&partial)));
     }
+    const bool skew_slices = n_slices > 1 && lut_t_dev && skew_sliced_capable(h);
     for (uint32_t sl = 0; sl < n_slices; sl++) {
         const uint32_t piece0 = sl * per, nvs = std::min(per, pieces - piece0);
         const int first = sl == 0, last = sl + 1 == n_slices;
+        if (skew_slices) {
+            const SkewSlice ss{(uint32_t)h->ds, piece0 * 16, m, first, last, partial};
+#define QAMD_PQ_SKEW_SLICE(NVV)                                                                              \
+    case NVV: {                                                                                             \
+        static std::atomic<uint64_t> set_on{0};                                                             \
+        if (first_use_on_device(set_on))                                                                    \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NVV, FILTER, true>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NVV))); \
+        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER, true>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
+                           skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t_dev, (uint32_t)n, out_dev,  \
+                           filt ? *filt : TopkFilter{}, ss);                                                \
+        break;                                                                                              \
+    }
+            switch (nvs) { QAMD_PQ_SKEW_SLICE(2) QAMD_PQ_SKEW_SLICE(4) QAMD_PQ_SKEW_SLICE(6) QAMD_PQ_SKEW_SLICE(8) }
+#undef QAMD_PQ_SKEW_SLICE
+            continue;
+        }
         const bool simple = n_slices == 1 && m % 16 == 0;
         const size_t lds = (size_t)std::min<uint32_t>(nvs * 16, m - piece0 * 16) * kCentroids * sizeof(float);
 #define QAMD_PQ_FAST(NVV)                                                                                   \
@@ -1658,7 +1724,7 @@ qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t 
         q->device = h->device;
     }
     const size_t n = (size_t)h->m * kCentroids;
-    const bool with_t = skew_capable(h);
+    const bool with_t = skew_capable(h) || skew_sliced_capable(h);
     if (q->m != h->m || !q->lut.ptr || q->transposed != with_t) {
         QAMD_TRY(q->lut.alloc(std::max<size_t>(n, 4) * sizeof(float) * (with_t ? 2 : 1)));
         q->m = h->m;
@@ -2058,7 +2124,7 @@ qamd_status qamd_pq_encode_query_batch(const qamd_pq *h, const float *queries, u
         b = fresh.get();
         b->device = h->device;
     }
-    const bool with_t = skew_capable(h);
+    const bool with_t = skew_capable(h) || skew_sliced_capable(h);
     const size_t per = (size_t)h->m * kCentroids, need = std::max<size_t>(per * n_queries, 4) * sizeof(float) * (with_t ? 2 : 1);
     if (b->luts.bytes < need) QAMD_TRY(b->luts.alloc(need));
     b->m = h->m;

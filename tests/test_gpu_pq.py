@@ -159,7 +159,9 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
 
 
 @pytest.mark.parametrize("m,chunk,n", [(96, 8, 300_001), (96, 8, 4097), (64, 4, 70_003), (32, 2, 50_000), (96, 1, 6007),
-                                       (128, 8, 200_003), (128, 2, 4100)])
+                                       (128, 8, 200_003), (128, 2, 4100),
+                                       # rows of several LUT slices (128-chunk slices + a last one of 64 / 32 / 96 / 128)
+                                       (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (512, 2, 20_011)])
 def test_pq_skewed_scan_shapes(qo, m, chunk, n):
     """m = 32 / 64 / 96 / 128 whole-store scans take pq_scan_skew_kernel (transposed LUT, quads skewed in time, rows through a
     per-wave LDS ring): same bits as the oracle's score_point_sse order for row counts that are not multiples of 16, waves
