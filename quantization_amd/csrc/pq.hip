@@ -469,6 +469,11 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         vals[1][e] = 0.0f;
     }
     float acc = 0.0f, done = 0.0f;
+    // All of the prologue's loads have landed before the loop starts (once per wave).  The compiler places the loop's
+    // `s_waitcnt vmcnt(n)` for the state of BOTH ways into the loop header, and it orders the prologue's loads its own way
+    // (all 8-byte rounds first): coming from there a buffer had 3 younger loads, so the loop waited with vmcnt(3) - for
+    // all but the last block asked for, one block of prefetch instead of four (measured: no overlap of loads and compute).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     for (uint32_t j0 = 0; j0 < J + 2; j0 += D) {
 #pragma unroll
         for (int G = 0; G < NG; G++) {
