@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
     }
 }
 
-// The same scan with the LDS gathers free of bank conflicts (m = 32, 64, 96 or 128; one slice).
+// The same scan with the LDS gathers free of bank conflicts: rows of 32, 64, 96 or 128 chunks, and - per slice - rows of
+// several LUT slices with m % 32 == 0 (SLICED below).  Measurements, ablations and what is still open: profiles/r03_pq_skew.txt.
 //
 // pq_scan_fast_kernel's 32 lanes of a `ds_read_b32` group read 8 rows' independent codes out of only four chunk tables:
 // 3.5 distinct addresses per bank on average, 6.9 LDS cycles per gather against 2 (profiles/r01_pmc_bin_pq_scans.txt).
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(kScanBlock) void pq_scan_fast_kernel(const uint4 *_
 // owns row q of every block, and lane (q, k) fetches its code bytes from the ring with `ds_read_u8` at 4 (u - r) + k - no
 // cross-lane moves and no bit-field extraction, two vector-ALU operations per gather (address, add).  During the first
 // r steps of a row time a quad is still finishing its row of the previous block (the ring's other slot); that slot is
-// refilled at step 8.  The ring reads are conflict-free too: rows are packed back to back (m / 4 dwords), so the eight
+// refilled right after those steps have been issued.  The ring reads are conflict-free too: rows are packed back to back (m / 4 dwords), so the eight
 // quads of a group start (m / 4 + 1) q dwords apart, an odd stride.  Result bits are those of pq_scan_fast_kernel.
 __global__ __launch_bounds__(kBlock) void pq_lut_transpose_kernel(const float *__restrict__ lut, uint32_t m,
                                                                  float *__restrict__ lut_t) {
