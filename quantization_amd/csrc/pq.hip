@@ -1113,9 +1113,30 @@ bool fast_capable(const qamd_pq *h, uint64_t n) {
 // One slice (at most 9 pieces: 144 chunks, 144 KiB of LUT) when the row fits, else line-sized slices (kMaxSlicePieces above).
 
 // pq_scan_skew_kernel: whole rows of 32, 64, 96 or 128 chunks on their natural pitch (QAMD_PQ_SKEW=0: the older kernel).
+std::atomic<bool> g_skew_unusable{false};  // a device refused the kernel's LDS size: every store goes back to pq_scan_fast_kernel
 bool skew_enabled() {
     static const bool on = [] { const char *e = getenv("QAMD_PQ_SKEW"); return !(e && e[0] == '0'); }();
-    return on;
+    return on && !g_skew_unusable.load(std::memory_order_relaxed);
+}
+// Opt in to the instance's dynamic LDS (up to the CU's whole 160 KiB) once per device; false: not available here.
+template <int NV, bool FILTER, bool SLICED> bool skew_ready() {
+    static std::atomic<uint64_t> set_on{0};
+    if (first_use_on_device(set_on) &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, FILTER, SLICED>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) != hipSuccess) {
+        (void)hipGetLastError();
+        g_skew_unusable.store(true, std::memory_order_relaxed);
+    }
+    return !g_skew_unusable.load(std::memory_order_relaxed);
+}
+template <bool FILTER, bool SLICED> bool skew_ready_for(uint32_t nv) {
+    switch (nv) {
+        case 2: return skew_ready<2, FILTER, SLICED>();
+        case 4: return skew_ready<4, FILTER, SLICED>();
+        case 6: return skew_ready<6, FILTER, SLICED>();
+        case 8: return skew_ready<8, FILTER, SLICED>();
+    }
+    return false;
 }
 // rows of several LUT slices (m > 144) with m % 32 == 0: slices of 128 chunks and a last one of 32 / 64 / 96 / 128 - all
 // shapes of pq_scan_skew_kernel<.., SLICED> (m = 192: 128 + 64; the reference bench's m = 512: four of 128)
@@ -1137,7 +1158,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     const uint32_t n_slices = (pieces + per - 1) / per;
     const uint64_t n = h->count;
     const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
-    if (skew_capable(h)) {
+    if (skew_capable(h) && skew_ready_for<FILTER, false>(m / 16)) {
         // the LUT as [code][chunk]: encode_query leaves that copy behind the chunk-major one; a caller without it pays a
         // transposing launch (96 KiB, L2-resident)
         const float *lut_t = lut_t_dev;
@@ -1150,10 +1171,6 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         const size_t lds = skew_lds_bytes(m);
 #define QAMD_PQ_SKEW(NVV)                                                                                    \
     case NVV: {                                                                                             \
-        static std::atomic<uint64_t> set_on{0};                                                             \
-        if (first_use_on_device(set_on))                                                                    \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NVV, FILTER, false>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NVV))); \
         hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER, false>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), lds, s, \
                            h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev, filt ? *filt : TopkFilter{}, SkewSlice{}); \
         break;                                                                                              \
@@ -1169,7 +1186,8 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         const uint64_t padded = round_up(n, kRowPad) + kRowPad;
         QAMD_TRY(thread_ws_acquire(WS_PARTIAL, padded * 16, s, reinterpret_cast<void **>(&partial)));
     }
-    const bool skew_slices = n_slices > 1 && lut_t_dev && skew_sliced_capable(h);
+    bool skew_slices = n_slices > 1 && lut_t_dev && skew_sliced_capable(h);
+    for (uint32_t sl = 0; skew_slices && sl < n_slices; sl++) skew_slices = skew_ready_for<FILTER, true>(std::min(per, pieces - sl * per));
     for (uint32_t sl = 0; sl < n_slices; sl++) {
         const uint32_t piece0 = sl * per, nvs = std::min(per, pieces - piece0);
         const int first = sl == 0, last = sl + 1 == n_slices;
@@ -1177,10 +1195,6 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             const SkewSlice ss{(uint32_t)h->ds, piece0 * 16, m, first, last, partial};
 #define QAMD_PQ_SKEW_SLICE(NVV)                                                                              \
     case NVV: {                                                                                             \
-        static std::atomic<uint64_t> set_on{0};                                                             \
-        if (first_use_on_device(set_on))                                                                    \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NVV, FILTER, true>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NVV))); \
         hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER, true>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
                            skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t_dev, (uint32_t)n, out_dev,  \
                            filt ? *filt : TopkFilter{}, ss);                                                \
