@@ -391,7 +391,8 @@ QAMD_API qamd_status qamd_pq_get_centroids(const qamd_pq *h, float *centroids);
 QAMD_API qamd_status qamd_pq_save(const qamd_pq *h, const char *data_path, const char *meta_path);
 QAMD_API qamd_status qamd_pq_load(const char *data_path, const char *meta_path,
                                   const qamd_vector_parameters *vp, qamd_pq **out);
-/* encode_query (:525-547): builds the chunk-major LUT. */
+/* encode_query (:525-547): builds the chunk-major LUT (what qamd_pq_query_read returns: EncodedQueryPQ.lut).  For stores
+ * whose whole-store scan runs without LDS bank conflicts (m % 32 == 0) the object also keeps a [code][chunk] copy. */
 QAMD_API qamd_status qamd_pq_encode_query(const qamd_pq *h, const float *query, uint64_t qdim,
                                           qamd_mem query_mem, void *stream,
                                           qamd_pq_query **query_io);
