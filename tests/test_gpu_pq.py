@@ -183,3 +183,39 @@ def test_pq_skewed_scan_shapes(qo, m, chunk, n):
             order = np.lexsort((np.arange(n), -want if largest else want))[:30]
             assert_bits_equal(sc, want[order], "top-k scores")
             assert np.array_equal(np.sort(want[ids]), np.sort(want[order]))
+
+
+def test_pq_skewed_and_older_scan_kernels_give_the_same_bits():
+    """The same stores scanned by pq_scan_skew_kernel (default) and by pq_scan_fast_kernel (QAMD_PQ_SKEW=0, read once per
+    process): identical score bits and identical top-k for whole rows (m = 64, 96, 128) and sliced rows (m = 192, 288)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import quantization_amd as qa
+D = qa.DistanceType
+h = hashlib.sha256()
+for m, chunk, n in ((64, 2, 9000), (96, 8, 50001), (128, 4, 30007), (192, 4, 20011), (288, 1, 7001)):
+    rng = np.random.default_rng(m)
+    dim = m * chunk
+    cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)
+    rows = rng.integers(0, 256, size=(n, m), dtype=np.uint8)
+    enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, D.L2, True), chunk, cen)
+    q = enc.encode_query((rng.random(dim, dtype=np.float32) - 0.5).astype(np.float32))
+    h.update(np.asarray(enc.score_all(q)).tobytes())
+    ids, sc = enc.topk(q, 50, largest=False)
+    h.update(np.asarray(ids).tobytes()); h.update(np.asarray(sc).tobytes())
+print("DIGEST", h.hexdigest())
+""" % root
+    digests = []
+    for skew in ("1", "0"):
+        env = dict(os.environ, QAMD_PQ_SKEW=skew)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        digests.append([ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
