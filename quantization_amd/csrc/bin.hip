@@ -1558,10 +1558,7 @@ qamd_status launch_bin_gemm(const qamd_bin *h, const qamd_bin_query_batch *b, co
     const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
 #define QAMD_BIN_GEMM(M_, LOW_, MI_)                                                                                        \
     do {                                                                                                                   \
-        static std::atomic<uint64_t> set_on{0};                                                                            \
-        if (first_use_on_device(set_on))                                                                                   \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gemm_rs_kernel<M_, LOW_, MI_>),               \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+        QAMD_LDS_OPT_IN((&bin_gemm_rs_kernel<M_, LOW_, MI_>), 160 * 1024); \
         hipLaunchKernelGGL((bin_gemm_rs_kernel<M_, LOW_, MI_>), dim3(grid), dim3(512), lds, s, rows, (uint32_t)h->ds,      \
                            b->bits.as<uint8_t>(), (uint32_t)b->q_stride, (float)h->vp.dim, zx ? 1 : 0, (uint32_t)n_rows,   \
                            (uint32_t)b->n_queries, q0, out, out_pitch, filt);                                              \
@@ -1619,7 +1616,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
         }
     }
     // rows of 512 / 1024 / 2048 bits, enough queries: the FP4 query-streaming form (QAMD_BIN4=0 / QAMD_BIN4_MIN: developer A/B)
-    static const char *e4 = getenv("QAMD_BIN4"), *e4min = getenv("QAMD_BIN4_MIN");
+    static const char *e4 = dev_env("QAMD_BIN4"), *e4min = dev_env("QAMD_BIN4_MIN");
     const bool qs4 = (h->ds == 64 || h->ds == 96 || h->ds == 128 || h->ds == 192) && !(e4 && e4[0] == '0') &&
                      Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries);
     const uint32_t n_lists = pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
@@ -1693,10 +1690,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
             fs.wave_base = (uint32_t)(q_base / kQs4Slice) * pp_waves_per_launch();
 #define QAMD_QS4_JT(M_, LOW_, IT_, JT_)                                                                                     \
     do {                                                                                                                   \
-        static std::atomic<uint64_t> set_on{0};                                                                            \
-        if (first_use_on_device(set_on))                                                                                   \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_gemm_qs4_kernel<M_, LOW_, IT_, JT_>),         \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+        QAMD_LDS_OPT_IN((&bin_gemm_qs4_kernel<M_, LOW_, IT_, JT_>), 160 * 1024); \
         hipLaunchKernelGGL((bin_gemm_qs4_kernel<M_, LOW_, IT_, JT_>), dim3(grid), dim3(512), lds, s, h->rows.as<uint8_t>(), \
                            (uint32_t)h->ds, frag + (q_base / 16) * nsteps * 64, q_off + q_base, bq + q_base, zx ? 1 : 0,   \
                            (uint32_t)n, nq, fs);                                                                           \

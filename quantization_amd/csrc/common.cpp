@@ -65,15 +65,6 @@ DeviceGuard::~DeviceGuard() {
     if (switched_) (void)hipSetDevice(prev_);
 }
 
-bool first_use_on_device(std::atomic<uint64_t> &mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    const uint64_t bit = 1ull << dev;
-    if (mask.load(std::memory_order_acquire) & bit) return false;
-    mask.fetch_or(bit, std::memory_order_acq_rel);
-    return true;
-}
-
 qamd_status DevBuf::alloc(size_t n, bool zero) {
     release();
     if (n == 0) n = 16;  // keep a valid pointer for empty stores

@@ -5,8 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdarg>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -59,10 +61,51 @@ class DeviceGuard {
     ::qamd::DeviceGuard _qamd_dev_guard(dev); \
     QAMD_TRY(_qamd_dev_guard.status())
 
-// True the first time it is called with this mask on the CURRENT device (per-device one-time
-// set-up such as hipFuncSetAttribute, which is a per-device property).  Benign when two threads
-// race: the set-up then runs twice.
-bool first_use_on_device(std::atomic<uint64_t> &mask);
+// Developer A/B switches (which kernel serves a call; results never differ) are read from the environment ONLY by the
+// tools/lib build (-DQAMD_DEV): the product library ignores them, so a stray variable cannot change which kernel serves
+// production queries.  (QAMD_SHARD_LANES, a documented deployment knob of the sharded handle, is not one of these.)
+inline const char *dev_env(const char *name) {
+#ifdef QAMD_DEV
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+// One-time set-up per (call site, device) - hipFuncSetAttribute is a per-device property, and its first call also loads
+// the code object.  Two-phase: the device's bit is published only AFTER the set-up has succeeded; first callers that
+// arrive together are serialised (one runs the set-up, the others wait for it and then see the bit), so no thread can
+// launch with 128-160 KiB of dynamic LDS before the attribute is applied; a failed set-up leaves the bit clear and is
+// retried by the next call.  run() returns the set-up's status (QAMD_OK when it had been done before).
+class DeviceOnce {
+  public:
+    template <class F> qamd_status run(F &&setup) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return setup();  // (idempotent: repeat it every time)
+        const uint64_t bit = 1ull << dev;
+        if (done_.load(std::memory_order_acquire) & bit) return QAMD_OK;
+        std::lock_guard<std::mutex> g(mu_);
+        if (done_.load(std::memory_order_relaxed) & bit) return QAMD_OK;
+        const qamd_status st = setup();
+        if (st == QAMD_OK) done_.fetch_or(bit, std::memory_order_release);
+        return st;
+    }
+
+  private:
+    std::atomic<uint64_t> done_{0};
+    std::mutex mu_;
+};
+// Raises a kernel's dynamic-LDS limit once per device: QAMD_LDS_OPT_IN((&kernel<...>), bytes);
+#define QAMD_LDS_OPT_IN(kernel, bytes)                                                                            \
+    do {                                                                                                          \
+        static ::qamd::DeviceOnce _qamd_once;                                                                     \
+        QAMD_TRY(_qamd_once.run([]() -> qamd_status {                                                             \
+            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),                                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));              \
+            return QAMD_OK;                                                                                       \
+        }));                                                                                                      \
+    } while (0)
 
 // Owning device allocation.
 struct DevBuf {

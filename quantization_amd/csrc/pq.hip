@@ -344,22 +344,33 @@ __device__ __forceinline__ uint32_t code_address(uint32_t code, uint32_t pitch, 
 constexpr int skew_waves(uint32_t m) { return m > 96 ? 8 : 16; }
 constexpr size_t skew_lds_bytes(uint32_t m) { return (size_t)skew_waves(m) * 32u * m + (size_t)m * kCentroids * 4; }
 
-// SLICED: this launch handles chunks [chunk0, chunk0 + 16 NV) of rows of m_total chunks on a pitch of `pitch` bytes (a LUT
-// larger than the LDS: pq_scan_fast_kernel's slicing, same `partial` buffer of lane sums between the launches).  A lane's
-// sum for a row then starts from partial[row][k] instead of 0 (unless first) and goes back there (unless last).
+// SLICED: this launch handles chunks [chunk0, chunk0 + 16 NV) of rows of m_total chunks (a LUT larger than the LDS).  The
+// store keeps such rows a second time as a PLANAR scan image (qamd_pq::planar): slice after slice, each a contiguous
+// [rows][16 NV] byte array, so a slice launch reads exactly its own bytes, whole 128-byte lines, at the pace of a store
+// whose rows ARE that slice (round 3 read them out of row-major rows on a 256-byte pitch: 1.33 x the bytes at m = 192).
+// `rows4` is the slice's array.  A lane's sum for a row starts from partial[row][k] instead of 0 (unless first) and goes
+// back there (unless last): the reference's SSE lane sum (:405-440), its order unchanged, parked between two launches.
 struct SkewSlice {
-    uint32_t pitch, chunk0, m_total;
+    uint32_t chunk0, m_total;
     int first, last;
     float *partial;
 };
 
-template <int NV, bool FILTER, bool SLICED>
+// R > 1: a ring row is R consecutive store rows (M = R m bytes, m % 4 == 0, m / 4 >= 8) and the LUT's columns repeat R
+// times in LDS.  That is the conflict-free scan for rows whose length is not a multiple of 32 chunks: the eight quads of a
+// lane group sit at eight consecutive chunk groups of their byte stream, and the banks those hit are distinct only if the
+// stream's period in chunk groups is a multiple of 8 - R m / 4 is, m / 4 need not be (m = 48: R = 2, the m = 96 shape).  A
+// quad then finishes a store row every m / 4 steps instead of every M / 4.  Per row nothing changes: lane k adds chunks
+// k, k + 4, ... of ITS row in order, (l0 + l2) + (l1 + l3).
+template <int NV, int R, bool FILTER, bool SLICED>
 __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
                                                                  const float *__restrict__ lut_t_g, uint32_t n_rows,
                                                                  float *__restrict__ out, TopkFilter filt, SkewSlice sl) {
     constexpr int M = 16 * NV, S = 4 * NV;
+    constexpr int MR = M / R, SR = S / R;  // chunks / chunk groups of one store row
     constexpr int D = 4;  // blocks of codes in flight per wave (registers)
     static_assert(M % 32 == 0 && S >= 8, "shape");
+    static_assert(M % R == 0 && MR % 4 == 0 && SR >= 8 && (R == 1 || !SLICED), "rows per ring row");
     constexpr int kWaves = skew_waves(M), kThreads = 64 * kWaves;
     constexpr uint32_t kSlot = 16u * M, kStage0 = 0, kLut0 = kWaves * 2u * kSlot;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -368,6 +379,9 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         if (SLICED) {  // the slice's columns of the [code][m_total] table
             for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads)
                 dst[i] = *reinterpret_cast<const float4 *>(lut_t_g + (size_t)(i / (M / 4)) * sl.m_total + sl.chunk0 + 4u * (i % (M / 4)));
+        } else if (R > 1) {  // [code][MR] in memory, every row of it R times in LDS
+            for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads)
+                dst[i] = *reinterpret_cast<const float4 *>(lut_t_g + (size_t)(i / (M / 4)) * MR + 4u * ((i % (M / 4)) % (MR / 4)));
         } else {
             const float4 *src = reinterpret_cast<const float4 *>(lut_t_g);
             for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads) dst[i] = src[i];
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     const uint32_t k = lane & 3, q = lane >> 2, r = 8u - (q & 7u);
     const uint32_t gw = blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWaves;
-    const uint32_t n_blocks = (n_rows + 15) / 16;  // blocks of 16 rows; this wave: gw, gw + n_waves, ...
+    const uint32_t n_blocks = ((n_rows + R - 1) / R + 15) / 16;  // blocks of 16 ring rows; this wave: gw, gw + n_waves, ...
     if (gw >= n_blocks) return;
     const uint32_t J = (n_blocks - gw + n_waves - 1) / n_waves;
     const uint32_t stage = kStage0 + (threadIdx.x >> 6) * 2u * kSlot;
@@ -417,24 +431,14 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(gw), n_waves_u = __builtin_amdgcn_readfirstlane(n_waves);
     const uint32_t J_u = __builtin_amdgcn_readfirstlane(J);
     const uint8_t *rows_b = reinterpret_cast<const uint8_t *>(rows4);
-    const uint32_t pitch = SLICED ? sl.pitch : (uint32_t)M;
     auto request = [&](Held &h, uint32_t j) {  // block j of this wave (past the end: its last block again, unused)
         const uint32_t blk = wave_u + (j < J_u ? j : J_u - 1) * n_waves_u;  // wave-uniform
-        const uint8_t *p = rows_b + (size_t)blk * 16u * pitch + (SLICED ? sl.chunk0 : 0u);
+        const uint8_t *p = rows_b + (size_t)blk * 16u * M;  // (SLICED: `rows4` is the slice's own [rows][M] array)
 #pragma unroll
-        for (int i = 0; i < kWide; i++) {
-            if (SLICED) {  // byte `at` of the block's ring image = byte at % M of row at / M's slice
-                const uint32_t at = 1024u * i + 16u * lane;
-                h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + (size_t)(at / M) * pitch + at % M));
-            } else {
-                h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
-            }
-        }
+        for (int i = 0; i < kWide; i++) h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
         if (kHalf) {
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const uint32_t at = 1024u * kWide + 8u * lane;
-            const u32x2 t = __builtin_nontemporal_load(
-                reinterpret_cast<const u32x2 *>(SLICED ? p + (size_t)(at / M) * pitch + at % M : p + at));
+            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p + 1024u * kWide + 8u * lane));
             h.half = make_uint2(t.x, t.y);
         }
         h.init = 0.0f;
@@ -505,25 +509,28 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     acc += vals[(G + 1) & 1][e];
-                    if (gp == 0) {  // step u = e < 8; quads r = u + 1: that was the last chunk group of their previous row
-                        const bool fin = (int)r == e + 1;
+                    const int u = 8 * gp + e, w = u % SR, sub = u / SR;  // step w of store row `sub` for a quad without lag
+                    if (w < 8) {  // quads r = w + 1: that was the last chunk group of their previous store row
+                        const bool fin = (int)r == w + 1;
                         done = fin ? acc : done;
-                        acc = fin ? (SLICED ? init_of[jjp & 1] : 0.0f) : acc;  // their row of block jp starts
+                        acc = fin ? (SLICED ? init_of[jjp & 1] : 0.0f) : acc;  // their next store row starts
                     }
-                }
-                if (gp == 0) {  // every quad's row of block jp - 1 is complete:  (l0 + l2) + (l1 + l3)  (:430-432)
-                    const float a = done + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(done), 0x4E, 0xF, 0xF, false));
-                    const float sc = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));
-                    const uint32_t row = (gw + (jp - 1) * n_waves) * 16u + q;
-                    const bool live = jp >= 1 && jp <= J && row < n_rows;
-                    if (SLICED && !sl.last) {  // the lane sums go back to `partial` for the next slice
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done), partial_rsrc, live ? (row * 4u + k) * 4u : 0xFFFFFFFFu, 0, 0);
-                    } else if (FILTER) {
-                        if (k == 0 && live) topk_offer(filt, pivot, sc, row);
-                    } else {
-                        // all four lanes of the quad hold the same bits (f32 addition commutes): they store the same word;
-                        // a buffer store drops the lanes whose offset is out of range, so there is no branch here either
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), out_rsrc, live ? row * 4u : 0xFFFFFFFFu, 0, 0);
+                    if (w == 7) {  // every quad's previous store row is complete:  (l0 + l2) + (l1 + l3)  (:430-432)
+                        const float a = done + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(done), 0x4E, 0xF, 0xF, false));
+                        const float sc = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));
+                        // sub == 0: the last store row of the ring row of block jp - 1; else store row sub - 1 of block jp's
+                        const uint32_t jb = sub == 0 ? jp - 1u : jp;
+                        const uint32_t row = ((gw + jb * n_waves) * 16u + q) * (uint32_t)R + (uint32_t)(sub == 0 ? R - 1 : sub - 1);
+                        const bool live = jb < J && row < n_rows;  // (jb = -1, -2 as unsigned: the pipeline's first trips)
+                        if (SLICED && !sl.last) {  // the lane sums go back to `partial` for the next slice
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done), partial_rsrc, live ? (row * 4u + k) * 4u : 0xFFFFFFFFu, 0, 0);
+                        } else if (FILTER) {
+                            if (k == 0 && live) topk_offer(filt, pivot, sc, row);
+                        } else {
+                            // all four lanes of the quad hold the same bits (f32 addition commutes): they store the same word;
+                            // a buffer store drops the lanes whose offset is out of range, so there is no branch here either
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), out_rsrc, live ? row * 4u : 0xFFFFFFFFu, 0, 0);
+                        }
                     }
                 }
             }
@@ -1077,6 +1084,12 @@ struct qamd_pq {
     uint32_t kmeans_iterations = 0;     // iterations the slowest chunk took (0: centroids were given)
     uint32_t kmeans_empty_clusters = 0; // clusters re-seeded over all iterations (kmeans.rs:111-118)
     DevBuf rows;                        // [padded][ds]
+    // Rows of several LUT slices (m > 144) with m % 32 == 0: the scan image - slice after slice, each a contiguous
+    // [padded][chunks of the slice] array (slice i starts at byte slice_chunk0[i] * padded) - that pq_scan_skew_kernel<SLICED>
+    // reads; `rows` stays the random-access image (score_ids, bursts, score_internal, export).
+    DevBuf planar;
+    std::vector<uint32_t> slice_chunk0, slice_chunks;
+    uint64_t padded = 0;
 };
 
 struct qamd_pq_query {
@@ -1090,13 +1103,54 @@ struct qamd_pq_query {
 
 namespace {
 
+// LUT slices of the planar scan image: 96 chunks where that tiles the row in at most three (m = 192, 288: every launch with
+// 16 waves per CU), else 128-chunk slices and a last one of 32 / 64 / 96 / 128 (the reference bench's m = 512: four of 128).
+void plan_slices(uint64_t m, std::vector<uint32_t> &chunk0, std::vector<uint32_t> &chunks) {
+    chunk0.clear();
+    chunks.clear();
+    if (valid_pieces(m) <= kMaxSlicePieces || m % 32 != 0) return;
+    const uint32_t per = (m % 96 == 0 && m <= 288) ? 96u : 128u;
+    for (uint32_t c = 0; c < m; c += per) {
+        chunk0.push_back(c);
+        chunks.push_back(std::min<uint32_t>(per, (uint32_t)m - c));
+    }
+}
+
 qamd_status alloc_store(qamd_pq *h) {
     h->m = chunks_of(h->vp.dim, h->chunk_size);
-    // rows of 16-byte pieces (the scan's load unit); tiny rows keep whole dwords
+    plan_slices(h->m, h->slice_chunk0, h->slice_chunks);
+    if (h->count >= (1ull << 28)) h->slice_chunks.clear();  // (the partial sums leave through 32-bit buffer offsets)
+    const bool planar = !h->slice_chunks.empty();
+    // rows of 16-byte pieces (the scan's load unit); tiny rows keep whole dwords; rows that pq_scan_fast_kernel scans in
+    // slices (m > 144, not a multiple of 32) sit on a 128-byte pitch so that a slice launch reads whole lines
     h->ds = h->m < 16 ? round_up(std::max<uint64_t>(h->m, 1), 4)
-          : valid_pieces(h->m) > kMaxSlicePieces ? round_up(h->m, 16 * kSlicePiecesAligned) : round_up(h->m, 16);
-    const uint64_t padded = round_up(h->count, kRowPad) + kRowPad;
-    return h->rows.alloc(padded * h->ds, true);
+          : (valid_pieces(h->m) > kMaxSlicePieces && !planar) ? round_up(h->m, 16 * kSlicePiecesAligned) : round_up(h->m, 16);
+    h->padded = round_up(h->count, kRowPad) + kRowPad;
+    if (planar) QAMD_TRY(h->planar.alloc(h->padded * h->m, true));
+    return h->rows.alloc(h->padded * h->ds, true);
+}
+
+// rows [r0, r0 + nr) of the row-major image -> the planar scan image (16-byte pieces; m % 32 == 0 there)
+__global__ __launch_bounds__(kBlock) void pq_planar_kernel(const uint4 *__restrict__ rows4, uint32_t row_pieces, uint64_t r0,
+                                                          uint64_t nr, uint4 *__restrict__ planar4, uint64_t padded,
+                                                          uint32_t piece0, uint32_t slice_pieces) {
+    const uint64_t total = nr * slice_pieces;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t r = r0 + i / slice_pieces;
+        const uint32_t pc = (uint32_t)(i % slice_pieces);
+        planar4[(uint64_t)piece0 * padded + r * slice_pieces + pc] = rows4[r * row_pieces + piece0 + pc];
+    }
+}
+
+qamd_status build_planar(qamd_pq *h, uint64_t r0, uint64_t nr, hipStream_t s) {
+    if (!h->planar.ptr || nr == 0) return QAMD_OK;
+    for (size_t i = 0; i < h->slice_chunks.size(); i++) {
+        const uint32_t pieces = h->slice_chunks[i] / 16;
+        hipLaunchKernelGGL(pq_planar_kernel, dim3(grid_for(nr * pieces, kBlock * 4, 8)), dim3(kBlock), 0, s, h->rows.as<uint4>(),
+                           (uint32_t)(h->ds / 16), r0, nr, h->planar.as<uint4>(), h->padded, h->slice_chunk0[i] / 16, pieces);
+    }
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
 }
 
 qamd_status set_centroids(qamd_pq *h, const float *centroids_host, hipStream_t s) {
@@ -1112,43 +1166,45 @@ bool fast_capable(const qamd_pq *h, uint64_t n) {
 
 // One slice (at most 9 pieces: 144 chunks, 144 KiB of LUT) when the row fits, else line-sized slices (kMaxSlicePieces above).
 
-// pq_scan_skew_kernel: whole rows of 32, 64, 96 or 128 chunks on their natural pitch (QAMD_PQ_SKEW=0: the older kernel).
+// pq_scan_skew_kernel: whole rows of 32, 64, 96 or 128 chunks, and of 48 (two rows per ring row), on their natural pitch.
 std::atomic<bool> g_skew_unusable{false};  // a device refused the kernel's LDS size: every store goes back to pq_scan_fast_kernel
 bool skew_enabled() {
-    static const bool on = [] { const char *e = getenv("QAMD_PQ_SKEW"); return !(e && e[0] == '0'); }();
-    return on && !g_skew_unusable.load(std::memory_order_relaxed);
+    static const bool on = [] { const char *e = dev_env("QAMD_PQ_SKEW"); return !(e && e[0] == '0'); }();  // developer A/B (tools/lib build): 0 = the older kernel
+    if (!on) return false;
+    return !g_skew_unusable.load(std::memory_order_relaxed);
 }
 // Opt in to the instance's dynamic LDS (up to the CU's whole 160 KiB) once per device; false: not available here.
-template <int NV, bool FILTER, bool SLICED> bool skew_ready() {
-    static std::atomic<uint64_t> set_on{0};
-    if (first_use_on_device(set_on) &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, FILTER, SLICED>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) != hipSuccess) {
-        (void)hipGetLastError();
-        g_skew_unusable.store(true, std::memory_order_relaxed);
-    }
-    return !g_skew_unusable.load(std::memory_order_relaxed);
+template <int NV, int R, bool FILTER, bool SLICED> bool skew_ready() {
+    static DeviceOnce once;
+    const qamd_status st = once.run([] {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) != hipSuccess) {
+            (void)hipGetLastError();
+            g_skew_unusable.store(true, std::memory_order_relaxed);  // (a refusal is final: the set-up counts as done)
+        }
+        return QAMD_OK;
+    });
+    return st == QAMD_OK && !g_skew_unusable.load(std::memory_order_relaxed);
 }
 template <bool FILTER, bool SLICED> bool skew_ready_for(uint32_t nv) {
     switch (nv) {
-        case 2: return skew_ready<2, FILTER, SLICED>();
-        case 4: return skew_ready<4, FILTER, SLICED>();
-        case 6: return skew_ready<6, FILTER, SLICED>();
-        case 8: return skew_ready<8, FILTER, SLICED>();
+        case 2: return skew_ready<2, 1, FILTER, SLICED>();
+        case 4: return skew_ready<4, 1, FILTER, SLICED>();
+        case 6: return skew_ready<6, 1, FILTER, SLICED>();
+        case 8: return skew_ready<8, 1, FILTER, SLICED>();
     }
     return false;
 }
-// rows of several LUT slices (m > 144) with m % 32 == 0: slices of 128 chunks and a last one of 32 / 64 / 96 / 128 - all
-// shapes of pq_scan_skew_kernel<.., SLICED> (m = 192: 128 + 64; the reference bench's m = 512: four of 128)
-bool skew_sliced_capable(const qamd_pq *h) {
-    return skew_enabled() && valid_pieces(h->m) > kMaxSlicePieces && h->m % 32 == 0 && h->ds == round_up(h->m, 128) &&
-           h->count < (1ull << 28);
-}
-bool skew_capable(const qamd_pq *h) {
-    const bool on = skew_enabled();
+// rows of several LUT slices with m % 32 == 0: the store holds a planar scan image (alloc_store)
+bool skew_sliced_capable(const qamd_pq *h) { return skew_enabled() && h->planar.ptr != nullptr; }
+// store rows per ring row: 1 for m = 32 / 64 / 96 / 128, 2 for m = 48; 0: not a shape of the kernel
+uint32_t skew_rows_per_ring_row(const qamd_pq *h) {
     // (scores leave through one buffer resource: 32-bit byte offsets)
-    return on && h->m % 32 == 0 && h->m <= 128 && h->ds == h->m && h->count < (1ull << 30);
+    if (!skew_enabled() || h->ds != h->m || h->count >= (1ull << 30)) return 0;
+    if (h->m % 32 == 0 && h->m <= 128) return 1;
+    return h->m == 48 ? 2 : 0;
 }
+bool skew_capable(const qamd_pq *h) { return skew_rows_per_ring_row(h) != 0; }
 
 template <bool FILTER>
 qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, const TopkFilter *filt,
@@ -1158,7 +1214,8 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     const uint32_t n_slices = (pieces + per - 1) / per;
     const uint64_t n = h->count;
     const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
-    if (skew_capable(h) && skew_ready_for<FILTER, false>(m / 16)) {
+    const uint32_t ring_rows = skew_rows_per_ring_row(h);
+    if (ring_rows == 2 ? skew_ready<6, 2, FILTER, false>() : ring_rows == 1 && skew_ready_for<FILTER, false>(m / 16)) {
         // the LUT as [code][chunk]: encode_query leaves that copy behind the chunk-major one; a caller without it pays a
         // transposing launch (96 KiB, L2-resident)
         const float *lut_t = lut_t_dev;
@@ -1168,53 +1225,60 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             hipLaunchKernelGGL(pq_lut_transpose_kernel, dim3((m * kCentroids + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lut_dev, m, ws);
             lut_t = ws;
         }
-        const size_t lds = skew_lds_bytes(m);
-#define QAMD_PQ_SKEW(NVV)                                                                                    \
-    case NVV: {                                                                                             \
-        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER, false>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), lds, s, \
-                           h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev, filt ? *filt : TopkFilter{}, SkewSlice{}); \
-        break;                                                                                              \
-    }
-        switch (m / 16) { QAMD_PQ_SKEW(2) QAMD_PQ_SKEW(4) QAMD_PQ_SKEW(6) QAMD_PQ_SKEW(8) }
+#define QAMD_PQ_SKEW(NVV, RR)                                                                                \
+    hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
+                       skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev,         \
+                       filt ? *filt : TopkFilter{}, SkewSlice{})
+        if (ring_rows == 2) QAMD_PQ_SKEW(6, 2);
+        else switch (m / 16) {
+            case 2: QAMD_PQ_SKEW(2, 1); break;
+            case 4: QAMD_PQ_SKEW(4, 1); break;
+            case 6: QAMD_PQ_SKEW(6, 1); break;
+            case 8: QAMD_PQ_SKEW(8, 1); break;
+        }
 #undef QAMD_PQ_SKEW
         if (ws) thread_ws_release(WS_PARTIAL, s);
         QAMD_HIP(hipGetLastError());
         return QAMD_OK;
+    }
+    if (lut_t_dev && skew_sliced_capable(h)) {  // rows of several LUT slices: one launch per slice of the planar scan image
+        bool ready = true;
+        for (uint32_t c : h->slice_chunks) ready = ready && skew_ready_for<FILTER, true>(c / 16);
+        if (ready) {
+            float *partial = nullptr;
+            QAMD_TRY(thread_ws_acquire(WS_PARTIAL, h->padded * 16, s, reinterpret_cast<void **>(&partial)));
+            const size_t ns = h->slice_chunks.size();
+            for (size_t sl = 0; sl < ns; sl++) {
+                const SkewSlice ss{h->slice_chunk0[sl], m, sl == 0, sl + 1 == ns, partial};
+                const uint4 *slice = reinterpret_cast<const uint4 *>(h->planar.as<uint8_t>() + (uint64_t)h->slice_chunk0[sl] * h->padded);
+#define QAMD_PQ_SKEW_SLICE(NVV)                                                                              \
+    case NVV:                                                                                               \
+        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, 1, FILTER, true>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
+                           skew_lds_bytes(16 * NVV), s, slice, lut_t_dev, (uint32_t)n, out_dev,              \
+                           filt ? *filt : TopkFilter{}, ss);                                                \
+        break;
+                switch (h->slice_chunks[sl] / 16) { QAMD_PQ_SKEW_SLICE(2) QAMD_PQ_SKEW_SLICE(4) QAMD_PQ_SKEW_SLICE(6) QAMD_PQ_SKEW_SLICE(8) }
+#undef QAMD_PQ_SKEW_SLICE
+            }
+            thread_ws_release(WS_PARTIAL, s);
+            QAMD_HIP(hipGetLastError());
+            return QAMD_OK;
+        }
     }
     float *partial = nullptr;
     if (n_slices > 1) {
         const uint64_t padded = round_up(n, kRowPad) + kRowPad;
         QAMD_TRY(thread_ws_acquire(WS_PARTIAL, padded * 16, s, reinterpret_cast<void **>(&partial)));
     }
-    bool skew_slices = n_slices > 1 && lut_t_dev && skew_sliced_capable(h);
-    for (uint32_t sl = 0; skew_slices && sl < n_slices; sl++) skew_slices = skew_ready_for<FILTER, true>(std::min(per, pieces - sl * per));
     for (uint32_t sl = 0; sl < n_slices; sl++) {
         const uint32_t piece0 = sl * per, nvs = std::min(per, pieces - piece0);
         const int first = sl == 0, last = sl + 1 == n_slices;
-        if (skew_slices) {
-            const SkewSlice ss{(uint32_t)h->ds, piece0 * 16, m, first, last, partial};
-#define QAMD_PQ_SKEW_SLICE(NVV)                                                                              \
-    case NVV: {                                                                                             \
-        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, FILTER, true>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
-                           skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t_dev, (uint32_t)n, out_dev,  \
-                           filt ? *filt : TopkFilter{}, ss);                                                \
-        break;                                                                                              \
-    }
-            switch (nvs) { QAMD_PQ_SKEW_SLICE(2) QAMD_PQ_SKEW_SLICE(4) QAMD_PQ_SKEW_SLICE(6) QAMD_PQ_SKEW_SLICE(8) }
-#undef QAMD_PQ_SKEW_SLICE
-            continue;
-        }
         const bool simple = n_slices == 1 && m % 16 == 0;
         const size_t lds = (size_t)std::min<uint32_t>(nvs * 16, m - piece0 * 16) * kCentroids * sizeof(float);
 #define QAMD_PQ_FAST(NVV)                                                                                   \
     case NVV: {                                                                                             \
-        static std::atomic<uint64_t> set_on{0};                                                             \
-        if (first_use_on_device(set_on)) {                                                                  \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, true>),  \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));     \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_fast_kernel<NVV, 4, FILTER, false>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));     \
-        }                                                                                                   \
+        QAMD_LDS_OPT_IN((&pq_scan_fast_kernel<NVV, 4, FILTER, true>), kLdsBudget);                           \
+        QAMD_LDS_OPT_IN((&pq_scan_fast_kernel<NVV, 4, FILTER, false>), kLdsBudget);                          \
         if (simple)                                                                                         \
             hipLaunchKernelGGL((pq_scan_fast_kernel<NVV, 4, FILTER, true>), dim3(grid), dim3(kScanBlock), lds, s, \
                                h->rows.as<uint4>(), pieces, piece0, lut_dev, m / 4, m, first, last, partial, \
@@ -1250,13 +1314,8 @@ qamd_status scan_launch(const qamd_pq *h, const float *lut_dev, const uint32_t *
     if (!ids_dev && fast_capable(h, n)) {
         return filt ? launch_fast<true>(h, lut_dev, out_dev, filt, s, lut_t_dev) : launch_fast<false>(h, lut_dev, out_dev, filt, s, lut_t_dev);
     } else if (in_lds) {
-        static std::atomic<uint64_t> set_on{0};  // opt in to > 64 KiB dynamic LDS once per kernel and device
-        if (first_use_on_device(set_on)) {
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_kernel<true, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        }
+        QAMD_LDS_OPT_IN((&pq_scan_kernel<true, true>), kLdsBudget);  // > 64 KiB of dynamic LDS: once per kernel and device
+        QAMD_LDS_OPT_IN((&pq_scan_kernel<true, false>), kLdsBudget);
         const int grid = (int)std::min<uint64_t>(cu, (n + 255) / 256);
         if (vec16) QAMD_PQ_LAUNCH(true, true, grid, lds);
         else QAMD_PQ_LAUNCH(true, false, grid, lds);
@@ -1277,16 +1336,12 @@ bool pq_topk_small(const qamd_pq *h, const float *lut, uint32_t k, int largest, 
     const size_t lut_bytes = (size_t)h->m * kCentroids * sizeof(float);
     // every workgroup stages the whole LUT (m KiB) before its first row: worth it from ~512 rows on
     if (h->m < 1 || lut_bytes > 128 * 1024 || !small_topk_plan(h->count, k, 16, 512, plan)) return false;
-    static std::atomic<uint64_t> set_on{0};
-    if (first_use_on_device(set_on)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_topk_small_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
-            status = fail(QAMD_ERR_DEVICE, "cannot raise the dynamic LDS limit of pq_topk_small_kernel");
-            return true;
-        }
-    }
+    status = [] {
+        QAMD_LDS_OPT_IN((&pq_topk_small_kernel<true>), 128 * 1024);
+        QAMD_LDS_OPT_IN((&pq_topk_small_kernel<false>), 128 * 1024);
+        return QAMD_OK;
+    }();
+    if (status != QAMD_OK) return true;
     const uint32_t row_words = (uint32_t)(h->ds / 4);
     status = small_topk(plan, k, largest, out_ids, out_scores, out_mem, s, [&](const SmallTopk &p, hipStream_t st) {
         if (row_words % 4 == 0)
@@ -1330,10 +1385,7 @@ qamd_status launch_assign(const float *src, uint64_t nr, uint64_t dim, uint64_t 
                           uint64_t r0, hipStream_t s) {
     const size_t lds = (size_t)kCentroids * chunk_size * sizeof(float);
     if (lds > kLdsBudget) return fail(QAMD_ERR_ARGUMENTS, "chunk_size %llu too large", (unsigned long long)chunk_size);
-    static std::atomic<uint64_t> set_on{0};
-    if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_encode_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    QAMD_LDS_OPT_IN((&pq_encode_kernel), (int)kLdsBudget);
     const uint32_t gx = (uint32_t)((nr + kBlock - 1) / kBlock);
     // few row blocks -> split the chunk loop over blockIdx.y to fill the chip
     uint32_t slices = 1;
@@ -1383,6 +1435,7 @@ qamd_status encode_rows(qamd_pq *h, const float *data, qamd_mem data_mem, qamd_s
         }
         QAMD_TRY(launch_assign(src, nr, dim, h->chunk_size, h->m, h->centroids.as<float>(), &pair_table,
                                h->rows.as<uint8_t>(), h->ds, r0, s));
+        QAMD_TRY(build_planar(h, r0, nr, s));
         if (data_mem == QAMD_MEM_HOST || stop) QAMD_HIP(hipStreamSynchronize(s));
     }
     QAMD_HIP(hipStreamSynchronize(s));
@@ -1604,6 +1657,7 @@ qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem, const qamd
             QAMD_HIP(hipStreamSynchronize(s));
         }
     }
+    QAMD_TRY(build_planar(h.get(), 0, h->count, s));
     QAMD_HIP(hipStreamSynchronize(s));
     *out = h.release();
     return QAMD_OK;
@@ -1946,6 +2000,25 @@ qamd_status qamd_pq_topk(const qamd_pq *h, const qamd_pq_query *q, uint32_t k, i
 
 void qamd_pq_free(qamd_pq *h) { delete h; }
 
+const char *qamd_pq_scan_kernel(const qamd_pq *h, uint32_t *n_launches) {
+    uint32_t launches = 1;
+    const char *name = "pq_scan_kernel";
+    if (h && fast_capable(h, h->count)) {
+        const uint32_t pieces = (uint32_t)valid_pieces(h->m);
+        if (skew_capable(h)) {
+            name = "pq_scan_skew_kernel";
+        } else if (skew_sliced_capable(h)) {
+            name = "pq_scan_skew_kernel<SLICED>";
+            launches = (uint32_t)h->slice_chunks.size();
+        } else {
+            name = "pq_scan_fast_kernel";
+            if (pieces > kMaxSlicePieces) launches = (pieces + kSlicePiecesAligned - 1) / kSlicePiecesAligned;
+        }
+    }
+    if (n_launches) *n_launches = launches;
+    return name;
+}
+
 qamd_status qamd_pq_kmeans_info(const qamd_pq *h, uint32_t *iterations, uint32_t *empty_clusters) {
     if (!h) return fail(QAMD_ERR_ARGUMENTS, "null handle");
     if (iterations) *iterations = h->kmeans_iterations;
@@ -2082,6 +2155,7 @@ qamd_status qamd_pq_encoder_push(qamd_pq_encoder *e, const float *batch, uint64_
         QAMD_TRY(local_view(batch + r * dim, batch_mem, nr * dim * 4, e->stage, e->stream, &src, &staged));
         QAMD_TRY(launch_assign(static_cast<const float *>(src), nr, dim, h->chunk_size, h->m, h->centroids.as<float>(),
                                &e->pair_table, h->rows.as<uint8_t>(), h->ds, e->pushed + r, e->stream));
+        QAMD_TRY(build_planar(h, e->pushed + r, nr, e->stream));
         if (staged) QAMD_HIP(hipStreamSynchronize(e->stream));
     }
     e->pushed += n_rows;

@@ -465,7 +465,7 @@ qamd_status fused_topk(uint64_t n, uint32_t k, int largest, uint32_t *out_ids, f
                 }
             }
         }
-        static const bool debug_topk = getenv("QAMD_DEBUG_TOPK") != nullptr;
+        static const bool debug_topk = dev_env("QAMD_DEBUG_TOPK") != nullptr;
         if (debug_topk) {
             struct { uint32_t pivot_key, status, total; } dbg{};
             (void)hipMemcpy(&dbg, st, sizeof dbg, hipMemcpyDeviceToHost);

@@ -1985,10 +1985,7 @@ qamd_status launch_gemm_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, cons
     const uint64_t blocks = r_tiles * q_tiles;
     if (blocks > 0x7FFFFFFFull) return fail(QAMD_ERR_ARGUMENTS, "batch too large for one launch");
     constexpr size_t lds_bytes = (size_t)2 * (TQ_ + TR_) * (BK_ + 16);
-    static std::atomic<uint64_t> set_on{0};  // per instantiation and device: the attribute is a device property
-    if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    QAMD_LDS_OPT_IN((&u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>), (int)lds_bytes);
     hipLaunchKernelGGL((u8_gemm_kernel<MODE, TQ_, TR_, WQ, WR, BK_>), dim3((unsigned)blocks), dim3(64 * WQ * WR), lds_bytes,
                        s, codes, v_offsets, b->codes.as<uint8_t>(), (uint32_t)b->pitch, b->offsets.as<float>(), h->meta.multiplier,
                        (uint32_t)n_rows, (uint32_t)b->n_queries, (uint32_t)h->meta.actual_dim, q_tiles, out, out_pitch,
@@ -2008,10 +2005,7 @@ template <int MODE, bool LOW, int MI, int MJ>
 qamd_status launch_gemm_pp_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
-    static std::atomic<uint64_t> set_on{0};
-    if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_pp_kernel<MODE, LOW, MI, MJ>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PpShape<MI, MJ>::LDS)));
+    QAMD_LDS_OPT_IN((&u8_gemm_pp_kernel<MODE, LOW, MI, MJ>), (int)(PpShape<MI, MJ>::LDS));
     constexpr uint64_t TQW = 64 * MI;  // queries per workgroup tile
     constexpr size_t lds_bytes = PpShape<MI, MJ>::LDS;
     const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
@@ -2069,10 +2063,7 @@ template <int MODE, bool LOW, int MI, bool NT>
 qamd_status launch_gemm_rs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                                const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                                const BatchFilter &filt, hipStream_t s) {
-    static std::atomic<uint64_t> set_on{0};
-    if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_rs_kernel<MODE, LOW, MI, NT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QAMD_LDS_OPT_IN((&u8_gemm_rs_kernel<MODE, LOW, MI, NT>), 160 * 1024);
     constexpr uint64_t TQW = 32 * MI;
     const size_t lds_bytes = RsShape<MI>::lds_bytes((uint32_t)h->meta.actual_dim);
     const uint32_t cus_per_xcd = (uint32_t)std::max(1, device_info().cu_count / 8);
@@ -2130,7 +2121,7 @@ inline uint32_t gemm_launches(const qamd_u8 *h, const qamd_u8_query_batch *b, bo
 // Which kernel serves a batch: the ping-pong kernel (rows of at least three 64-byte K-tiles, a
 // usable multiplier for its integer pre-filter), else u8_gemm_kernel.
 bool pp_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
-    static const char *cfg = getenv("QAMD_GEMM_CFG");  // developer A/B switch: 0/3/4/5 = u8_gemm_kernel shapes
+    static const char *cfg = dev_env("QAMD_GEMM_CFG");  // developer A/B switch: 0/3/4/5 = u8_gemm_kernel shapes
     if (cfg && cfg[0] != 'p') return false;
     const float m = h->meta.multiplier;
     return h->meta.actual_dim > 128 && h->meta.actual_dim <= 32768 && (!filter_mode || (std::isfinite(m) && m != 0.0f));
@@ -2143,10 +2134,7 @@ template <int MODE, bool LOW, int MJ>
 qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                                const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                                const BatchFilter &filt, const int *bq, hipStream_t s) {
-    static std::atomic<uint64_t> set_on{0};
-    if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs_kernel<MODE, LOW, MJ>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QAMD_LDS_OPT_IN((&u8_gemm_qs_kernel<MODE, LOW, MJ>), 160 * 1024);
     const uint32_t nkb = b->frag_nkb;
     constexpr int QS_ROWS = 32 * MJ;
     const size_t lds_bytes = (size_t)QS_ROWS * (nkb * 128 + 16) + 2 * QS_ROWS * 4 + 64 + kQsSlice * 4;
@@ -2172,7 +2160,7 @@ qamd_status launch_gemm_qs_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
 // The same on v_mfma_i32_16x16x64_i8 (u8_gemm_qs16_kernel): rows of up to 1024 bytes, the batch's fragment copy in its order.
 constexpr uint64_t kQs16SmallBatch = 256;
 inline bool qs16_wanted(uint32_t nkb) {
-    static const char *e = getenv("QAMD_QS16");  // developer A/B: 0 = the 32x32x32 kernel for every row length
+    static const char *e = dev_env("QAMD_QS16");  // developer A/B: 0 = the 32x32x32 kernel for every row length
     return nkb >= 1 && nkb <= 12 && !(e && e[0] == '0');
 }
 
@@ -2180,10 +2168,7 @@ template <int MODE, bool LOW, int JT, int IT>
 qamd_status launch_gemm_qs16_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                                  const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                                  const BatchFilter &filt, const int *bq, hipStream_t s) {
-    static std::atomic<uint64_t> set_on{0};
-    if (first_use_on_device(set_on))
-        QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qs16_kernel<MODE, LOW, JT, IT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QAMD_LDS_OPT_IN((&u8_gemm_qs16_kernel<MODE, LOW, JT, IT>), 160 * 1024);
     const uint32_t nkb = b->frag_nkb;
     constexpr int QS_ROWS = 16 * JT;
     const uint32_t per = (uint32_t)(h->meta.actual_dim / 16);
@@ -2222,8 +2207,8 @@ inline bool qr_possible(const qamd_u8 *h, const qamd_u8_query_batch *b, bool fil
     return b->frag.ptr && b->frag16 && (ad == 256 || ad == 384 || ad == 512 || ad == 768 || ad == 1024);
 }
 bool qr_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
-    static const char *cfg = getenv("QAMD_GEMM_CFG");
-    static const char *lo = getenv("QAMD_QR_MIN"), *hi = getenv("QAMD_QR_MAX");
+    static const char *cfg = dev_env("QAMD_GEMM_CFG");
+    static const char *lo = dev_env("QAMD_QR_MIN"), *hi = dev_env("QAMD_QR_MAX");
     if (cfg && cfg[0] != 'g') return false;
     if (!qr_possible(h, b, filter_mode)) return false;
     if (cfg) return true;
@@ -2250,10 +2235,7 @@ qamd_status launch_gemm_qr_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
         }
 #define QAMD_QR(NS_)                                                                                                          \
     do {                                                                                                                     \
-        static std::atomic<uint64_t> set_on{0};                                                                              \
-        if (first_use_on_device(set_on))                                                                                     \
-            QAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&u8_gemm_qr16_kernel<MODE, LOW, NS_>),               \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                           \
+        QAMD_LDS_OPT_IN((&u8_gemm_qr16_kernel<MODE, LOW, NS_>), 160 * 1024); \
         hipLaunchKernelGGL((u8_gemm_qr16_kernel<MODE, LOW, NS_>), dim3(grid), dim3(512), lds_bytes, s, codes, v_offsets,     \
                            b->frag.as<uint4>() + (q_base / 16) * nkb * 128, b->offsets.as<float>() + q_base,                 \
                            (MODE == 1 || MODE == 2) ? bq + q_base : nullptr, h->meta.multiplier, (uint32_t)n_rows, nq,       \
@@ -2334,7 +2316,7 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
 // The query-streaming kernel: rows short enough for a 128-row block in LDS, a fragment-order copy in
 // the batch, enough queries to keep the 8 waves of a workgroup busy (64 queries per wave and turn).
 bool qs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
-    static const char *cfg = getenv("QAMD_GEMM_CFG");
+    static const char *cfg = dev_env("QAMD_GEMM_CFG");
     if (qr_selected(h, b, filter_mode)) return true;  // a form of it (launch_gemm_qs dispatches)
     if (cfg && cfg[0] != 'q') return false;
     const float m = h->meta.multiplier;
@@ -2350,7 +2332,7 @@ bool qs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
 // The row-streaming kernel: where the ping-pong kernel could run (same pre-filter conditions), the
 // query tile fits in LDS, and the batch is small enough to be HBM-bound (QAMD_GEMM_CFG=r / p force).
 bool rs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
-    static const char *cfg = getenv("QAMD_GEMM_CFG");
+    static const char *cfg = dev_env("QAMD_GEMM_CFG");
     if (cfg && cfg[0] != 'r') return false;
     const float m = h->meta.multiplier;
     if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;
@@ -2376,7 +2358,7 @@ qamd_status launch_gemm(const qamd_u8 *h, const qamd_u8_query_batch *b, const ui
     if (rs_selected(h, b, MODE != 0)) return launch_gemm_rs<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (pp_selected(h, b, MODE != 0)) return launch_gemm_pp<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     if (b->n_queries > 128) {
-        static const char *cfg = getenv("QAMD_GEMM_CFG");
+        static const char *cfg = dev_env("QAMD_GEMM_CFG");
         if (cfg && cfg[0] == '3')  // two 4-wave workgroups per CU (61 KiB LDS each), 128 q x 256 rows
             return launch_gemm_cfg<MODE, 128, 256, 2, 2, 64>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
         if (cfg && cfg[0] == '4')  // same, 256 q x 128 rows
@@ -2705,7 +2687,7 @@ qamd_status qamd_u8_topk_batch(const qamd_u8 *h, const qamd_u8_query_batch *b, u
             overflow = back[Q];
         }
         if (pp && overflow) std::fill(status.begin(), status.end(), 1u);  // a wave list overflowed: redo all exactly
-        static const bool debug_topk = getenv("QAMD_DEBUG_TOPK") != nullptr;
+        static const bool debug_topk = dev_env("QAMD_DEBUG_TOPK") != nullptr;
         if (debug_topk) {
             std::vector<uint32_t> cnt(b->q_pad * kCounterStride);
             (void)hipMemcpy(cnt.data(), counters, cnt.size() * 4, hipMemcpyDeviceToHost);

@@ -134,6 +134,12 @@ class EncodedVectorsPQ(EncodedVectorsBase):
         check(_lib.lib().qamd_pq_kmeans_info(self._h, C.byref(it), C.byref(em)))
         return int(it.value), int(em.value)
 
+    def scan_kernel(self) -> tuple[str, int]:
+        """(name of the whole-store scan kernel this store takes, launches per scan) - for measurement harnesses."""
+        n = C.c_uint32()
+        name = _lib.lib().qamd_pq_scan_kernel(self._h, C.byref(n))
+        return name.decode(), int(n.value)
+
     @classmethod
     def from_storage(cls, rows, vector_parameters: VectorParameters, chunk_size: int, centroids,
                      stream=None) -> "EncodedVectorsPQ":

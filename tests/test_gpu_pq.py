@@ -160,8 +160,11 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
 
 @pytest.mark.parametrize("m,chunk,n", [(96, 8, 300_001), (96, 8, 4097), (64, 4, 70_003), (32, 2, 50_000), (96, 1, 6007),
                                        (128, 8, 200_003), (128, 2, 4100),
-                                       # rows of several LUT slices (128-chunk slices + a last one of 64 / 32 / 96 / 128)
-                                       (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (512, 2, 20_011)])
+                                       # m = 48: two store rows per ring row (odd and even row counts, a lone last row)
+                                       (48, 16, 300_001), (48, 2, 4096), (48, 1, 4097), (48, 4, 70_002), (48, 8, 33),
+                                       # rows of several LUT slices, scanned from the planar image (96 + 96, 128 + 32, 128 + 96,
+                                       # 96 x 3, four of 128)
+                                       (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (288, 2, 30_001), (512, 2, 20_011)])
 def test_pq_skewed_scan_shapes(qo, m, chunk, n):
     """m = 32 / 64 / 96 / 128 whole-store scans take pq_scan_skew_kernel (transposed LUT, quads skewed in time, rows through a
     per-wave LDS ring): same bits as the oracle's score_point_sse order for row counts that are not multiples of 16, waves
@@ -177,7 +180,13 @@ def test_pq_skewed_scan_shapes(qo, m, chunk, n):
         lut = qo.pq_encode_query(query, chunk, cen, int(dist), invert)
         want = qo.pq_score_all(rows, lut, order=qo.ORDER_SSE)
         q = enc.encode_query(query)
+        if n >= 4096:
+            assert enc.scan_kernel() == (("pq_scan_skew_kernel", 1) if m <= 128 else
+                                         ("pq_scan_skew_kernel<SLICED>", {192: 2, 160: 2, 224: 2, 288: 3, 512: 4}[m]))
         assert_bits_equal(enc.score_all(q), want, f"m={m} n={n}")
+        assert np.array_equal(enc.storage_bytes(), rows), "the row-major image is what export returns"
+        pick = rng.integers(0, n, size=64).astype(np.uint32)
+        assert_bits_equal(enc.score_ids(q, pick), want[pick], "random access reads the row-major image")
         for largest in (True, False):
             ids, sc = enc.topk(q, 30, largest=largest)
             order = np.lexsort((np.arange(n), -want if largest else want))[:30]
@@ -186,8 +195,9 @@ def test_pq_skewed_scan_shapes(qo, m, chunk, n):
 
 
 def test_pq_skewed_and_older_scan_kernels_give_the_same_bits():
-    """The same stores scanned by pq_scan_skew_kernel (default) and by pq_scan_fast_kernel (QAMD_PQ_SKEW=0, read once per
-    process): identical score bits and identical top-k for whole rows (m = 64, 96, 128) and sliced rows (m = 192, 288)."""
+    """The same stores scanned by pq_scan_skew_kernel (default) and by pq_scan_fast_kernel (QAMD_PQ_SKEW=0, a developer switch
+    that only the tools/lib build reads - the product library ignores it): identical score bits and identical top-k for whole
+    rows (m = 48, 64, 96, 128) and sliced rows (m = 192, 288)."""
     import hashlib
     import os
     import subprocess
@@ -200,22 +210,35 @@ import numpy as np
 import quantization_amd as qa
 D = qa.DistanceType
 h = hashlib.sha256()
-for m, chunk, n in ((64, 2, 9000), (96, 8, 50001), (128, 4, 30007), (192, 4, 20011), (288, 1, 7001)):
+names = []
+for m, chunk, n in ((48, 4, 40001), (64, 2, 9000), (96, 8, 50001), (128, 4, 30007), (192, 4, 20011), (288, 1, 7001)):
     rng = np.random.default_rng(m)
     dim = m * chunk
     cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)
     rows = rng.integers(0, 256, size=(n, m), dtype=np.uint8)
     enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, D.L2, True), chunk, cen)
     q = enc.encode_query((rng.random(dim, dtype=np.float32) - 0.5).astype(np.float32))
+    names.append(enc.scan_kernel()[0])
     h.update(np.asarray(enc.score_all(q)).tobytes())
     ids, sc = enc.topk(q, 50, largest=False)
     h.update(np.asarray(ids).tobytes()); h.update(np.asarray(sc).tobytes())
 print("DIGEST", h.hexdigest())
+print("KERNELS", " ".join(sorted(set(names))))
 """ % root
-    digests = []
-    for skew in ("1", "0"):
+    dev_lib = os.path.join(root, "tools", "lib", "libquantization_amd_dev.so")
+    if not os.path.exists(dev_lib):
+        pytest.skip("tools/lib/libquantization_amd_dev.so not built (make -C quantization_amd/csrc dev)")
+    digests, kernels = [], []
+    # product library (the switch set, and ignored), developer library with the switch on and off
+    for lib, skew in ((None, "0"), (dev_lib, "1"), (dev_lib, "0")):
         env = dict(os.environ, QAMD_PQ_SKEW=skew)
+        env.pop("QAMD_LIB_PATH", None)
+        if lib:
+            env["QAMD_LIB_PATH"] = lib
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
         assert res.returncode == 0, res.stderr[-2000:]
         digests.append([ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST")][-1])
-    assert digests[0] == digests[1]
+        kernels.append([ln for ln in res.stdout.splitlines() if ln.startswith("KERNELS")][-1])
+    assert digests[0] == digests[1] == digests[2]
+    assert "fast" not in kernels[0], "the product library must ignore developer switches"
+    assert "fast" not in kernels[1] and "skew" not in kernels[2], kernels

@@ -1,5 +1,7 @@
-"""PQ single-query top-k at config 2's shape (10M x 768, m = 96): ms per topk(30) call, device outputs, and per score_all call.
-QAMD_PQ_SKEW=0 selects the older scan kernel for comparison."""
+"""PQ single-query top-k and score_all, ms per call with device outputs: config 2's shape (10M x 768, m = 96), config 4's PQ
+leg (12.5M x 1536, m = 192: two LUT slices of the planar scan image), m = 48 (dim 768 at chunk 16: two rows per ring row),
+m = 80 / 112 / 16 (row lengths the conflict-free kernel does not take) and the reference bench's m = 512.  With
+QAMD_LIB_PATH=tools/lib/libquantization_amd_dev.so, QAMD_PQ_SKEW=0 selects the older scan kernel for comparison."""
 import sys as _sys
 if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:
     print(__doc__)
@@ -11,7 +13,12 @@ import torch
 import quantization_amd as qa
 D = qa.DistanceType
 dev = torch.device("cuda", 0)
-for n, dim, chunk in ((10_000_000, 768, 8), (12_500_000, 1536, 8)):
+shapes = ((10_000_000, 768, 8), (12_500_000, 1536, 8), (20_000_000, 768, 16), (12_000_000, 640, 8), (8_000_000, 896, 8),
+          (20_000_000, 128, 8), (2_000_000, 1024, 2))
+only = [int(a) for a in _sys.argv[1:] if a.isdigit()]  # optional: the m values to run
+for n, dim, chunk in shapes:
+    if only and dim // chunk not in only:
+        continue
     m = dim // chunk
     rows = torch.randint(0, 256, (n, m), device=dev, dtype=torch.uint8)
     cen = np.random.default_rng(0).random((256, dim), dtype=np.float32)
@@ -29,5 +36,7 @@ for n, dim, chunk in ((10_000_000, 768, 8), (12_500_000, 1536, 8)):
         for _ in range(50):
             fn()
         torch.cuda.synchronize()
-        print(f"{n} x {dim} m={m} {name}: {(time.perf_counter() - t0) / 50 * 1e3:.4f} ms per call")
+        ms = (time.perf_counter() - t0) / 50 * 1e3
+        print(f"{n} x {dim} m={m} {enc.scan_kernel()} {name}: {ms:.4f} ms per call = {n * m / ms / 1e9:.2f} TB/s of code bytes = "
+              f"{n * m / ms / 1e9 / 8:.3f} of 8 TB/s", flush=True)
     del enc, out
