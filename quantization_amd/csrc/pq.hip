@@ -778,6 +778,129 @@ __global__ __launch_bounds__(kBlock) void pq_lists_kernel(const uint32_t *__rest
     }
 }
 
+// The same for bursts whose lists are LONG (hundreds of pairs per query; the reference's PQ bench scores every query against
+// random rows, demos/benches/pq.rs:12-46): gathering LUT l through L1/L2 then costs more than the rows themselves - 1M pairs
+// in lists of 1024 dragged 96 KiB of LUT per list through the vector caches, 0.25 ms.  Here a 1024-thread workgroup takes
+// 1024 consecutive pairs, walks the list segments inside that range, and for every segment of at least kListStageMin pairs
+// stages the list's LUT in LDS ONCE (coalesced 16-byte loads) and gathers from there; shorter segments gather through L1/L2
+// as above.  A lane group has its up to four pairs' ids and row pieces in flight BEFORE the staging barrier, so the random
+// row fetches, the LUT fetch and nothing else stand in a segment's way; the four lanes of a pair load different pieces and
+// hand the dwords round the quad (pq_scan_fast_kernel's scheme).  The workgroup's first list is found by all threads
+// counting offsets at once (ten dependent loads of a binary search were 5 us in front of every workgroup).  Per pair
+// nothing changes: four lanes, lane k = the reference's SSE lane k, (l0 + l2) + (l1 + l3), the tail after it.
+constexpr uint32_t kListStageMin = 128, kListStagePairs = kScanBlock;
+template <int NP>  // 16-byte pieces per device row (ds / 16)
+__global__ __launch_bounds__(kScanBlock) void pq_lists_staged_kernel(const uint4 *__restrict__ rows4,
+                                                                    const float *__restrict__ luts, uint64_t lut_stride,
+                                                                    const uint32_t *__restrict__ lists, uint32_t n_lists,
+                                                                    const uint32_t *__restrict__ ids, uint64_t n, uint32_t n_rows,
+                                                                    uint32_t m, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];
+    __shared__ uint32_t first_list;
+    constexpr int JN = (NP + 3) / 4, U = kListStagePairs / (kScanBlock / 4);
+    const int lane = threadIdx.x & 63;
+    const int k = lane & 3, group = threadIdx.x / 4;
+    const uint64_t p0 = (uint64_t)blockIdx.x * kListStagePairs;
+    const uint64_t p1 = p0 + kListStagePairs < n ? p0 + kListStagePairs : n;
+    // the list of pair p0: the last l with lists[l] <= p0 (empty lists in front of it have the same offset and lose)
+    if (threadIdx.x == 0) first_list = 0;
+    __syncthreads();
+    {
+        uint32_t cnt = 0;
+        for (uint32_t i = 1 + threadIdx.x; i < n_lists; i += kScanBlock) cnt += lists[i] <= (uint32_t)p0;
+        for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0 && cnt) atomicAdd(&first_list, cnt);
+    }
+    __syncthreads();
+    uint32_t l = first_list;
+    const uint32_t groups_total = m / 4, shift = 8 * k;
+    for (uint64_t cur = p0; cur < p1;) {  // one trip per list segment inside [p0, p1): the control flow is workgroup-uniform
+        l = advance_list(lists, n_lists, l, cur);
+        const uint64_t seg_end = l + 1 < n_lists ? (p1 < lists[l + 1] ? p1 : (uint64_t)lists[l + 1]) : p1;
+        const float *lut_g = luts + (size_t)l * lut_stride;
+        // this group's pairs of the segment (at most U: a workgroup's range is U passes of its 256 groups)
+        uint32_t row[U];
+        uint4 mine[U][JN];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t idx = cur + group + (uint64_t)u * (kScanBlock / 4);
+            row[u] = idx < seg_end ? ids[idx] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint4 *p = rows4 + (uint64_t)(row[u] < n_rows ? row[u] : 0u) * NP;
+#pragma unroll
+            for (int j = 0; j < JN; j++) mine[u][j] = p[k + 4 * j < NP ? k + 4 * j : NP - 1];
+        }
+        const bool staged = seg_end - cur >= kListStageMin;
+        if (staged) {
+            __syncthreads();  // the previous segment's gathers are done with the LDS image
+            const float4 *src = reinterpret_cast<const float4 *>(lut_g);
+            float4 *dst = reinterpret_cast<float4 *>(lut_s);
+            float4 t[NP];  // m / 16 <= NP rounds, every load in flight before the first LDS store (a load -> store loop is one
+                           // memory round trip per round)
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const uint32_t at = threadIdx.x + (uint32_t)i * kScanBlock;
+                t[i] = src[at < m * (kCentroids / 4) ? at : 0u];
+            }
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const uint32_t at = threadIdx.x + (uint32_t)i * kScanBlock;
+                if (at < m * (kCentroids / 4)) dst[at] = t[i];
+            }
+            __syncthreads();
+        }
+        auto score = [&](const float *lut) {  // called once with the LDS image and once with the global LUT: two address spaces
+            const float *lut_k = lut + k * kCentroids;
+            float acc[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) acc[u] = 0.0f;
+#pragma unroll
+            for (int pc = 0; pc < NP; pc++) {
+                const float *t = lut_k + pc * 16 * kCentroids;  // piece pc = chunk groups 4 pc .. 4 pc + 3
+                const uint32_t g = 4 * pc;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint4 &held = mine[u][pc / 4];
+                    uint4 w;
+                    switch (pc & 3) {
+                        case 0: w = quad_bcast4<0>(held); break;
+                        case 1: w = quad_bcast4<1>(held); break;
+                        case 2: w = quad_bcast4<2>(held); break;
+                        default: w = quad_bcast4<3>(held); break;
+                    }
+                    if (g + 0 < groups_total) acc[u] += t[(w.x >> shift) & 255u];
+                    if (g + 1 < groups_total) acc[u] += t[4 * kCentroids + ((w.y >> shift) & 255u)];
+                    if (g + 2 < groups_total) acc[u] += t[8 * kCentroids + ((w.z >> shift) & 255u)];
+                    if (g + 3 < groups_total) acc[u] += t[12 * kCentroids + ((w.w >> shift) & 255u)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t idx = cur + group + (uint64_t)u * (kScanBlock / 4);
+                const float a = acc[u] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[u]), 0x4E, 0xF, 0xF, false));
+                float sc = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));
+                if (k == 0 && idx < seg_end) {
+                    if (row[u] < n_rows) {
+                        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(rows4 + (uint64_t)row[u] * NP);
+                        for (uint32_t c = groups_total * 4; c < m; c++) {  // tail (:434-438)
+                            const uint32_t code = (p32[c >> 2] >> (8 * (c & 3))) & 255u;
+                            sc += lut[(size_t)c * kCentroids + code];
+                        }
+                        out[idx] = sc;
+                    } else {
+                        out[idx] = __builtin_nanf("");
+                    }
+                }
+            }
+        };
+        if (staged) score(lut_s);
+        else score(lut_g);
+        cur = seg_end;
+    }
+}
+
 // score_internal (:566-593) for bursts of pairs: 16 lanes per pair.  Lane `sub` decodes chunks
 // sub, sub + 16, ... of both rows to their centroid sub-vectors and forms the chunk's metric with the
 // reference's sequential f32 loop; the chunk results are then added IN CHUNK ORDER (the reference's
@@ -2261,6 +2384,26 @@ qamd_status qamd_pq_score_ids_batch(const qamd_pq *h, const qamd_pq_query_batch 
     const size_t per = (size_t)h->m * kCentroids;
     return run_lists(list_offsets, n_lists, ids, n_ids, nullptr, lists_mem, out, out_mem, h->count, s, [&](const ListArgs &a) {
         const uint32_t row_words = (uint32_t)(h->ds / 4);
+        const size_t lut_bytes = per * sizeof(float);
+        // long lists (what a caller knows without reading device lists: the mean length): one LUT staging per list segment
+        if (a.n_pairs >= 4096 && a.n_pairs / a.n_lists >= 2 * kListStageMin && lut_bytes <= kLdsBudget && h->ds % 16 == 0 &&
+            h->ds / 16 <= 10) {
+            const unsigned grid = (unsigned)((a.n_pairs + kListStagePairs - 1) / kListStagePairs);
+#define QAMD_PQ_STAGED(NPV)                                                                                  \
+    case NPV:                                                                                               \
+        QAMD_LDS_OPT_IN((&pq_lists_staged_kernel<NPV>), kLdsBudget);                                        \
+        hipLaunchKernelGGL(pq_lists_staged_kernel<NPV>, dim3(grid), dim3(kScanBlock), lut_bytes, s, h->rows.as<uint4>(), \
+                           b->luts.as<float>(), (uint64_t)per, a.offsets, a.n_lists, a.ids, a.n_pairs, (uint32_t)h->count, \
+                           (uint32_t)h->m, a.out);                                                          \
+        break;
+            switch (h->ds / 16) {
+                QAMD_PQ_STAGED(1) QAMD_PQ_STAGED(2) QAMD_PQ_STAGED(3) QAMD_PQ_STAGED(4) QAMD_PQ_STAGED(5)
+                QAMD_PQ_STAGED(6) QAMD_PQ_STAGED(7) QAMD_PQ_STAGED(8) QAMD_PQ_STAGED(9) QAMD_PQ_STAGED(10)
+            }
+#undef QAMD_PQ_STAGED
+            QAMD_HIP(hipGetLastError());
+            return QAMD_OK;
+        }
         const uint32_t ppb = pairs_per_block(a.n_pairs, 64, 1);  // 64 lane groups per workgroup, one pass: the window of LUTs in use stays L2-sized
         const unsigned grid = (unsigned)((a.n_pairs + ppb - 1) / ppb);
         if (row_words % 4 == 0)

@@ -160,6 +160,42 @@ def test_pq_bursts_equal_the_per_pair_reference_calls(dim, chunk, dist, invert, 
     assert_bits_equal(got, want, "pq score_ids_batch")
 
 
+@pytest.mark.parametrize("dim,chunk", [(768, 8), (1536, 8), (130, 2), (100, 7)])
+def test_pq_bursts_with_long_lists_stage_the_lut_once_per_segment(dim, chunk, qo):
+    """Long lists (the reference's PQ bench shape, demos/benches/pq.rs:12-46: a query against many random rows) take
+    pq_lists_staged_kernel: a workgroup stages a list's LUT in LDS once per segment of >= 128 pairs and gathers the shorter
+    segments through the caches; list boundaries fall inside, on and across the 1024-pair workgroup ranges, empty lists and
+    an out-of-range id (device lists: NaN) included.  Same bits as the per-pair score_point_sse order."""
+    rng = np.random.default_rng(dim * 7 + chunk)
+    n = 3000
+    m = -(-dim // chunk)
+    cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)
+    rows = rng.integers(0, 256, size=(n, m), dtype=np.uint8)
+    enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, D.L2, True), chunk, cen)
+    lens = np.array([3000, 0, 130, 127, 1500, 1, 0, 700, 1024, 1024, 4000, 128, 5], dtype=np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    ids = rng.integers(0, n, int(offs[-1])).astype(np.uint32)
+    queries = (rng.random((len(lens), dim), dtype=np.float32) - 0.5).astype(np.float32)
+    batch = enc.encode_query_batch(queries)
+    want = np.empty(ids.size, dtype=np.float32)
+    for l in range(len(lens)):
+        sl = slice(int(offs[l]), int(offs[l + 1]))
+        if sl.stop > sl.start:
+            lut = qo.pq_encode_query(queries[l], chunk, cen, qo.L2, True)
+            want[sl] = qo.pq_score_all(rows[ids[sl]], lut, order=qo.ORDER_SSE)
+    assert_bits_equal(both_ways(lambda o, i, r, out: enc.score_ids_batch(batch, o, i, out=out), offs, ids), want,
+                      "pq score_ids_batch, long lists")
+    bad = ids.copy()
+    bad[4000] = n + 7
+    t = lambda a: torch.from_numpy(a.view(np.int32)).cuda()
+    out = torch.empty(ids.size, dtype=torch.float32, device="cuda")
+    enc.score_ids_batch(batch, t(offs), t(bad), out=out)
+    got = out.cpu().numpy()
+    assert np.isnan(got[4000])
+    keep = np.arange(ids.size) != 4000
+    assert_bits_equal(got[keep], want[keep], "device lists with one id out of range")
+
+
 def test_burst_argument_errors():
     rng = np.random.default_rng(0)
     n, dim = 500, 32
