@@ -130,35 +130,64 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
+def cpu_baseline(quantizer, enc, query, gpu_scores, dist_id, sample_rows, pq_chunk=None):
     """Times the reference's caller loop (encode_query once, score_point for every row,
-    demos/src/ann_benchmark.rs:247-252) on the host over the store's OWN encoded rows: the oracle's
-    loop driving the REFERENCE's compiled impl_score_dot_avx (oracle/_ref) when present
-    ("reference"), else the oracle's restatement ("port").  One core is what the reference does (it
-    is single-threaded); the all-cores figure splits the rows over persistent worker threads.  Also
-    checks every GPU score of those rows bit for bit."""
+    demos/src/ann_benchmark.rs:247-252) on the host over the store's OWN encoded rows, through the oracle's loop:
+      u8      the REFERENCE's compiled impl_score_dot_avx (oracle/_ref; "reference"), else the restatement ("port")
+      binary  the REFERENCE's compiled impl_xor_popcnt_sse_uint128 ("reference"), else the restatement
+      pq      the restatement of score_point_sse (encoded_vectors_pq.rs:405-440; Rust intrinsics, not compilable
+              here: "port")
+    One core is what the reference does (it is single-threaded); the all-cores figure splits the rows over persistent
+    worker threads.  Also checks every GPU score of those rows bit for bit."""
     from concurrent.futures import ThreadPoolExecutor
 
     import numpy as np
 
     from oracle import qoracle as qo
 
-    md = enc.metadata
-    vp = md["vector_parameters"]
     S = sample_rows
-    rows = enc.storage_bytes()[:S]  # reference-format rows, straight from the store being benchmarked
-    meta = qo.Meta(md["actual_dim"], float(md["alpha"]), float(md["offset"]), float(md["multiplier"]),
-                   vp.dim, S, dist_id, int(vp.invert))
-    kind = "reference" if qo.ref() is not None else "port"
-    use_ref = kind == "reference"
-    codes, qoff = qo.u8_encode_query(meta, queries[0])
-    want = qo.u8_score_all(meta, rows, codes, qoff, order=qo.ORDER_AVX2, use_ref=use_ref)
+    rows = enc.storage_rows(0, S)  # reference-format rows, straight from the store being benchmarked
+    have_ref = qo.ref() is not None
+    if quantizer == "u8":
+        md = enc.metadata
+        vp = md["vector_parameters"]
+        meta = qo.Meta(md["actual_dim"], float(md["alpha"]), float(md["offset"]), float(md["multiplier"]),
+                       vp.dim, S, dist_id, int(vp.invert))
+        kind, what = ("reference", "compiled reference impl_score_dot_avx") if have_ref else ("port", "oracle restatement")
+
+        def prepare():
+            return qo.u8_encode_query(meta, query)
+
+        def score(q, begin, end):
+            return qo.u8_score_all(meta, rows, q[0], q[1], order=qo.ORDER_AVX2, use_ref=have_ref, begin=begin, end=end)
+    elif quantizer == "binary":
+        vp = enc.vector_parameters
+        kind, what = (("reference", "compiled reference impl_xor_popcnt_sse_uint128") if have_ref else
+                      ("port", "oracle restatement of xor_popcnt"))
+
+        def prepare():
+            return qo.bin_encode(query[None, :], qo.STORE_U128)[0]
+
+        def score(q, begin, end):
+            return qo.bin_score_all(rows, q, vp.dim, dist_id, bool(vp.invert), qo.STORE_U128, use_ref=have_ref,
+                                    begin=begin, end=end)
+    else:
+        vp = enc.vector_parameters
+        cen = enc.centroids
+        kind, what = "port", "oracle restatement of score_point_sse (the reference's is Rust std::arch, not compilable here)"
+
+        def prepare():
+            return qo.pq_encode_query(query, pq_chunk, cen, dist_id, bool(vp.invert))
+
+        def score(q, begin, end):
+            return qo.pq_score_all(rows, q, order=qo.ORDER_SSE, begin=begin, end=end)
+
+    want = score(prepare(), 0, S)
     parity = bool(np.array_equal(want.view(np.uint32), gpu_scores[:S].view(np.uint32)))
 
     def one_core():
         t0 = time.perf_counter()
-        c, o = qo.u8_encode_query(meta, queries[0])
-        qo.u8_score_all(meta, rows, c, o, order=qo.ORDER_AVX2, use_ref=use_ref)
+        score(prepare(), 0, S)
         return time.perf_counter() - t0
 
     one_core()  # warm-up (criterion-like: warm-up + >= 10 samples, median)
@@ -166,6 +195,8 @@ def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
     t_budget = time.perf_counter()
     while len(samples) < 10 or (time.perf_counter() - t_budget < 6.0 and len(samples) < 30):
         samples.append(one_core())
+        if time.perf_counter() - t_budget > 20.0 and len(samples) >= 3:
+            break
     t1 = float(np.median(samples))
 
     cores = os.cpu_count() or 1
@@ -174,10 +205,9 @@ def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
     pool = ThreadPoolExecutor(max_workers=nthreads)  # persistent workers: no thread start inside a pass
 
     def all_cores():
-        c, o = qo.u8_encode_query(meta, queries[0])
+        q = prepare()
         t0 = time.perf_counter()
-        futs = [pool.submit(qo.u8_score_all, meta, rows, c, o, order=qo.ORDER_AVX2, use_ref=use_ref,
-                            begin=bounds[i], end=bounds[i + 1]) for i in range(nthreads)]
+        futs = [pool.submit(score, q, bounds[i], bounds[i + 1]) for i in range(nthreads)]
         for f in futs:
             f.result()
         return time.perf_counter() - t0
@@ -189,8 +219,7 @@ def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
     return {
         "value": S / t1, "unit": "vectors/s", "cores": 1, "kind": kind,
         "sample": f"the first {S} rows of the benchmarked store itself, 1 query, median of {len(samples)} passes of "
-                  f"the reference loop (encode_query + score_point per row, "
-                  f"{'compiled reference impl_score_dot_avx' if use_ref else 'oracle restatement'}); "
+                  f"the reference loop (encode_query + score_point per row, {what}); "
                   f"host: {host_cpu_model()}, {cores} logical cores, {usable_cores()} usable by this job",
         "all_cores": {"value": S / tn, "cores": nthreads,
                       "note": "same rows split over persistent worker threads, median of 10 passes"},
@@ -198,28 +227,27 @@ def cpu_baseline(enc, queries, gpu_scores, dist_id, sample_rows):
     }
 
 
-def pmc_traffic(quantizer, n, bytes_per_row):
-    """HBM bytes per launch from a committed rocprofv3 --pmc profile of THIS workload and kernel
-    source (profiles/r*_pmc_u8_scan.json names the commit it was taken at and a hash of the kernel
-    source: the part of csrc/u8.hip that defines u8_scan_kernel; a profile of other code is not quoted)."""
+def pmc_traffic(key, n, read_bytes_per_launch_unit):
+    """HBM bytes per scan from a committed rocprofv3 --pmc profile of THIS workload and kernel source:
+    profiles/r*_pmc_<key>.json (key: u8_scan, bin_scan, pq_scan_m<m>, u8_batch<Q>, bin_batch<Q>) names the commit it was
+    taken at and a hash of the kernel source (profiles/summarize.py kernel_source_hash); a profile of other code, or of
+    another row count, is not quoted."""
     import glob
 
-    if quantizer != "u8":
-        return None, None
     try:
         sys.path.insert(0, os.path.join(ROOT, "profiles"))
         from summarize import kernel_source_hash  # the one definition of "the source that was profiled"
-        src_hash = kernel_source_hash(ROOT)
+        src_hash = kernel_source_hash(ROOT, key)
     except Exception:
         return None, None
     finally:
         sys.path.pop(0)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_u8_scan.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{key}.json")), reverse=True):
         try:
             j = json.load(open(path))
         except Exception:
             continue
-        if (j.get("rows_per_launch") == n and j.get("algorithmic_read_bytes_per_launch") == n * bytes_per_row
+        if (j.get("rows_per_launch") == n and j.get("algorithmic_read_bytes_per_launch") == read_bytes_per_launch_unit
                 and j.get("kernel_source_sha256_16") == src_hash):
             return j.get("traffic_bytes_per_launch"), (f"{os.path.relpath(path, ROOT)} (rocprofv3 --pmc, FETCH_SIZE x2 "
                                                        f"per the guide; commit {j.get('commit', '?')})")
@@ -458,11 +486,17 @@ def main():
     qgen.manual_seed(43)
     if args.quantizer == "u8":
         data = torch.rand((n, dim), generator=gen, device=dev, dtype=torch.float32)
-        # one global (alpha, offset): data is U[0,1) on every rank, so use the analytic interval
-        # [0, 1) -> alpha = 1/127, offset = 0 rather than a cross-rank min/max reduction.
-        alpha_offset = (float(np.float32(1.0) / np.float32(127.0)), 0.0) if world > 1 else None
         vp = qa.VectorParameters(dim, n, dtype, False)
-        enc = qa.EncodedVectorsU8.encode(data, vp, alpha_offset=alpha_offset)
+        if use_dist:
+            # ONE global (alpha, offset) as the reference's encode finds it (encoded_vectors_u8.rs:57-71): every rank's
+            # min / max over its own rows, folded by an all-reduce over the process group, then every rank quantises
+            # its shard (quantization_amd/sharded.py encode_u8; tests/test_sharded_encode_gloo.py: shard bytes and
+            # metadata equal the single-handle encode of the concatenated data)
+            from quantization_amd.sharded import encode_u8 as distributed_encode_u8
+            enc, _ = distributed_encode_u8(dist, torch, data, qa.VectorParameters(dim, total_rows, dtype, False))
+            dist_info["encode"] = "distributed: per-rank find_min_max + all-reduce of the interval over the process group"
+        else:
+            enc = qa.EncodedVectorsU8.encode(data, vp)
         queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
         del data  # stays in torch's caching allocator on purpose: returning the 30.7 GB block to the
         # driver (empty_cache) measured 3.5 % SLOWER scans afterwards on the same box (1.171 vs 1.131 ms,
@@ -488,9 +522,8 @@ def main():
         del rows
         queries = torch.rand((args.queries, dim), generator=qgen, device=dev, dtype=torch.float32)
         bytes_per_row = m
-        pq_skew = m % 32 == 0 and m <= 128 and os.environ.get("QAMD_PQ_SKEW", "1")[:1] != "0"  # csrc/pq.hip skew_capable()
-        kernel_name = "pq_scan_skew_kernel" if pq_skew else "pq_scan_fast_kernel"
-    args.no_cpu_baseline = args.no_cpu_baseline or args.quantizer != "u8"
+        kernel_name, pq_launches = enc.scan_kernel()  # the library says which scan kernel this store takes
+        pq_skew = kernel_name.startswith("pq_scan_skew_kernel")
     scaling_field = "weak" if (world == 1 or scaling == "weak") else "strong"
     # (at N = 1 there is nothing to scale; the contract's field keeps its default)
 
@@ -541,9 +574,33 @@ def main():
             ad = dim if is_bin else enc.metadata["actual_dim"]  # binary: one 0/1 operand byte per bit on the matrix cores
             ops = 2.0 * Q * n * ad  # per GPU and step
             # binary batches of 129+ queries on rows of 4 / 6 / 8 / 12 128-bit words take the fp4 matrix-core kernel (csrc/bin.hip)
-            bin_fp4 = is_bin and Q >= 129 and (ad + 127) // 128 in (4, 6, 8, 12) and os.environ.get("QAMD_BIN4", "1") != "0"
+            bin_fp4 = is_bin and Q >= 129 and (ad + 127) // 128 in (4, 6, 8, 12)
             mfma_peak = MFMA_FP4_PEAK_TOPS if bin_fp4 else MFMA_INT8_PEAK_TOPS
             per_gpu_tops = ops * args.steps / elapsed / 1e12
+            row_bytes = nb if is_bin else bytes_per_row
+            traffic, source = pmc_traffic(f"{'bin' if is_bin else 'u8'}_batch{Q}_{dim}", n, n * row_bytes)
+            cpu = None
+            if world == 1 and not args.no_cpu_baseline:
+                # the reference has no batched form: a batch of Q queries is Q passes of its caller loop, timed here for
+                # one query of the batch over a bounded sample of the store's own rows; the batch's top-k for that query
+                # is checked against the top-k of the CPU's scores when the sample is the whole store
+                try:
+                    dist_id = 0 if args.distance == "dot" else 2
+                    q0 = enc.encode_query(bq[0])
+                    full = enc.score_all(q0, out=torch.empty(n, dtype=torch.float32, device=dev)).cpu().numpy()
+                    S = min(n, args.cpu_sample_rows or n, 10_000_000)
+                    cpu = cpu_baseline(args.quantizer, enc, bq[0].cpu().numpy(), full, dist_id, S, args.pq_chunk)
+                    cpu["unit"] = "pairs/s"
+                    cpu["sample"] = (f"ONE query of the batch (the CPU path scores a batch as {Q} such passes: pairs/s is "
+                                     f"the same figure); ") + cpu["sample"]
+                    enc.topk_batch(batch, k, largest=True, out_ids=ids, out_scores=sc)
+                    got_ids = ids[:k].cpu().numpy().view(np.uint32)
+                    got_sc = sc[:k].cpu().numpy()
+                    order = np.lexsort((np.arange(n), -full))[:k]
+                    cpu["batch_topk_of_that_query_matches"] = bool(np.array_equal(got_sc.view(np.uint32), full[order].view(np.uint32))
+                                                                   and np.array_equal(np.sort(full[got_ids]), np.sort(full[order])))
+                except Exception as e:
+                    cpu = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
             print(json.dumps({
                 "metric": f"(query, vector) pairs scored/sec, {Q} queries x {total_rows}x{dim} {args.quantizer} dot, top-{k} each",
                 "value": float(Q) * total_rows * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
@@ -557,9 +614,12 @@ def main():
                                        f"on the GPU",
                            "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows, **dist_info},
                 "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": mfma_peak, "unit": "TFLOP/s",
-                             "frac": per_gpu_tops / mfma_peak, "traffic": None,
+                             "frac": per_gpu_tops / mfma_peak, "traffic": traffic, "traffic_source": source,
+                             "algorithmic_read_bytes_per_step": n * row_bytes,
                              "note": ("fp4" if bin_fp4 else "int8") + " op/s per GPU over the whole step (sample pass, filter GEMM, scatter, "
-                                     "sort, exchange); algorithmic ops = 2 * actual_dim per (query, row) pair"},
+                                     "sort, exchange); algorithmic ops = 2 * actual_dim per (query, row) pair; traffic = HBM bytes "
+                                     "of the step's dominant (filter) kernel: the store's rows leave HBM once per batch"},
+                "cpu_baseline": cpu,
             }), flush=True)
         if use_dist:
             dist.barrier()
@@ -693,7 +753,8 @@ def main():
                                  "note": "achieved = 4 B x m LUT gathers per row (ds_read_b32) against the conflict-free "
                                          "LDS rate of all CUs; random 8-bit codes give ~3.5-way bank conflicts, i.e. a "
                                          "practical ceiling near 0.29 of that peak"})
-        traffic, source = pmc_traffic(args.quantizer, n, bytes_per_row)
+        pmc_key = {"u8": "u8_scan", "binary": "bin_scan", "pq": f"pq_scan_m{bytes_per_row}"}[args.quantizer]
+        traffic, source = pmc_traffic(pmc_key, n, n * bytes_per_row)
         if traffic is not None:
             roofline["traffic"] = traffic
             roofline["traffic_source"] = source
@@ -753,8 +814,8 @@ def main():
                 full = enc.score_all(qobjs[0], out=torch.empty(n, dtype=torch.float32, device=dev))
                 torch.cuda.synchronize()
                 sample_rows = min(n, args.cpu_sample_rows or n, 10_000_000)
-                result["cpu_baseline"] = cpu_baseline(enc, queries.cpu().numpy(), full.cpu().numpy(),
-                                                      0 if args.distance == "dot" else 2, sample_rows)
+                result["cpu_baseline"] = cpu_baseline(args.quantizer, enc, queries[0].cpu().numpy(), full.cpu().numpy(),
+                                                      0 if args.distance == "dot" else 2, sample_rows, args.pq_chunk)
             except Exception as e:
                 result["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port",
                                           "sample": f"failed: {e}"}

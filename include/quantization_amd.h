@@ -140,6 +140,23 @@ QAMD_API qamd_status qamd_u8_encoder_push(qamd_u8_encoder *e, const float *batch
 QAMD_API qamd_status qamd_u8_encoder_finish(qamd_u8_encoder *e, qamd_u8 **out);
 QAMD_API void qamd_u8_encoder_abort(qamd_u8_encoder *e);
 
+/* The two global statistics of encode's pass 1 ON THEIR OWN, for a host that holds the rows in several places (one
+ * process per GPU, quantization_amd/sharded.py; the single-process qamd_u8_sharded_encode does the same inside).  The
+ * reference finds ONE (alpha, offset) over all data before any row is quantised (encoded_vectors_u8.rs:57-71):
+ *   - qamd_u8_find_min_max = find_min_max_from_iter (quantile.rs:5-19) over the caller's n_rows x dim values (NaN never
+ *     wins a compare; no rows: (f32::MAX, f32::MIN), the reference's start values).  Every holder runs it on its rows,
+ *     the holders fold the results with min / max - order-free, hence the bits of the single-handle encode - and hand
+ *     alpha_offset_from_min_max (encoded_vectors_u8.rs:228-232: alpha = (max - min) / 127.0f, offset = min) to
+ *     qamd_u8_encode / qamd_u8_encoder_begin as `alpha_offset`.
+ *   - qamd_u8_find_quantile_interval = find_quantile_interval (quantile.rs:21-71) over `count` vectors; *found = 0 is the
+ *     reference's None (keep the min / max interval).  Its sample is every vector for count <= 100 000 and the rows
+ *     floor(k * count / 100 000), k < 100 000, beyond (the reference draws a random one there): a distributed host
+ *     gathers exactly those rows, in k order, to one holder and calls this with count = the number gathered. */
+QAMD_API qamd_status qamd_u8_find_min_max(const float *data, qamd_mem data_mem, uint64_t n_rows, uint64_t dim,
+                                          void *stream, float *min, float *max);
+QAMD_API qamd_status qamd_u8_find_quantile_interval(const float *data, qamd_mem data_mem, uint64_t count, uint64_t dim,
+                                                    float quantile, void *stream, int *found, float *min, float *max);
+
 /* Adopt rows already in the reference's storage format — what
  * EncodedStorage::get_vector_data serves (encoded_storage.rs:27-31): count rows of
  * [vector_offset f32 ne][actual_dim codes].  Used by load and by callers holding a store
@@ -384,6 +401,17 @@ QAMD_API qamd_status qamd_pq_encoder_push(qamd_pq_encoder *e, const float *batch
                                           qamd_mem batch_mem);
 QAMD_API qamd_status qamd_pq_encoder_finish(qamd_pq_encoder *e, qamd_pq **out);
 QAMD_API void qamd_pq_encoder_abort(qamd_pq_encoder *e);
+
+/* find_centroids (encoded_vectors_pq.rs:278-342) ON ITS OWN: the 256 x dim centroids qamd_pq_encode would train for
+ * `data` (vp->count rows), written to host memory `centroids`.  For a host that holds the rows in several places: the
+ * k-means sample is the rows floor(k * count / S), k < S = min(10 000, count) (the reference draws a random Permutor
+ * sample, :300-307); the holders gather exactly those rows, in k order, to one of them, which calls this with
+ * vp->count = S and broadcasts the result; every holder then encodes its rows with `centroids` given.  count <= 256:
+ * the vectors themselves, zero-filled (:290-297).  iterations / empty_clusters as qamd_pq_kmeans_info (may be NULL). */
+QAMD_API qamd_status qamd_pq_find_centroids(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                                            uint64_t chunk_size, uint32_t max_kmeans_threads, qamd_stop_fn stop,
+                                            void *stop_user, void *stream, float *centroids, uint32_t *iterations,
+                                            uint32_t *empty_clusters);
 QAMD_API qamd_status qamd_pq_from_rows(const uint8_t *rows, qamd_mem rows_mem,
                                        const qamd_vector_parameters *vp, uint64_t chunk_size,
                                        const float *centroids, void *stream, qamd_pq **out);

@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
         u64, i32, f32, u32 = C.c_uint64, C.c_int, C.c_float, C.c_uint32
         sig = {
             "qo_find_min_max": (None, [vp, u64, vp, vp]),
+            "qo_u8_alpha_offset": (None, [f32, f32, vp, vp]),
             "qo_f32_to_u8": (C.c_uint8, [f32, f32, f32]),
             "qo_u8_actual_dim": (u64, [u64]),
             "qo_u8_quantized_vector_size": (u64, [u64]),
@@ -163,6 +164,32 @@ def u8_encode(data, distance: int, invert: bool, quantile: float | None = None):
     return rows, meta
 
 
+def find_min_max(values) -> tuple[np.float32, np.float32]:
+    """quantile.rs:5-19 find_min_max_from_iter over all values (no values: (f32::MAX, f32::MIN))."""
+    v = _f32(values).reshape(-1)
+    mn, mx = C.c_float(), C.c_float()
+    lib().qo_find_min_max(_p(v), v.size, C.byref(mn), C.byref(mx))
+    return np.float32(mn.value), np.float32(mx.value)
+
+
+def alpha_offset(mn, mx) -> tuple[np.float32, np.float32]:
+    """encoded_vectors_u8.rs:228-232 alpha_offset_from_min_max."""
+    a, o = C.c_float(), C.c_float()
+    lib().qo_u8_alpha_offset(C.c_float(mn), C.c_float(mx), C.byref(a), C.byref(o))
+    return np.float32(a.value), np.float32(o.value)
+
+
+def find_quantile_interval(data, quantile: float):
+    """quantile.rs:21-71 for count <= 100 000 (every vector is in the sample) -> (min, max) or None."""
+    data = _f32(data)
+    count, dim = data.shape
+    mn, mx = C.c_float(), C.c_float()
+    r = lib().qo_find_quantile_interval(_p(data), dim, count, C.c_float(quantile), C.byref(mn), C.byref(mx))
+    if r < 0:
+        raise ValueError("count > 100000: a random sample in the reference")
+    return (np.float32(mn.value), np.float32(mx.value)) if r == 1 else None
+
+
 def u8_encode_empty(dim: int, distance: int, invert: bool):
     rows = np.zeros((0, u8_actual_dim(dim) + 4), dtype=np.uint8)
     meta = Meta()
@@ -231,18 +258,18 @@ def bin_encode(data, store: int = STORE_U8) -> np.ndarray:
 
 
 def bin_score_all(rows, q, dim: int, distance: int, invert: bool, store: int = STORE_U8,
-                  use_ref: bool = False) -> np.ndarray:
+                  use_ref: bool = False, begin: int = 0, end: int | None = None) -> np.ndarray:
     rows = _u8(rows)
     q = _u8(q)
-    n = rows.shape[0]
-    out = np.zeros(n, dtype=np.float32)
+    n = rows.shape[0] if end is None else end
+    out = np.zeros(n - begin, dtype=np.float32)
     rp = None
     if use_ref:
         R = ref()
         if R is None:
             raise RuntimeError("oracle/_ref is not built")
         rp = C.cast(R.impl_xor_popcnt_sse_uint128, C.c_void_p)
-    lib().qo_bin_score_all(_p(rows), _p(q), dim, store, distance, int(invert), 0, n, rp, _p(out))
+    lib().qo_bin_score_all(_p(rows), _p(q), dim, store, distance, int(invert), begin, n, rp, _p(out))
     return out
 
 
@@ -284,12 +311,13 @@ def pq_encode_query(query, chunk_size: int, centroids, distance: int, invert: bo
     return lut
 
 
-def pq_score_all(rows, lut, order: int = ORDER_SSE) -> np.ndarray:
+def pq_score_all(rows, lut, order: int = ORDER_SSE, begin: int = 0, end: int | None = None) -> np.ndarray:
     rows = _u8(rows)
     lut = _f32(lut)
     n, m = rows.shape
-    out = np.zeros(n, dtype=np.float32)
-    lib().qo_pq_score_all(_p(rows), m, _p(lut), 0, n, order, _p(out))
+    n = n if end is None else end
+    out = np.zeros(n - begin, dtype=np.float32)
+    lib().qo_pq_score_all(_p(rows), m, _p(lut), begin, n, order, _p(out))
     return out
 
 

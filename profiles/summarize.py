@@ -4,7 +4,9 @@ profiles/.  Kernel names are shortened (torch's are kilobytes long).
 
     python profiles/summarize.py stats <kernel_stats.csv> <out.csv>
     python profiles/summarize.py pmc   <fetch_counter_collection.csv> <write_counter_collection.csv> \
-                                       <kernel-substring> <rows_per_launch> <row_read_bytes> <out.json> [commit]
+                                       <kernel-substring[|more]> <rows_per_launch> <row_read_bytes> <out.json> [commit] \
+                                       [key = u8_scan | bin_scan | pq_scan_m<m> | u8_batch<Q>_<dim> | bin_batch<Q>_<dim>] \
+                                       [launches per scan / step] [score bytes written per row]
     python profiles/summarize.py counters <counter_collection.csv> <kernel-substring> <out.txt> [more csv ...]
 (profiles/collect.sh and profiles/collect_batch.sh run them on the GPU box.)
 
@@ -22,17 +24,34 @@ def short(name: str, n: int = 110) -> str:
     return name if len(name) <= n else name[:n] + "..."
 
 
-def kernel_source_hash(root=None):
-    import os as _os
-    root = root or _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
-    """Hash of the part of csrc/u8.hip that defines u8_scan_kernel (device helpers + the kernel):
-    edits elsewhere in the file do not void a PMC profile of that kernel."""
+def kernel_source_hash(root=None, key="u8_scan"):
+    """Hash of the source that defines the profiled kernel: a PMC profile is quoted by bench.py only while it matches.
+      u8_scan        the part of csrc/u8.hip that defines u8_scan_kernel (device helpers + the kernel)
+      pq_scan_m<m>   the scan section of csrc/pq.hip (everything in front of the encode section)
+      bin_scan       csrc/bin.hip
+      u8_batch...    csrc/u8_batch.hip + batch_common.hpp;   bin_batch...   csrc/bin.hip + batch_common.hpp"""
     import hashlib
     import os
-    src = open(os.path.join(root, "quantization_amd", "csrc", "u8.hip"), "rb").read()
-    a = src.find(b"// ------------------------------------------------------------------------------ device helpers")
-    b = src.find(b"// NQ (2, 4, 8) queries per row read on the vector ALU")
-    region = src[a:b] if 0 <= a < b else src
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "quantization_amd", "csrc")
+    rd = lambda name: open(os.path.join(csrc, name), "rb").read()
+    if key == "u8_scan":
+        src = rd("u8.hip")
+        a = src.find(b"// ------------------------------------------------------------------------------ device helpers")
+        b = src.find(b"// NQ (2, 4, 8) queries per row read on the vector ALU")
+        region = src[a:b] if 0 <= a < b else src
+    elif key.startswith("pq_scan"):
+        src = rd("pq.hip")
+        b = src.find(b"// ------------------------------------------------------------------------------ encode")
+        region = src[:b] if b > 0 else src
+    elif key == "bin_scan":
+        region = rd("bin.hip")
+    elif key.startswith("u8_batch"):
+        region = rd("u8_batch.hip") + rd("batch_common.hpp")
+    elif key.startswith("bin_batch"):
+        region = rd("bin.hip") + rd("batch_common.hpp")
+    else:
+        raise ValueError(key)
     return hashlib.sha256(region).hexdigest()[:16]
 
 
@@ -79,35 +98,50 @@ def stats(src, dst):
                         r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 
-def pmc(fetch_csv, write_csv, needle, rows_per_launch, row_read_bytes, dst, commit="unknown"):
+def pmc(fetch_csv, write_csv, needle, rows_per_launch, row_read_bytes, dst, commit="unknown", key="u8_scan",
+        launches_per_unit=1, alg_write_bytes_per_row=4):
+    """`needle`: kernel-name substring(s), '|'-separated.  A unit (one scan of the store, one batch step) may be several
+    launches of the matching kernels (PQ rows of several LUT slices: one launch per slice): the bytes of all matching
+    launches are summed and divided by the number of units."""
+    needles = needle.split("|")
+
     def collect(path, counter):
         vals, durs = [], []
         for r in csv.DictReader(open(path)):
-            if needle in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if any(nd in r["Kernel_Name"] for nd in needles) and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
                 durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        return vals, durs
+        # the same kernel template also serves short helper passes (the batched top-k's pivot sample): only launches of
+        # at least half the longest one are the scan / the filter pass
+        keep = [i for i, d in enumerate(durs) if d >= 0.5 * max(durs)]
+        return [vals[i] for i in keep], [durs[i] for i in keep]
 
     fv, fd = collect(fetch_csv, "FETCH_SIZE")
     wv, _ = collect(write_csv, "WRITE_SIZE")
-    fetch_kib = sum(fv) / len(fv)
-    write_kib = sum(wv) / len(wv)
+    units_f, units_w = len(fv) / launches_per_unit, len(wv) / launches_per_unit
+    fetch_kib = sum(fv) / units_f
+    write_kib = sum(wv) / units_w
     read_bytes = fetch_kib * 1024 * 2
     write_bytes = write_kib * 1024
+    alg_read, alg_write = rows_per_launch * row_read_bytes, rows_per_launch * alg_write_bytes_per_row
     out = {
-        "kernel": needle, "rows_per_launch": rows_per_launch, "launches_sampled": len(fv),
+        "kernel": needle, "key": key, "rows_per_launch": rows_per_launch, "launches_sampled": len(fv),
+        "launches_per_unit": launches_per_unit,
         "FETCH_SIZE_KiB_mean": fetch_kib, "WRITE_SIZE_KiB_mean": write_kib,
         "read_bytes_per_launch": read_bytes,
-        "read_bytes_note": "FETCH_SIZE*1024*2 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream)",
+        "read_bytes_note": "FETCH_SIZE*1024*2 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream); per unit = all "
+                           "launches of one scan / one batch step",
         "write_bytes_per_launch": write_bytes,
         "traffic_bytes_per_launch": read_bytes + write_bytes,
-        "algorithmic_read_bytes_per_launch": rows_per_launch * row_read_bytes,
-        "algorithmic_write_bytes_per_launch": rows_per_launch * 4,
-        "traffic_over_algorithmic": (read_bytes + write_bytes) / (rows_per_launch * (row_read_bytes + 4)),
+        "algorithmic_read_bytes_per_launch": alg_read,
+        "algorithmic_write_bytes_per_launch": alg_write,
+        "read_over_algorithmic_read": read_bytes / alg_read,
+        "traffic_over_algorithmic": (read_bytes + write_bytes) / (alg_read + alg_write),
         "mean_kernel_ns_in_fetch_pass": sum(fd) / len(fd),
+        "kernel_ns_per_unit_in_fetch_pass": sum(fd) / units_f,
         # bench.py quotes this file as roofline.traffic only while the kernel source is the one profiled
         "commit": commit,
-        "kernel_source_sha256_16": kernel_source_hash(),
+        "kernel_source_sha256_16": kernel_source_hash(None, key),
     }
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
@@ -122,4 +156,5 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7],
-            sys.argv[8] if len(sys.argv) > 8 else "unknown")
+            sys.argv[8] if len(sys.argv) > 8 else "unknown", sys.argv[9] if len(sys.argv) > 9 else "u8_scan",
+            int(sys.argv[10]) if len(sys.argv) > 10 else 1, int(sys.argv[11]) if len(sys.argv) > 11 else 4)

@@ -171,6 +171,9 @@ def lib() -> C.CDLL:
         "qamd_pq_topk_batch": (i32, [vp, vp, u32, i32, vp, vp, i32, vp]),
         "qamd_pq_kmeans_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32)]),
         "qamd_pq_scan_kernel": (C.c_char_p, [vp, C.POINTER(u32)]),
+        "qamd_pq_find_centroids": (i32, [vp, i32, VP, u64, u32, STOP_FN, vp, vp, vp, C.POINTER(u32), C.POINTER(u32)]),
+        "qamd_u8_find_min_max": (i32, [vp, i32, u64, u64, vp, f32p, f32p]),
+        "qamd_u8_find_quantile_interval": (i32, [vp, i32, u64, u64, C.c_float, vp, C.POINTER(i32), f32p, f32p]),
         "qamd_pq_encoder_begin": (i32, [VP, u64, vp, u32, STOP_FN, vp, vp, pp]),
         "qamd_pq_encoder_observe": (i32, [vp, vp, u64, i32]),
         "qamd_pq_encoder_push": (i32, [vp, vp, u64, i32]),

@@ -2497,3 +2497,18 @@ qamd_status pq_train_centroids(const float *data, qamd_mem data_mem, const qamd_
 }
 
 }  // namespace qamd
+
+extern "C" qamd_status qamd_pq_find_centroids(const float *data, qamd_mem data_mem, const qamd_vector_parameters *vp,
+                                              uint64_t chunk_size, uint32_t max_kmeans_threads, qamd_stop_fn stop,
+                                              void *stop_user, void *stream, float *centroids, uint32_t *iterations,
+                                              uint32_t *empty_clusters) {
+    if (!vp || !centroids) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    if (chunk_size == 0) return fail(QAMD_ERR_ARGUMENTS, "chunk_size must be > 0");
+    if (vp->count > 0 && vp->dim > 0 && !data) return fail(QAMD_ERR_ARGUMENTS, "data is null");
+    QAMD_ON_DEVICE(current_device());
+    std::vector<float> cen;
+    QAMD_TRY(qamd::pq_train_centroids(data, data_mem, vp, chunk_size, max_kmeans_threads, stop, stop_user, as_stream(stream), cen,
+                                      iterations, empty_clusters));
+    memcpy(centroids, cen.data(), cen.size() * sizeof(float));
+    return QAMD_OK;
+}

@@ -1564,6 +1564,11 @@ qamd_status qamd_u8_encode(const float *data, qamd_mem data_mem, const qamd_vect
     QAMD_TRY(alloc_store(h.get()));
     if (vp->count == 0) {  // encoded_vectors_u8.rs:43-54
         h->meta.alpha = h->meta.offset = h->meta.multiplier = 0.0f;
+        if (alpha_offset) {  // an empty SHARD of a store whose interval was found elsewhere keeps that store's metadata
+            h->meta.alpha = alpha_offset[0];
+            h->meta.offset = alpha_offset[1];
+            h->meta.multiplier = host_multiplier(alpha_offset[0], vp->distance_type, vp->invert);
+        }
         *out = h.release();
         return QAMD_OK;
     }
@@ -2265,6 +2270,32 @@ qamd_status u8_quantile_interval(const float *data, qamd_mem mem, uint64_t count
     if (count < 127 || quantile >= 1.0f) return QAMD_OK;  // quantile.rs:27-29
     return quantile_interval_device(data, mem, count, dim, quantile, s, *found, *mn, *mx);
 }
+
+}  // namespace qamd
+
+extern "C" {
+
+qamd_status qamd_u8_find_min_max(const float *data, qamd_mem data_mem, uint64_t n_rows, uint64_t dim, void *stream,
+                                 float *min, float *max) {
+    if (!min || !max || (!data && n_rows && dim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_ON_DEVICE(current_device());
+    return qamd::u8_minmax_range(data, data_mem, n_rows, dim, as_stream(stream), min, max);
+}
+
+qamd_status qamd_u8_find_quantile_interval(const float *data, qamd_mem data_mem, uint64_t count, uint64_t dim,
+                                           float quantile, void *stream, int *found, float *min, float *max) {
+    if (!found || !min || !max || (!data && count && dim)) return fail(QAMD_ERR_ARGUMENTS, "null argument");
+    QAMD_ON_DEVICE(current_device());
+    bool f = false;
+    *min = *max = 0.0f;
+    QAMD_TRY(qamd::u8_quantile_interval(data, data_mem, count, dim, quantile, as_stream(stream), &f, min, max));
+    *found = f ? 1 : 0;
+    return QAMD_OK;
+}
+
+}  // extern "C"
+
+namespace qamd {
 
 qamd_status u8_encode_queries_device(const qamd_u8 *h, const float *queries_dev, uint64_t n_queries, uint64_t qdim,
                                      uint8_t *codes_dev, uint64_t code_pitch, float *offsets_dev, hipStream_t stream) {

@@ -134,6 +134,21 @@ class EncodedVectorsPQ(EncodedVectorsBase):
         check(_lib.lib().qamd_pq_kmeans_info(self._h, C.byref(it), C.byref(em)))
         return int(it.value), int(em.value)
 
+    @staticmethod
+    def find_centroids(rows, chunk_size: int, max_kmeans_threads: int = 1, stop_condition=None, stream=None) -> np.ndarray:
+        """find_centroids (encoded_vectors_pq.rs:278-342) on its own: the [256, dim] centroids `encode` would train for
+        `rows` ([n, dim] f32, host or HBM) - for callers that hold the data in several places
+        (quantization_amd.sharded.encode_pq gathers the k-means sample rows to one rank and broadcasts the result)."""
+        n, dim = int(rows.shape[0]), int(rows.shape[1])
+        vp = VectorParameters(dim, n, DistanceType.Dot, False).to_c()  # (the training does not depend on the metric)
+        buf = in_buf(rows, np.float32)
+        cen = np.empty((256, dim), dtype=np.float32)
+        stop = make_stop(stop_condition)
+        with creating_on(rows):
+            check(_lib.lib().qamd_pq_find_centroids(buf.ptr, buf.mem, C.byref(vp), int(chunk_size), int(max_kmeans_threads),
+                                                    stop, None, stream_ptr(stream), C.c_void_p(cen.ctypes.data), None, None))
+        return cen
+
     def scan_kernel(self) -> tuple[str, int]:
         """(name of the whole-store scan kernel this store takes, launches per scan) - for measurement harnesses."""
         n = C.c_uint32()

@@ -74,6 +74,28 @@ class EncodedVectorsU8(EncodedVectorsBase):
                                             stop, None, stream_ptr(stream), C.byref(out)))
         return cls(out, dev)
 
+    @staticmethod
+    def find_min_max(rows, stream=None) -> tuple[np.float32, np.float32]:
+        """find_min_max_from_iter (quantile.rs:5-19) over `rows` ([n, dim] f32, host or HBM) - pass 1 of `encode` on its
+        own, for callers that hold the data in several places (quantization_amd.sharded.encode_u8)."""
+        n, dim = (int(rows.shape[0]), int(rows.shape[1])) if len(rows.shape) == 2 else (0, 0)
+        buf = in_buf(rows, np.float32)
+        mn, mx = C.c_float(), C.c_float()
+        with creating_on(rows):
+            check(_lib.lib().qamd_u8_find_min_max(buf.ptr, buf.mem, n, dim, stream_ptr(stream), C.byref(mn), C.byref(mx)))
+        return np.float32(mn.value), np.float32(mx.value)
+
+    @staticmethod
+    def find_quantile_interval(rows, quantile: float, stream=None) -> tuple[np.float32, np.float32] | None:
+        """find_quantile_interval (quantile.rs:21-71) over `rows`; None as in the reference."""
+        n, dim = (int(rows.shape[0]), int(rows.shape[1])) if len(rows.shape) == 2 else (0, 0)
+        buf = in_buf(rows, np.float32)
+        found, mn, mx = C.c_int32(), C.c_float(), C.c_float()
+        with creating_on(rows):
+            check(_lib.lib().qamd_u8_find_quantile_interval(buf.ptr, buf.mem, n, dim, C.c_float(quantile), stream_ptr(stream),
+                                                            C.byref(found), C.byref(mn), C.byref(mx)))
+        return (np.float32(mn.value), np.float32(mx.value)) if found.value else None
+
     @classmethod
     def encode_stream(cls, make_batches, vector_parameters: VectorParameters, quantile: float | None = None,
                       stop_condition=None, *, alpha_offset: tuple[float, float] | None = None,

@@ -18,8 +18,15 @@ query, after the local scan:
 The single-PROCESS form of all this — one handle, one worker thread per GPU, peer copies instead
 of collectives — is `sharded_store.py` over `qamd_*_sharded_*`.
 
-The scoring itself is any object with the EncodedVectors API of this package; this module only
-does the index arithmetic and the collectives, so the CPU tests drive it with a stand-in scorer.
+`encode_u8` / `encode_pq` / `encode_binary` build such a sharded store from data that is ALREADY spread over the ranks
+(rank g holds rows [g*N/G, (g+1)*N/G) of the f32 input): the reference's `encode` finds its global statistics over all
+data before any row is quantised - ONE (alpha, offset) (encoded_vectors_u8.rs:57-71), ONE set of centroids
+(encoded_vectors_pq.rs:278-342) - so the ranks agree on them first (two tiny collectives, or a gather of the <= 100 000
+/ <= 10 000 sampled rows to rank 0 and a broadcast) and then every rank encodes its own rows.  Each rank's row bytes and
+metadata equal the single-handle encode of the concatenated data.
+
+The scoring and the local encoding are any object with the EncodedVectors API of this package; this module only does
+the index arithmetic and the collectives, so the CPU tests drive it with stand-in (oracle-backed) operations.
 """
 from __future__ import annotations
 
@@ -270,3 +277,176 @@ class ShardedTopKBatch:
         out_ids[~ok] = 0xFFFFFFFF
         out_sc[~ok] = -np.inf if largest else np.inf
         return out_ids, out_sc
+
+
+# ----------------------------------------------------------------------------------------------- distributed encode
+QUANTILE_SAMPLE_SIZE = 100_000  # quantile.rs:3
+KMEANS_SAMPLE_SIZE = 10_000     # encoded_vectors_pq.rs:22
+
+
+def sample_rows_of_shard(count: int, sample_size: int, begin: int, end: int) -> np.ndarray:
+    """LOCAL indices (ascending) of the sampled rows that fall into shard [begin, end): the sample of `count` rows is the
+    rows floor(k * count / S), k < S = min(sample_size, count) - every row when count <= sample_size - which is the rule of
+    the single-handle encoders (include/quantization_amd.h: qamd_u8_find_quantile_interval, qamd_pq_find_centroids; the
+    reference draws a random Permutor sample there)."""
+    S = min(sample_size, count)
+    if S == 0 or end <= begin:
+        return np.zeros(0, dtype=np.int64)
+    # smallest k with floor(k*count/S) >= begin is ceil(begin*S/count); the picks are ascending in k
+    k0 = (begin * S + count - 1) // count
+    k1 = min(S, (end * S + count - 1) // count)
+    ks = np.arange(k0, k1, dtype=np.uint64)
+    rows = (ks * np.uint64(count)) // np.uint64(S)
+    return rows.astype(np.int64) - begin
+
+
+def _f32_key(x) -> int:
+    """Order-preserving integer key of an f32 (-0.0 < +0.0): the min / max fold is then an integer all-reduce, whose result
+    does not depend on the backend's float min/max semantics."""
+    b = int(np.float32(x).view(np.uint32))
+    return b ^ 0xFFFFFFFF if b >> 31 else b | 0x80000000
+
+
+def _key_f32(k: int) -> np.float32:
+    b = (k & 0x7FFFFFFF) if k >> 31 else (k ^ 0xFFFFFFFF)
+    return np.uint32(b).view(np.float32)
+
+
+def alpha_offset_from_min_max(mn, mx) -> tuple[np.float32, np.float32]:
+    """encoded_vectors_u8.rs:228-232, in f32."""
+    with np.errstate(all="ignore"):
+        return np.float32((np.float32(mx) - np.float32(mn)) / np.float32(127.0)), np.float32(mn)
+
+
+class LibraryOps:
+    """The per-rank operations of the distributed encode through the C ABI (the product path; GPU).  The CPU tests pass an
+    object with the same methods backed by the oracle."""
+
+    def find_min_max(self, rows):
+        from .encoded_vectors_u8 import EncodedVectorsU8
+        return EncodedVectorsU8.find_min_max(rows)
+
+    def find_quantile_interval(self, rows, quantile):
+        from .encoded_vectors_u8 import EncodedVectorsU8
+        return EncodedVectorsU8.find_quantile_interval(rows, quantile)
+
+    def find_centroids(self, rows, chunk_size, max_kmeans_threads):
+        from .encoded_vectors_pq import EncodedVectorsPQ
+        return EncodedVectorsPQ.find_centroids(rows, chunk_size, max_kmeans_threads)
+
+    def encode_u8(self, rows, vp, alpha_offset):
+        from .encoded_vectors_u8 import EncodedVectorsU8
+        return EncodedVectorsU8.encode(rows, vp, alpha_offset=alpha_offset)
+
+    def encode_pq(self, rows, vp, chunk_size, centroids):
+        from .encoded_vectors_pq import EncodedVectorsPQ
+        return EncodedVectorsPQ.encode(rows, vp, chunk_size, centroids=centroids)
+
+    def encode_binary(self, rows, vp):
+        from .encoded_vectors_binary import EncodedVectorsBin
+        return EncodedVectorsBin.encode(rows, vp)
+
+
+def _coll_device(dist, torch, rows):
+    """Where the collectives' tensors live: HBM for nccl (= RCCL), host for gloo."""
+    if dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    if getattr(rows, "is_cuda", False):
+        return rows.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _local_vp(vp, n_local: int):
+    return type(vp)(vp.dim, n_local, vp.distance_type, vp.invert)
+
+
+def _gather_sample(dist, torch, local_rows, count: int, sample_size: int, dim: int, group=None):
+    """The sampled rows of the whole data set, in sample order, on rank 0 (None elsewhere): every rank contributes the
+    picks that fall into its shard (padded to the largest contribution: a gather wants equal sizes)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    picks = [sample_rows_of_shard(count, sample_size, *shard_range(count, r, world)) for r in range(world)]
+    mine = picks[rank]
+    dev = _coll_device(dist, torch, local_rows)
+    if hasattr(local_rows, "is_cuda"):  # torch tensor
+        part = local_rows.index_select(0, torch.from_numpy(mine).to(local_rows.device)).to(device=dev, dtype=torch.float32)
+    else:
+        part = torch.from_numpy(np.ascontiguousarray(np.asarray(local_rows, dtype=np.float32)[mine])).to(dev)
+    part = part.reshape(len(mine), dim)
+    pad = max(len(p) for p in picks)
+    if world == 1:
+        return part
+    send = torch.zeros((pad, dim), dtype=torch.float32, device=dev)
+    send[: len(mine)] = part
+    glist = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, gather_list=glist, dst=0, group=group)
+    if rank != 0:
+        return None
+    return torch.cat([g[: len(p)] for g, p in zip(glist, picks)])
+
+
+def encode_u8(dist, torch, local_rows, vector_parameters, quantile=None, *, ops=None, group=None):
+    """EncodedVectorsU8::encode (encoded_vectors_u8.rs:34-140) over rows spread across the ranks: `local_rows` is this
+    rank's shard [n_local, dim] (numpy or tensor, host or HBM) of the vector_parameters.count rows.  Returns
+    (this rank's encoded shard, (alpha, offset)).
+
+      pass 1   every rank: find_min_max over its rows (quantile.rs:5-19); one all-reduce of the two order-preserving
+               integer keys (min of mins, max of maxes: order-free, so the bits of the single-handle encode)
+      pass 1b  quantile given: the <= 100 000 sampled rows are gathered to rank 0, which runs find_quantile_interval
+               (quantile.rs:21-71); the interval (or "None") is broadcast
+      pass 2   every rank encodes its rows with the agreed (alpha, offset)."""
+    ops = ops or LibraryOps()
+    vp = vector_parameters
+    world = dist.get_world_size(group)
+    n_local = int(local_rows.shape[0])
+    if vp.count == 0:  # encoded_vectors_u8.rs:43-54
+        return ops.encode_u8(local_rows, _local_vp(vp, 0), None), (np.float32(0), np.float32(0))
+    dev = _coll_device(dist, torch, local_rows)
+    mn, mx = ops.find_min_max(local_rows)
+    keys = torch.tensor([_f32_key(mn), -_f32_key(mx)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+    kmin, kmax = (int(v) for v in keys.cpu().tolist())
+    alpha, offset = alpha_offset_from_min_max(_key_f32(kmin), _key_f32(-kmax))
+    if quantile is not None and not (vp.count < 127 or quantile >= 1.0):  # quantile.rs:27-29
+        sample = _gather_sample(dist, torch, local_rows, vp.count, QUANTILE_SAMPLE_SIZE, vp.dim, group)
+        res = torch.zeros(3, dtype=torch.float32, device=dev)
+        if dist.get_rank(group) == 0:
+            found = ops.find_quantile_interval(sample, quantile)
+            if found is not None:
+                res = torch.tensor([1.0, float(found[0]), float(found[1])], dtype=torch.float32, device=dev)
+        if world > 1:
+            dist.broadcast(res, src=0, group=group)
+        r = res.cpu().numpy()
+        if r[0] != 0:
+            alpha, offset = alpha_offset_from_min_max(r[1], r[2])
+    enc = ops.encode_u8(local_rows, _local_vp(vp, n_local), (float(alpha), float(offset)))
+    return enc, (alpha, offset)
+
+
+def encode_pq(dist, torch, local_rows, vector_parameters, chunk_size: int, max_kmeans_threads: int = 1, *,
+              centroids=None, ops=None, group=None):
+    """EncodedVectorsPQ::encode (encoded_vectors_pq.rs:56-107) over rows spread across the ranks.  find_centroids
+    (:278-342) needs the <= 10 000 sampled rows in one place: they are gathered to rank 0, which trains (k-means in the
+    reference's summation order, csrc/pq.hip) and broadcasts the 256 x dim centroids; every rank then runs
+    encode_storage (:136-226) on its own rows.  Returns (this rank's encoded shard, centroids)."""
+    ops = ops or LibraryOps()
+    vp = vector_parameters
+    world = dist.get_world_size(group)
+    dev = _coll_device(dist, torch, local_rows)
+    if centroids is None:
+        sample = _gather_sample(dist, torch, local_rows, vp.count, KMEANS_SAMPLE_SIZE, vp.dim, group)
+        cen = torch.zeros((256, vp.dim), dtype=torch.float32, device=dev)
+        if dist.get_rank(group) == 0:
+            cen = torch.from_numpy(np.ascontiguousarray(ops.find_centroids(sample, chunk_size, max_kmeans_threads),
+                                                        dtype=np.float32)).to(dev)
+        if world > 1:
+            dist.broadcast(cen, src=0, group=group)
+        centroids = cen.cpu().numpy()
+    enc = ops.encode_pq(local_rows, _local_vp(vp, int(local_rows.shape[0])), chunk_size, centroids)
+    return enc, centroids
+
+
+def encode_binary(dist, torch, local_rows, vector_parameters, *, ops=None, group=None):
+    """EncodedVectorsBin::encode (encoded_vectors_binary.rs:165-191) has no global statistic: every rank packs its rows."""
+    ops = ops or LibraryOps()
+    return ops.encode_binary(local_rows, _local_vp(vector_parameters, int(local_rows.shape[0])))

@@ -32,19 +32,21 @@ def test_bench_single_gpu_line(extra):
         assert key in j, key
     assert j["n_gpus"] == 1 and j["steps"] == 5 and j["value"] > 0
     rf = j["roofline"]
-    # PQ: m = 96 takes the conflict-free scan (HBM is its roofline again); m = 192 the sliced one, bound by LDS bank conflicts
-    gather_bound = "--pq-chunk" in extra
-    assert rf["bound"] == ("lds" if gather_bound else "hbm") and 0 < rf["frac"] < 1.2
+    # PQ: m = 96 takes the conflict-free scan; m = 192 (--pq-chunk 4) the same kernel per LUT slice of the planar scan
+    # image (round 3: pq_scan_fast_kernel, bound by LDS bank conflicts): HBM is the roofline of both
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1.2
     assert rf["kernel_ms_min"] <= rf["kernel_ms_median"] and rf["kernel_ms_mean"] == rf["kernel_ms"]
-    if gather_bound:
-        assert 0 < rf["hbm_frac"] < 1.2 and rf["kernel"] == "pq_scan_fast_kernel"
-    elif "pq" in extra:
-        assert rf["kernel"] == "pq_scan_skew_kernel" and 0 < rf["lds_gather_frac_of_conflict_free_peak"] < 1.0
-    if not extra:
-        cb = j["cpu_baseline"]
-        assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("reference", "port")
-        assert cb["gpu_matches_cpu_bits"] is True
-        assert cb["all_cores"]["value"] > 0
+    if "pq" in extra:
+        assert rf["kernel"] == ("pq_scan_skew_kernel<SLICED>" if "--pq-chunk" in extra else "pq_scan_skew_kernel")
+        assert 0 < rf["lds_gather_frac_of_conflict_free_peak"] < 1.0
+    # every quantizer's line carries the CPU baseline: the reference's compiled kernels for u8 and binary, the oracle's
+    # restatement of score_point_sse for PQ; all GPU scores of the sample equal the CPU's bit for bit
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("reference", "port")
+    assert cb["gpu_matches_cpu_bits"] is True
+    assert cb["all_cores"]["value"] > 0
+    if "pq" in extra:
+        assert cb["kind"] == "port"
 
 
 def test_bench_rccl_code_path_on_one_gpu():
@@ -106,6 +108,10 @@ def test_bench_batched_topk_mode(ranks):
     assert j["n_gpus"] == ranks and j["unit"] == "pairs/s" and j["value"] > 0
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     assert j["config"]["total_rows"] == 1200000  # strong scaling: the store is fixed, the ranks split it
+    if ranks == 1:  # one query of the batch through the reference's per-query loop on the CPU; its top-k checked
+        cb = j["cpu_baseline"]
+        assert cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["gpu_matches_cpu_bits"] is True
+        assert cb["batch_topk_of_that_query_matches"] is True
 
 
 def test_bench_starts_its_own_ranks_without_torchrun():
