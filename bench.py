@@ -242,7 +242,7 @@ def pmc_traffic(key, n, read_bytes_per_launch_unit):
         return None, None
     finally:
         sys.path.pop(0)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{key}.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{key}*.json")), reverse=True):
         try:
             j = json.load(open(path))
         except Exception:

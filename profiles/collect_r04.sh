@@ -9,7 +9,7 @@ run() { n=$1; if [ -z "$sel" ] || [[ " $sel " == *" $n "* ]]; then bash profiles
 #   name        key                 needle                         rows      row B  launches  score B -- bench args
 run u8          u8_scan             u8_scan_kernel                 10000000  772    1 4 --
 run u8l2        u8_scan             u8_scan_kernel                 10000000  772    1 4 -- --distance l2
-run u8_1536     u8_scan             u8_scan_kernel                 12500000  1540   1 4 -- --dim 1536 --rows 12500000
+run u8_1536     u8_scan_1536        u8_scan_kernel                 12500000  1540   1 4 -- --dim 1536 --rows 12500000
 run bin         bin_scan            bin_scan_kernel                50000000  128    1 4 -- --quantizer binary --dim 1024 --rows 50000000
 run pq          pq_scan_m96         pq_scan_skew_kernel            10000000  96     1 4 -- --quantizer pq
 run pq192       pq_scan_m192        pq_scan_skew_kernel            12500000  192    2 4 -- --quantizer pq --dim 1536 --rows 12500000

@@ -35,7 +35,7 @@ def kernel_source_hash(root=None, key="u8_scan"):
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "quantization_amd", "csrc")
     rd = lambda name: open(os.path.join(csrc, name), "rb").read()
-    if key == "u8_scan":
+    if key.startswith("u8_scan"):
         src = rd("u8.hip")
         a = src.find(b"// ------------------------------------------------------------------------------ device helpers")
         b = src.find(b"// NQ (2, 4, 8) queries per row read on the vector ALU")
@@ -44,7 +44,7 @@ def kernel_source_hash(root=None, key="u8_scan"):
         src = rd("pq.hip")
         b = src.find(b"// ------------------------------------------------------------------------------ encode")
         region = src[:b] if b > 0 else src
-    elif key == "bin_scan":
+    elif key.startswith("bin_scan"):
         region = rd("bin.hip")
     elif key.startswith("u8_batch"):
         region = rd("u8_batch.hip") + rd("batch_common.hpp")
