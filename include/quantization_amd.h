@@ -500,7 +500,21 @@ QAMD_API qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_ba
  * synchronised on entry when a buffer of the call is device memory (the workers run on their own
  * streams, which nothing else orders against the caller's); ignored for host buffers.  At return
  * every output is complete.
+ * Deployment knob: the environment variable QAMD_SHARD_LANES (1..8, default 3) is the number of worker threads
+ * ("lanes") per shard, read once per process: while one lane waits for its kernel the others enqueue.  It is the
+ * only environment variable the product library reads.
+ * Peer access: the exchanges between a shard's device and devices[0] are device-to-device copies.  At construction
+ * the handle tries hipDeviceEnablePeerAccess in both directions for every such pair and RECORDS the outcome
+ * (qamd_*_sharded_peer_access); where it is unavailable or fails the same hipMemcpyAsync calls still work, staged
+ * through host memory by the runtime - slower, never wrong.
  * =================================================================================== */
+/* How shard g's device reaches devices[0] (qamd_*_sharded_peer_access): */
+typedef enum {
+    QAMD_PEER_SAME_DEVICE = 0, /* the shard lives on devices[0] itself (or is a logical shard of it) */
+    QAMD_PEER_ENABLED = 1,     /* direct peer copies (xGMI) in both directions */
+    QAMD_PEER_UNAVAILABLE = 2, /* hipDeviceCanAccessPeer said no: copies are staged by the runtime */
+    QAMD_PEER_FAILED = 3       /* hipDeviceEnablePeerAccess failed (*reason = the HIP error): staged copies */
+} qamd_peer_state;
 typedef struct qamd_u8_sharded qamd_u8_sharded;
 typedef struct qamd_u8_sharded_query qamd_u8_sharded_query;
 typedef struct qamd_u8_sharded_query_batch qamd_u8_sharded_query_batch;
@@ -516,6 +530,8 @@ QAMD_API qamd_status qamd_u8_sharded_from_rows(const uint8_t *rows, qamd_mem row
                                                uint32_t n_shards, void *stream,
                                              qamd_u8_sharded **out);
 QAMD_API uint32_t qamd_u8_sharded_shard_count(const qamd_u8_sharded *h);
+/* *state = a qamd_peer_state for shard g; *reason (may be NULL) = a static or handle-owned string saying why. */
+QAMD_API qamd_status qamd_u8_sharded_peer_access(const qamd_u8_sharded *h, uint32_t g, int *state, const char **reason);
 /* Borrow shard g (owned by the sharded handle): its single-device handle, first global row, device. */
 QAMD_API qamd_status qamd_u8_sharded_shard(const qamd_u8_sharded *h, uint32_t g, const qamd_u8 **shard,
                                            uint64_t *row_begin, int *device);
@@ -552,6 +568,8 @@ QAMD_API qamd_status qamd_bin_sharded_from_rows(const uint8_t *rows, qamd_mem ro
                                                 const int *devices, uint32_t n_shards, void *stream,
                                              qamd_bin_sharded **out);
 QAMD_API uint32_t qamd_bin_sharded_shard_count(const qamd_bin_sharded *h);
+/* *state = a qamd_peer_state for shard g; *reason (may be NULL) = a static or handle-owned string saying why. */
+QAMD_API qamd_status qamd_bin_sharded_peer_access(const qamd_bin_sharded *h, uint32_t g, int *state, const char **reason);
 QAMD_API qamd_status qamd_bin_sharded_shard(const qamd_bin_sharded *h, uint32_t g, const qamd_bin **shard,
                                             uint64_t *row_begin, int *device);
 QAMD_API qamd_status qamd_bin_sharded_encode_query(qamd_bin_sharded *h, const float *query, uint64_t qdim,
@@ -589,6 +607,8 @@ QAMD_API qamd_status qamd_pq_sharded_from_rows(const uint8_t *rows, qamd_mem row
                                                uint32_t n_shards, void *stream,
                                              qamd_pq_sharded **out);
 QAMD_API uint32_t qamd_pq_sharded_shard_count(const qamd_pq_sharded *h);
+/* *state = a qamd_peer_state for shard g; *reason (may be NULL) = a static or handle-owned string saying why. */
+QAMD_API qamd_status qamd_pq_sharded_peer_access(const qamd_pq_sharded *h, uint32_t g, int *state, const char **reason);
 QAMD_API qamd_status qamd_pq_sharded_shard(const qamd_pq_sharded *h, uint32_t g, const qamd_pq **shard,
                                            uint64_t *row_begin, int *device);
 QAMD_API qamd_status qamd_pq_sharded_get_centroids(const qamd_pq_sharded *h, float *centroids);

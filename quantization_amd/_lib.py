@@ -183,6 +183,7 @@ def lib() -> C.CDLL:
         "qamd_u8_sharded_encode": (i32, [vp, i32, VP, f32p, f32p, STOP_FN, vp, C.POINTER(i32), u32, vp, pp]),
         "qamd_u8_sharded_from_rows": (i32, [vp, i32, C.POINTER(U8MetadataC), C.POINTER(i32), u32, vp, pp]),
         "qamd_u8_sharded_shard_count": (u32, [vp]),
+        "qamd_u8_sharded_peer_access": (i32, [vp, u32, C.POINTER(i32), C.POINTER(C.c_char_p)]),
         "qamd_u8_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
         "qamd_u8_sharded_get_metadata": (i32, [vp, C.POINTER(U8MetadataC)]),
         "qamd_u8_sharded_encode_query": (i32, [vp, vp, u64, i32, vp, pp]),
@@ -196,6 +197,7 @@ def lib() -> C.CDLL:
         "qamd_bin_sharded_encode": (i32, [vp, i32, VP, i32, STOP_FN, vp, C.POINTER(i32), u32, vp, pp]),
         "qamd_bin_sharded_from_rows": (i32, [vp, i32, VP, i32, C.POINTER(i32), u32, vp, pp]),
         "qamd_bin_sharded_shard_count": (u32, [vp]),
+        "qamd_bin_sharded_peer_access": (i32, [vp, u32, C.POINTER(i32), C.POINTER(C.c_char_p)]),
         "qamd_bin_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
         "qamd_bin_sharded_encode_query": (i32, [vp, vp, u64, i32, vp, pp]),
         "qamd_bin_sharded_query_free": (None, [vp]),
@@ -208,6 +210,7 @@ def lib() -> C.CDLL:
         "qamd_pq_sharded_encode": (i32, [vp, i32, VP, u64, vp, u32, STOP_FN, vp, C.POINTER(i32), u32, vp, pp]),
         "qamd_pq_sharded_from_rows": (i32, [vp, i32, VP, u64, vp, C.POINTER(i32), u32, vp, pp]),
         "qamd_pq_sharded_shard_count": (u32, [vp]),
+        "qamd_pq_sharded_peer_access": (i32, [vp, u32, C.POINTER(i32), C.POINTER(C.c_char_p)]),
         "qamd_pq_sharded_shard": (i32, [vp, u32, pp, C.POINTER(u64), C.POINTER(i32)]),
         "qamd_pq_sharded_get_centroids": (i32, [vp, vp]),
         "qamd_pq_sharded_encode_query": (i32, [vp, vp, u64, i32, vp, pp]),

@@ -794,10 +794,14 @@ qamd_status qamd_bin_save(const qamd_bin *h, const char *data_path, const char *
 qamd_status qamd_bin_load(const char *data_path, const char *meta_path, const qamd_vector_parameters *vp,
                           qamd_bits_store store, qamd_bin **out) {
     if (!data_path || !meta_path || !vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    std::string js;
-    if (!read_file(meta_path, js)) return fail(QAMD_ERR_IO, "cannot read %s", meta_path);
+    JsonValue root;
+    QAMD_TRY(read_metadata(meta_path, root));
     qamd_vector_parameters file_vp{};
-    if (!parse_vector_parameters(js, file_vp)) return fail(QAMD_ERR_IO, "malformed metadata in %s", meta_path);
+    {   // Metadata{vector_parameters} (encoded_vectors_binary.rs:21-24)
+        std::string err;
+        const JsonValue *vpj = json_field(root, "vector_parameters", err);
+        if (!vpj || !parse_vector_parameters(*vpj, file_vp, err)) return fail(QAMD_ERR_IO, "%s: %s", meta_path, err.c_str());
+    }
     std::string bytes;
     if (!read_file(data_path, bytes)) return fail(QAMD_ERR_IO, "cannot read %s", data_path);
     const uint64_t expected = row_bytes_of(vp->dim, store) * vp->count;  // :277-279

@@ -404,11 +404,16 @@ void thread_ws_release(ThreadWsSlot slot, hipStream_t s, bool synced) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return;
     ThreadWs &w = thread_state().at(dev, slot);
-    w.in_flight = false;
-    if (synced) return;
+    if (synced) {
+        w.in_flight = false;
+        return;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+    // A captured call launches nothing now: whatever an EARLIER enqueue-only call of this thread left in flight (its
+    // event, in_flight) is still the state the next eager call must wait for - leave both untouched.
     if (cap != hipStreamCaptureStatusNone) return;
+    w.in_flight = false;
     if (!w.done && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) {
         w.done = nullptr;
         (void)hipGetLastError();
@@ -438,15 +443,28 @@ const DeviceInfo &device_info() {
 // ---------------------------------------------------------------------------------- JSON
 std::string json_f32(float v) {
     if (!std::isfinite(v)) return "null";  // serde_json writes null for NaN/inf
+    // serde_json prints floats with ryu: the shortest decimal digits that read back as the same f32, laid out as
+    // 12340000000.0 / 12.34 / 0.001234 while -6 < decimal exponent <= 13 and as 1e30 / 1.234e33 outside (ryu's
+    // pretty::format32).  Same bytes as the reference's save() for every finite value.
+    std::string sign = std::signbit(v) ? "-" : "";
+    if (v == 0.0f) return sign + "0.0";
     char buf[64];
-    for (int p = 1; p <= 9; p++) {
-        snprintf(buf, sizeof buf, "%.*g", p, (double)v);
-        if (strtof(buf, nullptr) == v) break;
+    const double a = std::fabs((double)v);
+    for (int p = 0; p <= 8; p++) {
+        snprintf(buf, sizeof buf, "%.*e", p, a);
+        if (strtof(buf, nullptr) == std::fabs(v)) break;
     }
-    std::string s(buf);
-    // serde_json (ryu) always prints a fraction or exponent for floats: 1 -> 1.0
-    if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
-    return s;
+    std::string digits;
+    const char *e = strchr(buf, 'e');
+    for (const char *c = buf; c < e; c++)
+        if (*c != '.') digits += *c;
+    const int exp10 = atoi(e + 1), length = (int)digits.size();
+    const int kk = exp10 + 1, k = kk - length;  // value = digits * 10^k, 10^(kk-1) <= value < 10^kk
+    if (0 <= k && kk <= 13) return sign + digits + std::string((size_t)k, '0') + ".0";
+    if (0 < kk && kk <= 13) return sign + digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+    if (-6 < kk && kk <= 0) return sign + "0." + std::string((size_t)(-kk), '0') + digits;
+    if (length == 1) return sign + digits + "e" + std::to_string(kk - 1);
+    return sign + digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1);
 }
 
 bool read_file(const char *path, std::string &out) {
@@ -481,50 +499,11 @@ void make_parent_dirs(const char *path) {
     }
 }
 
-static size_t json_value_pos(const std::string &s, const char *key) {
-    std::string k = std::string("\"") + key + "\"";
-    size_t p = s.find(k);
-    if (p == std::string::npos) return p;
-    p = s.find(':', p + k.size());
-    if (p == std::string::npos) return p;
-    p++;
-    while (p < s.size() && (s[p] == ' ' || s[p] == '\n' || s[p] == '\t' || s[p] == '\r')) p++;
-    return p;
-}
-
-bool json_find_number(const std::string &s, const char *key, double &out) {
-    size_t p = json_value_pos(s, key);
-    if (p == std::string::npos) return false;
-    if (s.compare(p, 4, "null") == 0) {
-        out = NAN;
-        return true;
-    }
-    char *end = nullptr;
-    out = strtod(s.c_str() + p, &end);
-    return end != s.c_str() + p;
-}
-
-bool json_find_string(const std::string &s, const char *key, std::string &out) {
-    size_t p = json_value_pos(s, key);
-    if (p == std::string::npos || s[p] != '"') return false;
-    size_t e = s.find('"', p + 1);
-    if (e == std::string::npos) return false;
-    out = s.substr(p + 1, e - p - 1);
-    return true;
-}
-
-bool json_find_bool(const std::string &s, const char *key, bool &out) {
-    size_t p = json_value_pos(s, key);
-    if (p == std::string::npos) return false;
-    if (s.compare(p, 4, "true") == 0) {
-        out = true;
-        return true;
-    }
-    if (s.compare(p, 5, "false") == 0) {
-        out = false;
-        return true;
-    }
-    return false;
+qamd_status read_metadata(const char *meta_path, JsonValue &root) {
+    std::string js, err;
+    if (!read_file(meta_path, js)) return fail(QAMD_ERR_IO, "cannot read %s", meta_path);
+    if (!json_parse(js, root, err)) return fail(QAMD_ERR_IO, "%s: %s", meta_path, err.c_str());
+    return QAMD_OK;
 }
 
 const char *distance_name(int d) { return d == QAMD_DOT ? "Dot" : d == QAMD_L1 ? "L1" : "L2"; }
@@ -546,19 +525,20 @@ std::string vector_parameters_json(const qamd_vector_parameters &vp) {
     return buf;
 }
 
-bool parse_vector_parameters(const std::string &json, qamd_vector_parameters &vp) {
-    size_t p = json.find("\"vector_parameters\"");
-    std::string sub = p == std::string::npos ? json : json.substr(p);
-    double dim, count;
+bool parse_vector_parameters(const JsonValue &obj, qamd_vector_parameters &vp, std::string &err) {
+    uint64_t dim = 0, count = 0;
     std::string dist;
-    bool inv;
-    if (!json_find_number(sub, "dim", dim) || !json_find_number(sub, "count", count) ||
-        !json_find_string(sub, "distance_type", dist) || !json_find_bool(sub, "invert", inv))
+    bool inv = false;
+    if (!json_usize(obj, "dim", dim, err) || !json_usize(obj, "count", count, err) ||
+        !json_string(obj, "distance_type", dist, err) || !json_bool(obj, "invert", inv, err))
         return false;
-    int d;
-    if (!parse_distance(dist, d)) return false;
-    vp.dim = (uint64_t)dim;
-    vp.count = (uint64_t)count;
+    int d = 0;
+    if (!parse_distance(dist, d)) {
+        err = "unknown variant `" + dist + "`, expected one of `Dot`, `L1`, `L2`";
+        return false;
+    }
+    vp.dim = dim;
+    vp.count = count;
     vp.distance_type = d;
     vp.invert = inv ? 1 : 0;
     return true;

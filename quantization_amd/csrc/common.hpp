@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include "json.hpp"
+
 #include "../../include/quantization_amd.h"
 
 namespace qamd {
@@ -238,19 +240,19 @@ const DeviceInfo &device_info();  // of the current device
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
-// Minimal JSON helpers for the serde_json metadata files (save/load).
+// serde_json metadata files (save / load): the writer's float formatting, file helpers, and the reader (json.hpp).
 std::string json_f32(float v);
 bool read_file(const char *path, std::string &out);
 bool write_file(const char *path, const void *data, size_t bytes);
 void make_parent_dirs(const char *path);
-// Finds `"key":` at any depth and parses the scalar after it.
-bool json_find_number(const std::string &s, const char *key, double &out);
-bool json_find_string(const std::string &s, const char *key, std::string &out);
-bool json_find_bool(const std::string &s, const char *key, bool &out);
+// Reads and parses a metadata file; QAMD_ERR_IO (std::io::Error in the reference: read_to_string / serde_json::from_str,
+// encoded_vectors_u8.rs:278-279) with the reader's message when it cannot.
+qamd_status read_metadata(const char *meta_path, JsonValue &root);
 
 const char *distance_name(int d);
 bool parse_distance(const std::string &s, int &d);
 std::string vector_parameters_json(const qamd_vector_parameters &vp);
-bool parse_vector_parameters(const std::string &json, qamd_vector_parameters &vp);
+// `obj`: the VectorParameters struct of a metadata file (encoded_vectors.rs:13-19), any key order
+bool parse_vector_parameters(const JsonValue &obj, qamd_vector_parameters &vp, std::string &err);
 
 }  // namespace qamd

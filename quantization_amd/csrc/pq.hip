@@ -1847,51 +1847,48 @@ qamd_status qamd_pq_save(const qamd_pq *h, const char *data_path, const char *me
 qamd_status qamd_pq_load(const char *data_path, const char *meta_path, const qamd_vector_parameters *vp,
                          qamd_pq **out) {
     if (!data_path || !meta_path || !vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    std::string js;
-    if (!read_file(meta_path, js)) return fail(QAMD_ERR_IO, "cannot read %s", meta_path);
+    JsonValue root;
+    QAMD_TRY(read_metadata(meta_path, root));
     qamd_vector_parameters file_vp{};
-    if (!parse_vector_parameters(js, file_vp)) return fail(QAMD_ERR_IO, "malformed metadata in %s", meta_path);
-    // centroids: 256 arrays of dim numbers
-    size_t p = js.find("\"centroids\"");
-    if (p == std::string::npos) return fail(QAMD_ERR_IO, "metadata has no centroids");
-    p = js.find('[', p);
     std::vector<float> cen;
-    cen.reserve((size_t)kCentroids * file_vp.dim);
-    int depth = 0;
-    size_t i = p;
-    for (; i < js.size(); i++) {
-        const char ch = js[i];
-        if (ch == '[') depth++;
-        else if (ch == ']') {
-            if (--depth == 0) break;
-        } else if (ch == '-' || ch == 'n' || (ch >= '0' && ch <= '9')) {
-            if (ch == 'n') {
-                cen.push_back(NAN);
-                i += 3;
-            } else {
-                char *end = nullptr;
-                cen.push_back(strtof(js.c_str() + i, &end));
-                i = (size_t)(end - js.c_str()) - 1;
+    uint64_t m = 0, chunk_size = 0;
+    {   // Metadata{centroids: Vec<Vec<f32>>, vector_division: Vec<Range<usize>>, vector_parameters} (:39-44), any key order
+        std::string err;
+        const JsonValue *vpj = json_field(root, "vector_parameters", err);
+        if (!vpj || !parse_vector_parameters(*vpj, file_vp, err)) return fail(QAMD_ERR_IO, "%s: %s", meta_path, err.c_str());
+        const JsonValue *cj = json_field(root, "centroids", err);
+        if (!cj) return fail(QAMD_ERR_IO, "%s: %s", meta_path, err.c_str());
+        if (cj->kind != JsonValue::Array) return fail(QAMD_ERR_IO, "%s: centroids: expected a sequence", meta_path);
+        if (cj->items.size() != (size_t)kCentroids)
+            return fail(QAMD_ERR_IO, "%s: metadata holds %zu centroids, expected %d", meta_path, cj->items.size(), kCentroids);
+        cen.reserve((size_t)kCentroids * file_vp.dim);
+        for (const JsonValue &row : cj->items) {
+            if (row.kind != JsonValue::Array || row.items.size() != file_vp.dim)
+                return fail(QAMD_ERR_IO, "%s: every centroid must be a sequence of dim = %llu numbers", meta_path,
+                            (unsigned long long)file_vp.dim);
+            for (const JsonValue &x : row.items) {
+                float f = 0.0f;
+                if (!json_number_as_f32(x, f, err)) return fail(QAMD_ERR_IO, "%s: centroids: %s", meta_path, err.c_str());
+                cen.push_back(f);
             }
         }
+        // vector_division: the ranges get_vector_division (:116-121) produces - the first one's length is the chunk size,
+        // their number the row size
+        const JsonValue *dj = json_field(root, "vector_division", err);
+        if (!dj) return fail(QAMD_ERR_IO, "%s: %s", meta_path, err.c_str());
+        if (dj->kind != JsonValue::Array) return fail(QAMD_ERR_IO, "%s: vector_division: expected a sequence", meta_path);
+        m = dj->items.size();
+        for (uint64_t c = 0; c < m; c++) {
+            uint64_t st = 0, en = 0;
+            if (!json_usize(dj->items[c], "start", st, err) || !json_usize(dj->items[c], "end", en, err))
+                return fail(QAMD_ERR_IO, "%s: vector_division[%llu]: %s", meta_path, (unsigned long long)c, err.c_str());
+            if (c == 0) chunk_size = en > st ? en - st : 0;
+            if (chunk_size == 0 || st != c * chunk_size || en != std::min<uint64_t>(st + chunk_size, file_vp.dim))
+                return fail(QAMD_ERR_IO, "%s: vector_division does not tile dim %llu in chunks of %llu", meta_path,
+                            (unsigned long long)file_vp.dim, (unsigned long long)chunk_size);
+        }
+        if (chunk_size == 0) chunk_size = 1;  // dim == 0: no ranges
     }
-    if (cen.size() != (size_t)kCentroids * file_vp.dim)
-        return fail(QAMD_ERR_IO, "metadata holds %zu centroid values, expected %llu", cen.size(),
-                    (unsigned long long)((uint64_t)kCentroids * file_vp.dim));
-    // vector_division: the first range's length is the chunk size; its count is the row size
-    size_t d = js.find("\"vector_division\"", i);
-    if (d == std::string::npos) return fail(QAMD_ERR_IO, "metadata has no vector_division");
-    const size_t dend = js.find(']', d);
-    uint64_t m = 0, chunk_size = 0;
-    for (size_t q = js.find("\"start\"", d); q != std::string::npos && q < dend; q = js.find("\"start\"", q + 1)) {
-        double st = 0, en = 0;
-        const std::string sub = js.substr(q, 64);
-        json_find_number(sub, "start", st);
-        json_find_number(sub, "end", en);
-        if (m == 0) chunk_size = (uint64_t)(en - st);
-        m++;
-    }
-    if (chunk_size == 0) chunk_size = 1;
     std::string bytes;
     if (!read_file(data_path, bytes)) return fail(QAMD_ERR_IO, "cannot read %s", data_path);
     const uint64_t expected = m * vp->count;

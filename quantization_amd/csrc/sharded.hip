@@ -179,7 +179,16 @@ struct Worker {
                 q.queued.store((uint32_t)q.jobs.size(), std::memory_order_release);
             }
             const qamd_status r = (*job.fn)(job.shard, *this);
-            job.call->finish_one(r, r == QAMD_OK ? std::string() : last_error());
+            std::string err;
+            if (r != QAMD_OK) {
+                // a job that failed half-way returned without its own wait: what it had already enqueued on this lane's
+                // stream (copies into the call's leased buffers, kernels) must be finished BEFORE the caller hears of the
+                // failure and gives the lease back - another caller's job may be handed the same buffers next
+                err = last_error();
+                (void)hipStreamSynchronize(stream);
+                (void)hipGetLastError();
+            }
+            job.call->finish_one(r, err);
         }
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
@@ -389,6 +398,11 @@ template <class H, class Qy> struct Sharded {
     std::vector<H *> shards;
     Pool pool;
     DevBuf bases_dev;  // [G] u64 on devices[0], written once
+    struct Peer {
+        int state = QAMD_PEER_SAME_DEVICE;
+        std::string reason = "same device as devices[0]";
+    };
+    std::vector<Peer> peer;  // how shard g's device reaches devices[0] (recorded at construction, reported on request)
     std::mutex slots_m;
     std::vector<std::unique_ptr<CallSlot>> slots;
 
@@ -444,18 +458,32 @@ template <class H, class Qy> struct Sharded {
         shard_bounds(total, n, base);
         shards.assign(n, nullptr);
         QAMD_TRY(pool.start(devs, n));
-        // direct xGMI copies between the shards' devices and devices[0] (the exchanges are peer copies);
-        // where peer access cannot be enabled hipMemcpyAsync still works, staged by the runtime
+        // direct xGMI copies between the shards' devices and devices[0] (the exchanges are peer copies); where peer
+        // access cannot be enabled the same hipMemcpyAsync calls still work, staged through host memory by the runtime:
+        // the outcome is recorded per shard (qamd_*_sharded_peer_access), never ignored
+        peer.assign(n, Peer{});
         for (uint32_t g = 1; g < n; g++) {
             if (devs[g] == devs[0]) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devs[0], devs[g]) == hipSuccess && can) {
-                DeviceGuard a(devs[0]);
-                (void)hipDeviceEnablePeerAccess(devs[g], 0);
-                DeviceGuard b(devs[g]);
-                (void)hipDeviceEnablePeerAccess(devs[0], 0);
+            const hipError_t ce = hipDeviceCanAccessPeer(&can, devs[0], devs[g]);
+            if (ce != hipSuccess || !can) {
+                peer[g] = Peer{QAMD_PEER_UNAVAILABLE, ce != hipSuccess ? std::string("hipDeviceCanAccessPeer failed: ") + hipGetErrorString(ce)
+                                                                      : "hipDeviceCanAccessPeer: no peer access between the devices; copies are staged by the runtime"};
+                (void)hipGetLastError();
+                continue;
             }
-            (void)hipGetLastError();  // "already enabled" is fine
+            auto enable = [](int from, int to) {
+                DeviceGuard a(from);
+                const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+                (void)hipGetLastError();
+                return e == hipErrorPeerAccessAlreadyEnabled ? hipSuccess : e;
+            };
+            const hipError_t e1 = enable(devs[0], devs[g]), e2 = enable(devs[g], devs[0]);
+            if (e1 == hipSuccess && e2 == hipSuccess)
+                peer[g] = Peer{QAMD_PEER_ENABLED, "hipDeviceEnablePeerAccess in both directions"};
+            else
+                peer[g] = Peer{QAMD_PEER_FAILED, std::string("hipDeviceEnablePeerAccess failed: ") +
+                                                     hipGetErrorString(e1 != hipSuccess ? e1 : e2) + "; copies are staged by the runtime"};
         }
         QAMD_ON_DEVICE(root());
         QAMD_TRY(bases_dev.alloc(n * sizeof(uint64_t)));
@@ -877,6 +905,12 @@ qamd_status qamd_u8_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, co
 }
 
 uint32_t qamd_u8_sharded_shard_count(const qamd_u8_sharded *h) { return h ? h->G() : 0; }
+qamd_status qamd_u8_sharded_peer_access(const qamd_u8_sharded *h, uint32_t g, int *state, const char **reason) {
+    if (!h || !state || g >= h->G()) return fail(QAMD_ERR_ARGUMENTS, "bad shard index");
+    *state = h->peer[g].state;
+    if (reason) *reason = h->peer[g].reason.c_str();
+    return QAMD_OK;
+}
 
 qamd_status qamd_u8_sharded_shard(const qamd_u8_sharded *h, uint32_t g, const qamd_u8 **shard, uint64_t *row_begin,
                                   int *device) {
@@ -1013,6 +1047,12 @@ qamd_status qamd_bin_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, c
 }
 
 uint32_t qamd_bin_sharded_shard_count(const qamd_bin_sharded *h) { return h ? h->G() : 0; }
+qamd_status qamd_bin_sharded_peer_access(const qamd_bin_sharded *h, uint32_t g, int *state, const char **reason) {
+    if (!h || !state || g >= h->G()) return fail(QAMD_ERR_ARGUMENTS, "bad shard index");
+    *state = h->peer[g].state;
+    if (reason) *reason = h->peer[g].reason.c_str();
+    return QAMD_OK;
+}
 
 qamd_status qamd_bin_sharded_shard(const qamd_bin_sharded *h, uint32_t g, const qamd_bin **shard, uint64_t *row_begin,
                                    int *device) {
@@ -1157,6 +1197,12 @@ qamd_status qamd_pq_sharded_from_rows(const uint8_t *rows, qamd_mem rows_mem, co
 }
 
 uint32_t qamd_pq_sharded_shard_count(const qamd_pq_sharded *h) { return h ? h->G() : 0; }
+qamd_status qamd_pq_sharded_peer_access(const qamd_pq_sharded *h, uint32_t g, int *state, const char **reason) {
+    if (!h || !state || g >= h->G()) return fail(QAMD_ERR_ARGUMENTS, "bad shard index");
+    *state = h->peer[g].state;
+    if (reason) *reason = h->peer[g].reason.c_str();
+    return QAMD_OK;
+}
 
 qamd_status qamd_pq_sharded_shard(const qamd_pq_sharded *h, uint32_t g, const qamd_pq **shard, uint64_t *row_begin,
                                   int *device) {

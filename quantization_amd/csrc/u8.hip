@@ -1767,28 +1767,16 @@ qamd_status qamd_u8_save(const qamd_u8 *h, const char *data_path, const char *me
 qamd_status qamd_u8_load(const char *data_path, const char *meta_path, const qamd_vector_parameters *vp,
                          qamd_u8 **out) {
     if (!data_path || !meta_path || !vp || !out) return fail(QAMD_ERR_ARGUMENTS, "null argument");
-    std::string js;
-    if (!read_file(meta_path, js)) return fail(QAMD_ERR_IO, "cannot read %s", meta_path);
+    JsonValue root;
+    QAMD_TRY(read_metadata(meta_path, root));
     qamd_u8_metadata meta{};
-    double ad, a, o, m;
-    if (!json_find_number(js, "actual_dim", ad) || !json_find_number(js, "alpha", a) ||
-        !json_find_number(js, "offset", o) || !json_find_number(js, "multiplier", m) ||
-        !parse_vector_parameters(js, meta.vector_parameters))
-        return fail(QAMD_ERR_IO, "malformed metadata in %s", meta_path);
-    meta.actual_dim = (uint64_t)ad;
-    meta.alpha = (float)a;
-    meta.offset = (float)o;
-    meta.multiplier = (float)m;
-    {  // re-parse the f32 fields straight from their decimal text (no double rounding)
-        auto f32_of = [&](const char *key, float &dst) {
-            std::string k = std::string("\"") + key + "\":";
-            size_t p = js.find(k);
-            if (p != std::string::npos && js.compare(p + k.size(), 4, "null") != 0)
-                dst = strtof(js.c_str() + p + k.size(), nullptr);
-        };
-        f32_of("alpha", meta.alpha);
-        f32_of("offset", meta.offset);
-        f32_of("multiplier", meta.multiplier);
+    {   // Metadata (:24-31), the fields in any order
+        std::string err;
+        const JsonValue *vpj = nullptr;
+        if (!json_usize(root, "actual_dim", meta.actual_dim, err) || !json_f32_field(root, "alpha", meta.alpha, err) ||
+            !json_f32_field(root, "offset", meta.offset, err) || !json_f32_field(root, "multiplier", meta.multiplier, err) ||
+            !(vpj = json_field(root, "vector_parameters", err)) || !parse_vector_parameters(*vpj, meta.vector_parameters, err))
+            return fail(QAMD_ERR_IO, "%s: %s", meta_path, err.c_str());
     }
     const uint64_t size = qamd_u8_quantized_vector_size(vp);
     std::string bytes;

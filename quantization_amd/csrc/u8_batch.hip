@@ -2212,6 +2212,9 @@ bool qr_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mod
     if (cfg && cfg[0] != 'g') return false;
     if (!qr_possible(h, b, filter_mode)) return false;
     if (cfg) return true;
+    // a store of fewer than ~4 slabs per workgroup (a small Qdrant segment) leaves this persistent grid a ragged tail too:
+    // the same guard as qs_selected (the row-streaming tiles split such a store evenly)
+    if (!lo && !hi && h->count < 131072 && h->meta.actual_dim <= 1152) return false;
     const uint64_t q_min = lo ? (uint64_t)atoll(lo) : (h->meta.actual_dim == 1024 ? 65 : 129);
     const uint64_t q_max = hi ? (uint64_t)atoll(hi) : kQrQueries;
     return b->n_queries >= q_min && b->n_queries <= q_max;

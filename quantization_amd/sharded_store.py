@@ -89,6 +89,16 @@ class _ShardedBase:
         check(self._fn("shard")(self._h, int(g), C.byref(h), C.byref(base), C.byref(dev)))
         return h, int(base.value), int(dev.value)
 
+    PEER_STATES = ("same device", "enabled", "unavailable", "failed")
+
+    def peer_access(self, g: int) -> tuple[str, str]:
+        """(state, reason) of the route between shard g's device and devices[0]: direct peer copies where
+        hipDeviceEnablePeerAccess succeeded, else the runtime stages the copies through host memory - recorded, never
+        silently ignored (include/quantization_amd.h qamd_peer_state)."""
+        st, why = C.c_int32(), C.c_char_p()
+        check(self._fn("peer_access")(self._h, int(g), C.byref(st), C.byref(why)))
+        return self.PEER_STATES[st.value], (why.value or b"").decode()
+
     def _check_root(self, *buffers):
         for b in buffers:
             d = device_of(b)

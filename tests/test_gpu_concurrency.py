@@ -77,3 +77,50 @@ def test_scan_is_capturable_in_a_hip_graph():
         want = enc.score_all(enc.encode_query(q_host))
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
         assert np.array_equal(bout.cpu().numpy(), benc.score_all(benc.encode_query(q_host)))
+
+
+def test_first_calls_from_two_threads_at_once_see_the_kernel_set_up():
+    """Per-device one-time set-up (hipFuncSetAttribute: the opt-in to more than 64 KiB of dynamic LDS) is two-phase
+    (csrc/common.hpp DeviceOnce): a thread that arrives while another is still inside the set-up waits for it instead of
+    launching with the attribute not yet applied.  A FRESH process, so that the calls below really are the first ones: two
+    threads start together on the first PQ m = 96 scan (144 KiB of LDS) and the first 129-query u8 batch (the
+    queries-in-registers MFMA kernel, 160 KiB) of the process; every call must succeed and give the single-threaded bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, threading
+sys.path.insert(0, %r)
+import numpy as np
+import quantization_amd as qa
+D = qa.DistanceType
+rng = np.random.default_rng(1)
+n = 20000
+rows = rng.integers(0, 256, size=(n, 96), dtype=np.uint8)
+cen = rng.random((256, 768), dtype=np.float32)
+pq = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(768, n, D.Dot, False), 8, cen)
+u8 = qa.EncodedVectorsU8.encode(rng.random((140000, 768), dtype=np.float32), qa.VectorParameters(768, 140000, D.Dot, False))
+pq_q = [pq.encode_query(rng.random(768, dtype=np.float32)) for _ in range(4)]
+batches = [u8.encode_query_batch(rng.random((129, 768), dtype=np.float32)) for _ in range(4)]
+start = threading.Barrier(4)
+out, errs = {}, []
+def run(i):
+    try:
+        start.wait()
+        out[i] = (pq.score_all(pq_q[i]), u8.topk_batch(batches[i], 10)) if i %% 2 == 0 else \
+                 (u8.topk_batch(batches[i], 10), pq.score_all(pq_q[i]))
+    except Exception as e:
+        errs.append(repr(e))
+ts = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errs, errs
+for i in range(4):
+    a, b = out[i] if i %% 2 == 0 else out[i][::-1]
+    assert np.array_equal(a.view(np.uint32), pq.score_all(pq_q[i]).view(np.uint32))
+    ids, sc = u8.topk_batch(batches[i], 10)
+    assert np.array_equal(b[0], ids) and np.array_equal(b[1].view(np.uint32), sc.view(np.uint32))
+print("OK")
+""" % root
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "OK" in res.stdout, (res.stdout + res.stderr)[-3000:]

@@ -331,3 +331,51 @@ def test_shard_view_keeps_its_sharded_store_alive():
     assert np.array_equal(view.storage_bytes(), one.storage_bytes()[2000:])
     q = rng.random(32, dtype=np.float32)
     assert_bits_equal(view.score_all(view.encode_query(q)), one.score_all(one.encode_query(q))[2000:], "view after parent drop")
+
+
+def test_sharded_topk_at_the_documented_limits():
+    """include/quantization_amd.h: k <= 1024 and shards x k <= 8192 merge slots.  AT the limits (8 shards x k = 1024, and
+    4 shards x 1024 in a batch) the answer equals the single handle's; one past either limit is an argument error, not a
+    wrong answer or a fault."""
+    rng = np.random.default_rng(77)
+    n, dim = 40_000, 32
+    data = rng.random((n, dim), dtype=np.float32)
+    data[1000:1400] = data[0]  # a tie group of 401 rows across the shard boundaries
+    vp = qa.VectorParameters(dim, n, D.Dot, False)
+    one = qa.EncodedVectorsU8.encode(data, vp)
+    q = rng.random(dim, dtype=np.float32)
+    q1 = one.encode_query(q)
+    sh8 = qa.ShardedVectorsU8.encode(data, vp, [0] * 8)
+    for largest in (True, False):
+        _same_topk(sh8.topk(sh8.encode_query(q), 1024, largest=largest), one.topk(q1, 1024, largest=largest))
+    with pytest.raises(qa.EncodingError):  # k > 1024
+        sh8.topk(sh8.encode_query(q), 1025)
+    with pytest.raises(qa.EncodingError):
+        one.topk(q1, 1025)
+    sh9 = qa.ShardedVectorsU8.encode(data, vp, [0] * 9)  # 9 x 1024 > 8192 merge slots
+    with pytest.raises(qa.EncodingError, match="8192"):
+        sh9.topk(sh9.encode_query(q), 1024)
+    _same_topk(sh9.topk(sh9.encode_query(q), 910), one.topk(q1, 910))  # 9 x 910 = 8190 fits
+    # batched: 3 queries x k = 1024 over 4 shards
+    queries = rng.random((3, dim), dtype=np.float32)
+    sh4 = qa.ShardedVectorsU8.encode(data, vp, [0] * 4)
+    ids, sc = sh4.topk_batch(sh4.encode_query_batch(queries), 1024)
+    ids1, sc1 = one.topk_batch(one.encode_query_batch(queries), 1024)
+    assert np.array_equal(ids, ids1)
+    assert_bits_equal(sc, sc1, "batched top-1024 over 4 shards")
+
+
+def test_peer_access_outcome_is_recorded():
+    """Construction records, per shard, how its device reaches devices[0] (never ignored): logical shards of one GPU are
+    'same device'; a second real GPU is 'enabled' or carries the reason copies are staged."""
+    rng = np.random.default_rng(3)
+    data = rng.random((1000, 16), dtype=np.float32)
+    vp = qa.VectorParameters(16, 1000, D.Dot, False)
+    sh = qa.ShardedVectorsU8.encode(data, vp, [0, 0, 0])
+    assert [sh.peer_access(g)[0] for g in range(3)] == ["same device"] * 3
+    if qa.lib().qamd_device_count() >= 2:
+        sh2 = qa.ShardedVectorsU8.encode(data, vp, [0, 1])
+        state, why = sh2.peer_access(1)
+        assert state in ("enabled", "unavailable", "failed") and why
+    with pytest.raises(qa.EncodingError):
+        sh.peer_access(3)
