@@ -51,5 +51,32 @@ def test_tool_compiles_answers_help_and_names_only_what_exists(tool):
                 qa.ShardedVectorsBin, qa.ShardedVectorsPQ):
         api.update(dir(cls))
     api.update(dir(qa))  # module-level functions such as qa.topk_scores
+    if re.search(r"^\s*from oracle import qoracle", src, re.M):  # a tool that times the oracle's CPU loop beside the GPU's
+        from oracle import qoracle
+        api.update(dir(qoracle))
     for name in set(re.findall(r"\.(encode\w*|score_\w+|topk\w*|storage_\w+|from_storage|shard\w*)\(", src)):
         assert name in api or name in ("encode",), f"{tool}: no API method {name}"
+
+
+@pytest.mark.gpu
+def test_ann_protocol_harness_small(tmp_path):
+    """tools/ann_protocol.py at a small size: the reference's per-query latency statistics and same_10/20/30 accuracy
+    (demos/src/ann_benchmark_data.rs:93-185,202-220) for every quantizer, with the oracle's CPU loop beside them."""
+    import json
+    out = tmp_path / "ann.jsonl"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ann_protocol.py"), "--rows", "30000", "--dims", "64",
+                          "--queries", "25", "--cpu-queries", "2", "--out", str(out)], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    recs = [json.loads(ln) for ln in open(out)]
+    assert len(recs) == 2 * 5  # two metrics x (u8, u8 quantile, pq strided, pq random, binary)
+    for r in recs:
+        g, c = r["gpu"], r["cpu_oracle_loop"]
+        assert g["queries"] == 25 and g["min_ms"] <= g["avg_ms"] <= g["max_ms"] and g["min_ms"] <= g["p95_ms"] <= g["max_ms"]
+        assert 0 <= g["same_10"] <= g["same_20"] <= g["same_30"] <= 10
+        assert c["topk_scores_equal_the_gpus"] is True and c["queries"] == 2
+        if r["quantizer"].startswith("u8"):
+            assert g["same_30"] >= 9.0, r  # scalar quantization keeps the ten true neighbours within the first 30
+    strided = [r for r in recs if "strided" in r["quantizer"]]
+    rand = [r for r in recs if "RANDOM" in r["quantizer"]]
+    for a, b in zip(strided, rand):  # the strided k-means sample is no worse than a random one (within noise)
+        assert a["gpu"]["same_30"] >= b["gpu"]["same_30"] - 1.0
