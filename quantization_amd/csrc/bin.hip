@@ -1204,14 +1204,16 @@ constexpr uint64_t kQs4Slice = 2048, kQs4MinQueries = 129;  // queries per launc
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
-// 8 bits -> 8 E2M1 nibbles (1.0 where set), bit j of the low nibble at nibble 2j, of the high nibble at 2j + 1 (any fixed
-// order does: rows and queries use the same one)
-__device__ __forceinline__ uint32_t nib8(uint32_t b8) {
-    const uint32_t lo = __umul24(b8 & 0xFu, 0x00204081u) & 0x01010101u, hi = __umul24((b8 >> 4) & 0xFu, 0x00204081u) & 0x01010101u;
-    return (lo | (hi << 4)) << 1;
-}
+// 32 bits -> 32 E2M1 nibbles (1.0 = 0b0010 where set).  Rows and queries go through the same function and a k-step sums
+// over all 32 places of a dword's chunk, so ANY fixed placement of the bits inside the chunk does: dword p of the result
+// holds bit pairs p of the four bytes (bits 2 p, 2 p + 1 of byte j at nibbles 2 j, 2 j + 1).  Per output dword one shift,
+// one mask - four byte-sized selectors 0..3 - and one v_perm_b32 that looks each selector up in the four-byte table
+// {0x00, 0x02, 0x20, 0x22}: 11 vector-ALU operations per 32 bits.  (Round 3 spread every nibble of every byte with 24-bit
+// multiplies: ~38 operations, 1.1 us of the 3.3 us a 128-row block cost.)
 __device__ __forceinline__ uint4 nib32(uint32_t w) {
-    return make_uint4(nib8(w & 255u), nib8((w >> 8) & 255u), nib8((w >> 16) & 255u), nib8(w >> 24));
+    constexpr uint32_t kPairs = 0x03030303u, kTable = 0x22200200u;
+    return make_uint4(__builtin_amdgcn_perm(0u, kTable, w & kPairs), __builtin_amdgcn_perm(0u, kTable, (w >> 2) & kPairs),
+                      __builtin_amdgcn_perm(0u, kTable, (w >> 4) & kPairs), __builtin_amdgcn_perm(0u, kTable, (w >> 6) & kPairs));
 }
 
 // out[(t16 * nsteps + s) * 64 + lane] = nibbles of bits [128 s + 32 g, +32) of query 16 t16 + i (lane = 16 g + i); also the
@@ -1320,7 +1322,13 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     // the K loop waits for its query fragments at every k-step, so a request in front of a K loop stalls it for an HBM
     // round trip (measured: a 3.9 us floor per block); the request is placed behind the last query loads of the wave's
     // last chunk instead, and the data is not needed before the END of the following block.
-    uint4 stA[MAXP], stB[MAXP];
+    // (Round 4: up to FOUR register sets, the request four blocks ahead.  With two, a workgroup had at most two 16 KiB blocks in
+    // flight - 32 KiB per CU against the ~64 KiB that 8 TB/s x ~2 us of HBM latency ask for: a launch with the K loop cut
+    // out still took 3.2 ms for the 6.4 GB of a 50M x 1024-bit store, 2 TB/s, and that was the floor of every small batch.)
+    // The streamed-query forms (IT = 4) and the 96-row form with IT = 2 sit at the 256-register limit and keep two sets:
+    // their blocks last long enough (MFMA-bound) for one block of look-ahead.
+    constexpr int DEPTH = (IT == 4 || (IT == 2 && JT == 6)) ? 2 : 4;
+    uint4 st[DEPTH][MAXP];
     auto fill_request = [&](uint4(&st)[MAXP], uint32_t blk) {
         const uint8_t *p = rows + (uint64_t)blk * QS_ROWS * ds;
 #pragma unroll
@@ -1358,9 +1366,10 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     const uint32_t my_first = wave;
     const uint32_t first_blk = blockIdx.x < n_blocks ? blockIdx.x : 0u;
     auto clamp_blk = [&](uint32_t blk) { return blk < n_blocks ? blk : first_blk; };  // past the end: a harmless re-read
-    fill_request(stA, first_blk);
-    fill_write(stA, (uint64_t)first_blk * QS_ROWS, 0u);
-    fill_request(stA, clamp_blk(first_blk + gridDim.x));  // the second block's bits: expanded at the end of the first block
+    // set (i mod DEPTH) holds the bits of the workgroup's i-th block from its request until they are expanded
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) fill_request(st[d], clamp_blk(first_blk + (uint32_t)d * gridDim.x));
+    fill_write(st[0], (uint64_t)first_blk * QS_ROWS, 0u);
     if (!QREG && my_first < live_chunks) {
         load_step(Q0, my_first, 0);
         load_step(Q1, my_first, 1);
@@ -1368,11 +1377,11 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
     __syncthreads();
     uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave) * filt.wave_cap;
 
-    // one row block: slab `par` holds it, st_use the next block's bits (requested a block ago), st_req takes the bits of
+    // one row block: slab `par` holds it, st_use the next block's bits (requested three blocks ago), st_req takes the bits of
     // the block after that
     auto block_body = [&](uint32_t blk, uint32_t par, const uint4(&st_use)[MAXP], uint4(&st_req)[MAXP]) {
         const uint64_t row0 = (uint64_t)blk * QS_ROWS;
-        const uint32_t next_blk = clamp_blk(blk + gridDim.x), next2_blk = clamp_blk(blk + 2 * gridDim.x);
+        const uint32_t next_blk = clamp_blk(blk + gridDim.x), next2_blk = clamp_blk(blk + (uint32_t)DEPTH * gridDim.x);
         bool requested = false;
         const uint8_t *slab = lds_raw + par * SLAB;
         const float *voff_cur = voff_s + par * QS_ROWS;
@@ -1516,10 +1525,169 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
         fill_write(st_use, (uint64_t)next_blk * QS_ROWS, par ^ 1u);  // the other slab: last read a block ago, a barrier has passed since
         __syncthreads();
     };
-    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += 2 * gridDim.x) {
-        block_body(blk, 0u, stA, stB);
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += 4 * gridDim.x) {  // block i: expands set (i + 1) mod DEPTH, refills set i mod DEPTH
+        block_body(blk, 0u, st[1 % DEPTH], st[0]);
         if (blk + gridDim.x >= n_blocks) break;
-        block_body(blk + gridDim.x, 1u, stB, stA);
+        block_body(blk + gridDim.x, 1u, st[2 % DEPTH], st[1 % DEPTH]);
+        if (blk + 2 * gridDim.x >= n_blocks) break;
+        block_body(blk + 2 * gridDim.x, 0u, st[3 % DEPTH], st[2 % DEPTH]);
+        if (blk + 3 * gridDim.x >= n_blocks) break;
+        block_body(blk + 3 * gridDim.x, 1u, st[0], st[3 % DEPTH]);
+    }
+    if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+}
+
+// ------------------------------------------------------------------------------------------
+// FP4 matrix cores, ROW-STREAMING form (round 4): batches whose whole nibble image fits in LDS - 256 queries of 1024 bits
+// are 128 KiB.  bin_gemm_qs4_kernel keeps ROWS in LDS and pays per 128-row block an expansion phase, an epilogue phase and
+// a barrier during which the matrix pipes idle (timeline, profiles/r04_bin_batch.txt: at 256 queries the K loop is 35 % of
+// a block, at 128 queries less; no amount of look-ahead on the row loads moved it).  Here the roles are swapped, as in
+// bin_gemm_rs_kernel / u8_gemm_rs_kernel: the QUERIES are resident (fragment order: the A operand of k-step s of a
+// 16-query tile is one lane-linear 1 KiB piece, conflict-free by construction), every wave streams its OWN rows - 32 per
+// trip, loaded two trips ahead, expanded to nibbles ONCE per row into 64 registers, then multiplied with every query tile -
+// and after the set-up there is no barrier: each SIMD's two waves drift apart and fill each other's vector-ALU phases with
+// MFMAs.  A lane owns NS consecutive dwords of its row (lane (i, g): dwords [NS g, NS g + NS) of row i: whole 16-byte
+// loads, every line fetched once); k-step s multiplies dword NS g + s of the row with the same dword of the query, which is
+// where the staging copy puts it (any pairing of K positions is the same dot product).  Arithmetic, bounds and candidate
+// lists are bin_gemm_qs4_kernel's.
+constexpr uint32_t kRs4MinQueries = 12;
+inline uint32_t rs4_max_queries(uint64_t ds) {  // whole 32-query tile pairs whose nibble image + bounds fit the CU's LDS
+    return (uint32_t)((160 * 1024 - 1024) / (ds * 4 + 4) / 32 * 32);
+}
+template <int MODE, bool LOW, int NS>  // MODE 1 / 2: filter for the largest / smallest scores; NS = k-steps = ds / 16
+__global__ __launch_bounds__(512) void bin_gemm_rs4_kernel(const uint8_t *__restrict__ rows, const uint4 *__restrict__ qfrag,
+                                                          const float *__restrict__ q_offsets, const int *__restrict__ bq_all,
+                                                          int zx, uint32_t n_rows, uint32_t n_tiles /* even */, BatchFilter filt) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr int RT = 2, QP = 2, DS = 16 * NS;
+    constexpr bool LARGEST = MODE == 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
+    const float multiplier = zx ? 4.0f : -4.0f;
+    uint4 *img = reinterpret_cast<uint4 *>(lds_raw);                                      // [n_tiles][NS][64] x 16 B
+    float *nbq_s = reinterpret_cast<float *>(lds_raw + (size_t)n_tiles * NS * 1024);      // [16 n_tiles]: MINUS the query bounds
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(nbq_s + 16 * n_tiles) + wave;
+    if (lane == 0) *wcount_s = 0;
+    for (uint32_t idx = t; idx < n_tiles * NS * 64; idx += 512) {  // position (tile, s, lane (i, g)) <- the query's dword NS g + s
+        const uint32_t tile = idx / (NS * 64), rem = idx % (NS * 64), sx = rem >> 6, i = rem & 15u, g = (rem >> 4) & 3u;
+        const uint32_t d = NS * g + sx;
+        img[idx] = qfrag[((uint64_t)tile * NS + d / 4) * 64 + 16 * (d % 4) + i];
+    }
+    // (the "always" / "never" sentinels of the bounds, +-2^29, are brought to +-2^23: far beyond any count, and exact in f32)
+    // stored negated and as f32: a tile's accumulators START at -bound, and the first MFMA of a chain takes these four
+    // values as its C operand straight from the LDS read - no conversion, no copy per tile
+    for (uint32_t i = t; i < 16 * n_tiles; i += 512) nbq_s[i] = -(float)max(min(bq_all[i], 1 << 23), -(1 << 23));
+    __syncthreads();
+
+    const uint32_t n_chunks = (n_rows + 16 * RT - 1) / (16 * RT), stride = gridDim.x * 8;
+    uint32_t raw[RT][NS], raw2[RT][NS];  // the rows of this trip and of the next; the trip after that is requested into `raw`
+                                         // as soon as it has been expanded (two trips = 8 KiB per wave in flight)
+    auto load_rows = [&](uint32_t (&raw)[RT][NS], uint32_t chunk) {  // rows past the store are its zero padding
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const uint8_t *p = rows + ((uint64_t)chunk * (16 * RT) + rt * 16 + i16) * DS + 4 * NS * g4;
+            if (NS % 4 == 0) {
+#pragma unroll
+                for (int v = 0; v < NS / 4; v++) {
+                    const uint4 x = reinterpret_cast<const uint4 *>(p)[v];
+                    raw[rt][4 * v] = x.x, raw[rt][4 * v + 1] = x.y, raw[rt][4 * v + 2] = x.z, raw[rt][4 * v + 3] = x.w;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < NS / 2; v++) {
+                    const uint2 x = reinterpret_cast<const uint2 *>(p)[v];
+                    raw[rt][2 * v] = x.x, raw[rt][2 * v + 1] = x.y;
+                }
+            }
+        }
+    };
+    uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave) * filt.wave_cap;
+    const uint32_t first = blockIdx.x * 8 + wave;
+    auto clamp_chunk = [&](uint32_t c) { return c < n_chunks ? c : (first < n_chunks ? first : 0u); };  // past the end: a harmless re-read
+    load_rows(raw, clamp_chunk(first));
+    load_rows(raw2, clamp_chunk(first + stride));
+    auto trip = [&](uint32_t chunk, uint32_t (&raw)[RT][NS]) {
+        v8i_t B[RT][NS];
+        uint32_t pop[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            pop[rt] = 0;
+#pragma unroll
+            for (int sx = 0; sx < NS; sx++) {
+                const uint4 nb = nib32(raw[rt][sx]);
+                B[rt][sx] = v8i_t{(int)nb.x, (int)nb.y, (int)nb.z, (int)nb.w, 0, 0, 0, 0};
+                pop[rt] += __popc(raw[rt][sx]);
+            }
+        }
+        const uint64_t row0 = (uint64_t)chunk * (16 * RT);
+        load_rows(raw, clamp_chunk(chunk + 2 * stride));  // two trips ahead, behind this trip's MFMAs
+        float v_off[RT], brf[RT];
+        int br[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {  // the row's popcount: its four lanes (i, 0..3)
+            uint32_t pv = pop[rt] + (uint32_t)__shfl_xor((int)pop[rt], 16);
+            pv += (uint32_t)__shfl_xor((int)pv, 32);
+            v_off[rt] = zx ? -2.0f * (float)pv : 2.0f * (float)pv;
+            const bool ok = row0 + rt * 16 + i16 < n_rows;
+            br[rt] = ok ? pp_bound<LOW>(-v_off[rt], fabsf(v_off[rt]), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+            brf[rt] = (float)br[rt];
+        }
+        for (uint32_t qt = 0; qt < n_tiles; qt += QP) {
+            v4f_t acc[QP][RT];
+            const uint4 *a_base = img + (size_t)qt * NS * 64 + lane;
+#pragma unroll
+            for (int sx = 0; sx < NS; sx++) {
+#pragma unroll
+                for (int qp = 0; qp < QP; qp++) {
+                    const uint4 a = a_base[(qp * NS + sx) * 64];
+                    const v8i_t a8 = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+                    const v4f_t start = *reinterpret_cast<const v4f_t *>(nbq_s + 16 * (qt + qp) + 4 * g4);  // (used at sx == 0 only)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+                        acc[qp][rt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, B[rt][sx], sx == 0 ? start : acc[qp][rt], 4, 4, 0, 127, 0, 127);
+                }
+            }
+            // ---- epilogue: lane (i, g) holds queries 16 (qt + qp) + 4 g + e against row 16 rt + i of the trip
+            bool any_lane = false;
+#pragma unroll
+            for (int qp = 0; qp < QP; qp++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const float ext = LOW ? fminf(fminf(acc[qp][rt][0], acc[qp][rt][1]), fminf(acc[qp][rt][2], acc[qp][rt][3]))
+                                          : fmaxf(fmaxf(acc[qp][rt][0], acc[qp][rt][1]), fmaxf(acc[qp][rt][2], acc[qp][rt][3]));
+                    any_lane |= LOW ? ext < brf[rt] : ext >= brf[rt];
+                }
+            if (__builtin_amdgcn_readfirstlane(__ballot(any_lane) != 0)) {
+#pragma unroll
+                for (int qp = 0; qp < QP; qp++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        const uint32_t q = 16 * (qt + qp) + 4 * g4;
+                        const uint64_t row = row0 + rt * 16 + i16;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int av = (int)acc[qp][rt][e];
+                            if (LOW ? av < br[rt] : av >= br[rt]) {  // may pass: the exact f32 comparison decides
+                                const float qo = q_offsets[q + e];
+                                const float pvt = filt.pivot_scores[q + e];
+                                const float sc = (multiplier * (float)(av - (int)nbq_s[q + e]) + qo) + v_off[rt];
+                                const float d = LARGEST ? sc - pvt : pvt - sc;
+                                if (d >= 0.0f) {
+                                    const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                    if (pos < filt.wave_cap)
+                                        wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row, filt.query_base + q + e, 0u);
+                                }
+                            }
+                        }
+                    }
+            }
+        }
+    };
+    for (uint32_t chunk = first; chunk < n_chunks; chunk += 2 * stride) {
+        trip(chunk, raw);
+        if (chunk + stride >= n_chunks) break;
+        trip(chunk + stride, raw2);
     }
     if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
@@ -1621,8 +1789,11 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     }
     // rows of 512 / 1024 / 2048 bits, enough queries: the FP4 query-streaming form (QAMD_BIN4=0 / QAMD_BIN4_MIN: developer A/B)
     static const char *e4 = dev_env("QAMD_BIN4"), *e4min = dev_env("QAMD_BIN4_MIN");
-    const bool qs4 = (h->ds == 64 || h->ds == 96 || h->ds == 128 || h->ds == 192) && !(e4 && e4[0] == '0') &&
-                     Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries);
+    static const char *ers4 = dev_env("QAMD_BIN_RS4");  // developer A/B: 0 = without the row-streaming fp4 form
+    const bool fp4_shape = (h->ds == 64 || h->ds == 96 || h->ds == 128 || h->ds == 192) && !(e4 && e4[0] == '0');
+    // the whole batch's nibble image in LDS: the row-streaming fp4 form (one pass, no barriers); larger batches: query-streaming
+    const bool rs4 = fp4_shape && !(ers4 && ers4[0] == '0') && Q >= kRs4MinQueries && round_up(Q, 32) <= rs4_max_queries(h->ds);
+    const bool qs4 = rs4 || (fp4_shape && Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries));
     const uint32_t n_lists = pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
     const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, qs4 ? kQs4Slice : TQ) / (double)pp_waves_per_launch();
     // (at least 1024 slots: queries of one batch can be near-duplicates, and then a passing row appends to every
@@ -1686,6 +1857,38 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
         const size_t qs_rows = h->ds > 128 ? 96 : 128;
         const size_t lds = 2 * qs_rows * round_up(h->ds * 4, 256) + 4 * qs_rows * 4 + 64 + kQs4Slice * 4;
         const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
+        if (rs4) {
+            const uint32_t n_tiles = (uint32_t)(round_up(Q, 32) / 16);
+            const size_t lds4 = (size_t)n_tiles * h->ds * 64 + (size_t)n_tiles * 64 + 64;
+            BatchFilter fs = f;
+            fs.query_base = 0;
+            fs.wave_base = 0;
+#define QAMD_RS4_NS(M_, LOW_, NS_)                                                                                          \
+    do {                                                                                                                   \
+        QAMD_LDS_OPT_IN((&bin_gemm_rs4_kernel<M_, LOW_, NS_>), 160 * 1024);                                                 \
+        hipLaunchKernelGGL((bin_gemm_rs4_kernel<M_, LOW_, NS_>), dim3(grid), dim3(512), lds4, s, h->rows.as<uint8_t>(), frag, \
+                           q_off, bq, zx ? 1 : 0, (uint32_t)n, n_tiles, fs);                                               \
+    } while (0)
+#define QAMD_RS4(M_, LOW_)                                                                                                  \
+    do {                                                                                                                   \
+        switch (h->ds) {                                                                                                   \
+            case 64: QAMD_RS4_NS(M_, LOW_, 4); break;                                                                      \
+            case 96: QAMD_RS4_NS(M_, LOW_, 6); break;                                                                      \
+            case 128: QAMD_RS4_NS(M_, LOW_, 8); break;                                                                     \
+            default: QAMD_RS4_NS(M_, LOW_, 12); break;                                                                     \
+        }                                                                                                                  \
+    } while (0)
+            if (largest) {
+                if (low) QAMD_RS4(1, true);
+                else QAMD_RS4(1, false);
+            } else {
+                if (low) QAMD_RS4(2, true);
+                else QAMD_RS4(2, false);
+            }
+#undef QAMD_RS4
+#undef QAMD_RS4_NS
+            QAMD_HIP(hipGetLastError());
+        } else
         for (uint64_t q_base = 0; q_base < Q; q_base += kQs4Slice) {
             const uint32_t nq = (uint32_t)std::min<uint64_t>(kQs4Slice, Q - q_base);
             BatchFilter fs = f;

@@ -103,11 +103,19 @@ def test_batch_edge_cases():
     (1536, 40_000, 300),    # 1536-bit rows: 96-row blocks, twelve k-steps
     (1500, 35_000, 100 + 60),  # ... pad bits, chunks of 32 queries in registers (12 k-steps x 2 tiles)
     (1024, 40_000, 2100),   # two launch slices of 2048 queries
+    # round 4: batches whose nibble image fits in LDS take the row-streaming fp4 form (bin_gemm_rs4_kernel) from 12 queries on:
+    (1024, 70_001, 12),     # one tile pair, the second tile all padding
+    (1024, 33_000, 288),    # the largest batch of 1024-bit rows (144 KiB of nibbles)
+    (512, 40_000, 608),     # ... of 512-bit rows: 38 query tiles, four k-steps
+    (1536, 50_000, 192),    # ... of 1536-bit rows: twelve k-steps (193 queries go to the query-streaming form)
+    (768, 33_333, 16),      # six k-steps (8-byte row loads), a ragged last trip
+    (1024, 32_768 + 31, 64),
 ])
 def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
     """12 queries and more on 32k rows and more take the matrix cores - bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
-    registers, int8 MFMA, u8-style epilogue with integer operands), and from 129 queries on rows of 512 / 1024 bits
-    bin_gemm_qs4_kernel (bits as E2M1 nibbles, FP4 MFMA, exact f32 counts): every list must equal the single-query
+    registers, int8 MFMA, u8-style epilogue with integer operands); on rows of 512 / 768 / 1024 / 1536 bits the FP4 matrix
+    cores (bits as E2M1 nibbles, exact f32 counts): bin_gemm_rs4_kernel while the batch's nibble image fits in LDS (queries
+    resident, every wave streams its own rows), bin_gemm_qs4_kernel beyond: every list must equal the single-query
     top-k AND the oracle's restatement of the caller loop (score_point for every row,
     encoded_vectors_binary.rs:293-300 -> calculate_metric :219-253, then a stable best-k: ties to the
     lower id), for the four metric variants and both directions."""
