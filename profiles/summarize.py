@@ -28,8 +28,8 @@ def kernel_source_hash(root=None, key="u8_scan"):
     """Hash of the source that defines the profiled kernel: a PMC profile is quoted by bench.py only while it matches.
       u8_scan        the part of csrc/u8.hip that defines u8_scan_kernel (device helpers + the kernel)
       pq_scan_m<m>   the scan section of csrc/pq.hip (everything in front of the encode section)
-      bin_scan       csrc/bin.hip
-      u8_batch...    csrc/u8_batch.hip + batch_common.hpp;   bin_batch...   csrc/bin.hip + batch_common.hpp"""
+      bin_scan       csrc/bin.hip in front of its "many queries on the matrix cores" part;   bin_batch...   that part + batch_common.hpp
+      u8_batch...    csrc/u8_batch.hip + batch_common.hpp"""
     import hashlib
     import os
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,12 +44,13 @@ def kernel_source_hash(root=None, key="u8_scan"):
         src = rd("pq.hip")
         b = src.find(b"// ------------------------------------------------------------------------------ encode")
         region = src[:b] if b > 0 else src
-    elif key.startswith("bin_scan"):
-        region = rd("bin.hip")
+    elif key.startswith("bin_scan") or key.startswith("bin_batch"):
+        src = rd("bin.hip")
+        cut = src.find(b"// ============================================================================= many queries on the matrix cores")
+        cut = cut if cut > 0 else len(src)
+        region = src[:cut] if key.startswith("bin_scan") else src[cut:] + rd("batch_common.hpp")
     elif key.startswith("u8_batch"):
         region = rd("u8_batch.hip") + rd("batch_common.hpp")
-    elif key.startswith("bin_batch"):
-        region = rd("bin.hip") + rd("batch_common.hpp")
     else:
         raise ValueError(key)
     return hashlib.sha256(region).hexdigest()[:16]

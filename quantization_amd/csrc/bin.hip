@@ -1554,12 +1554,15 @@ constexpr uint32_t kRs4MinQueries = 12;
 inline uint32_t rs4_max_queries(uint64_t ds) {  // whole 32-query tile pairs whose nibble image + bounds fit the CU's LDS
     return (uint32_t)((160 * 1024 - 1024) / (ds * 4 + 4) / 32 * 32);
 }
+// Waves per workgroup: 12 (three per SIMD: 166 registers at NS = 8) where the registers allow, else 8 - a third wave covers
+// more of the other two's vector-ALU phases with MFMAs.
+constexpr int rs4_waves(int ns) { return ns <= 8 ? 12 : 8; }
 template <int MODE, bool LOW, int NS>  // MODE 1 / 2: filter for the largest / smallest scores; NS = k-steps = ds / 16
-__global__ __launch_bounds__(512) void bin_gemm_rs4_kernel(const uint8_t *__restrict__ rows, const uint4 *__restrict__ qfrag,
+__global__ __launch_bounds__(64 * rs4_waves(NS)) void bin_gemm_rs4_kernel(const uint8_t *__restrict__ rows, const uint4 *__restrict__ qfrag,
                                                           const float *__restrict__ q_offsets, const int *__restrict__ bq_all,
                                                           int zx, uint32_t n_rows, uint32_t n_tiles /* even */, BatchFilter filt) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
-    constexpr int RT = 2, QP = 2, DS = 16 * NS;
+    constexpr int RT = 2, QP = 2, DS = 16 * NS, WAVES = rs4_waves(NS), THREADS = 64 * WAVES;
     constexpr bool LARGEST = MODE == 1;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1569,7 +1572,7 @@ __global__ __launch_bounds__(512) void bin_gemm_rs4_kernel(const uint8_t *__rest
     float *nbq_s = reinterpret_cast<float *>(lds_raw + (size_t)n_tiles * NS * 1024);      // [16 n_tiles]: MINUS the query bounds
     uint32_t *wcount_s = reinterpret_cast<uint32_t *>(nbq_s + 16 * n_tiles) + wave;
     if (lane == 0) *wcount_s = 0;
-    for (uint32_t idx = t; idx < n_tiles * NS * 64; idx += 512) {  // position (tile, s, lane (i, g)) <- the query's dword NS g + s
+    for (uint32_t idx = t; idx < n_tiles * NS * 64; idx += THREADS) {  // position (tile, s, lane (i, g)) <- the query's dword NS g + s
         const uint32_t tile = idx / (NS * 64), rem = idx % (NS * 64), sx = rem >> 6, i = rem & 15u, g = (rem >> 4) & 3u;
         const uint32_t d = NS * g + sx;
         img[idx] = qfrag[((uint64_t)tile * NS + d / 4) * 64 + 16 * (d % 4) + i];
@@ -1577,10 +1580,10 @@ __global__ __launch_bounds__(512) void bin_gemm_rs4_kernel(const uint8_t *__rest
     // (the "always" / "never" sentinels of the bounds, +-2^29, are brought to +-2^23: far beyond any count, and exact in f32)
     // stored negated and as f32: a tile's accumulators START at -bound, and the first MFMA of a chain takes these four
     // values as its C operand straight from the LDS read - no conversion, no copy per tile
-    for (uint32_t i = t; i < 16 * n_tiles; i += 512) nbq_s[i] = -(float)max(min(bq_all[i], 1 << 23), -(1 << 23));
+    for (uint32_t i = t; i < 16 * n_tiles; i += THREADS) nbq_s[i] = -(float)max(min(bq_all[i], 1 << 23), -(1 << 23));
     __syncthreads();
 
-    const uint32_t n_chunks = (n_rows + 16 * RT - 1) / (16 * RT), stride = gridDim.x * 8;
+    const uint32_t n_chunks = (n_rows + 16 * RT - 1) / (16 * RT), stride = gridDim.x * WAVES;
     uint32_t raw[RT][NS], raw2[RT][NS];  // the rows of this trip and of the next; the trip after that is requested into `raw`
                                          // as soon as it has been expanded (two trips = 8 KiB per wave in flight)
     auto load_rows = [&](uint32_t (&raw)[RT][NS], uint32_t chunk) {  // rows past the store are its zero padding
@@ -1602,8 +1605,8 @@ __global__ __launch_bounds__(512) void bin_gemm_rs4_kernel(const uint8_t *__rest
             }
         }
     };
-    uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * 8 + wave) * filt.wave_cap;
-    const uint32_t first = blockIdx.x * 8 + wave;
+    uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * WAVES + wave) * filt.wave_cap;
+    const uint32_t first = blockIdx.x * WAVES + wave;
     auto clamp_chunk = [&](uint32_t c) { return c < n_chunks ? c : (first < n_chunks ? first : 0u); };  // past the end: a harmless re-read
     load_rows(raw, clamp_chunk(first));
     load_rows(raw2, clamp_chunk(first + stride));
@@ -1689,7 +1692,7 @@ __global__ __launch_bounds__(512) void bin_gemm_rs4_kernel(const uint8_t *__rest
         if (chunk + stride >= n_chunks) break;
         trip(chunk + stride, raw2);
     }
-    if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
+    if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * WAVES + wave] = *wcount_s;
 }
 
 // Sample rows for the pivots (rows only; the golden-ratio scatter of topk.hip), then `pad` zero rows.
@@ -1794,7 +1797,8 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     // the whole batch's nibble image in LDS: the row-streaming fp4 form (one pass, no barriers); larger batches: query-streaming
     const bool rs4 = fp4_shape && !(ers4 && ers4[0] == '0') && Q >= kRs4MinQueries && round_up(Q, 32) <= rs4_max_queries(h->ds);
     const bool qs4 = rs4 || (fp4_shape && Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries));
-    const uint32_t n_lists = pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
+    const uint32_t n_lists = rs4 ? pp_waves_per_launch() / 8 * (uint32_t)rs4_waves((int)(h->ds / 16))  // one list per wave of the launch
+                                 : pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
     const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, qs4 ? kQs4Slice : TQ) / (double)pp_waves_per_launch();
     // (at least 1024 slots: queries of one batch can be near-duplicates, and then a passing row appends to every
     // query's list at once - 64 entries in one wave's list per such row)
@@ -1866,7 +1870,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
 #define QAMD_RS4_NS(M_, LOW_, NS_)                                                                                          \
     do {                                                                                                                   \
         QAMD_LDS_OPT_IN((&bin_gemm_rs4_kernel<M_, LOW_, NS_>), 160 * 1024);                                                 \
-        hipLaunchKernelGGL((bin_gemm_rs4_kernel<M_, LOW_, NS_>), dim3(grid), dim3(512), lds4, s, h->rows.as<uint8_t>(), frag, \
+        hipLaunchKernelGGL((bin_gemm_rs4_kernel<M_, LOW_, NS_>), dim3(grid), dim3(64 * rs4_waves(NS_)), lds4, s, h->rows.as<uint8_t>(), frag, \
                            q_off, bq, zx ? 1 : 0, (uint32_t)n, n_tiles, fs);                                               \
     } while (0)
 #define QAMD_RS4(M_, LOW_)                                                                                                  \
