@@ -573,8 +573,9 @@ def main():
             is_bin = args.quantizer == "binary"
             ad = dim if is_bin else enc.metadata["actual_dim"]  # binary: one 0/1 operand byte per bit on the matrix cores
             ops = 2.0 * Q * n * ad  # per GPU and step
-            # binary batches of 129+ queries on rows of 4 / 6 / 8 / 12 128-bit words take the fp4 matrix-core kernel (csrc/bin.hip)
-            bin_fp4 = is_bin and Q >= 129 and (ad + 127) // 128 in (4, 6, 8, 12)
+            # binary batches of 12+ queries on rows of 4 / 6 / 8 / 12 128-bit words take the fp4 matrix-core kernels (csrc/bin.hip:
+            # bin_gemm_rs4_kernel while the batch's nibble image fits in LDS, bin_gemm_qs4_kernel beyond)
+            bin_fp4 = is_bin and Q >= 12 and (ad + 127) // 128 in (4, 6, 8, 12)
             mfma_peak = MFMA_FP4_PEAK_TOPS if bin_fp4 else MFMA_INT8_PEAK_TOPS
             per_gpu_tops = ops * args.steps / elapsed / 1e12
             row_bytes = nb if is_bin else bytes_per_row

@@ -14,11 +14,11 @@ run bin         bin_scan            bin_scan_kernel                50000000  128
 run pq          pq_scan_m96         pq_scan_skew_kernel            10000000  96     1 4 -- --quantizer pq
 run pq192       pq_scan_m192        pq_scan_skew_kernel            12500000  192    2 4 -- --quantizer pq --dim 1536 --rows 12500000
 run pq48        pq_scan_m48         pq_scan_skew_kernel            20000000  48     1 4 -- --quantizer pq --pq-chunk 16 --rows 20000000
-run batch1024   u8_batch1024_768    u8_gemm_qs16_kernel           10000000  768    1 0 -- --batch-queries 1024 --k 30 --steps 5 --warmup 3
-run batch1024_1536 u8_batch1024_1536 u8_gemm_qs16_kernel          12500000  1536   1 0 -- --batch-queries 1024 --k 30 --steps 5 --warmup 3 --dim 1536 --rows 12500000
-run batch64     u8_batch64_768      u8_gemm_rs_kernel             10000000  768    1 0 -- --batch-queries 64 --k 30 --steps 10 --warmup 5
+run batch1024   u8_batch1024_768    u8_gemm_qs16_kernel           10000000  772    1 0 -- --batch-queries 1024 --k 30 --steps 5 --warmup 3
+run batch1024_1536 u8_batch1024_1536 u8_gemm_qs16_kernel          12500000  1540   1 0 -- --batch-queries 1024 --k 30 --steps 5 --warmup 3 --dim 1536 --rows 12500000
+run batch64     u8_batch64_768      u8_gemm_rs_kernel             10000000  772    1 0 -- --batch-queries 64 --k 30 --steps 10 --warmup 5
 run bin_batch64 bin_batch64_1024    bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 64 --k 30 --steps 10 --warmup 5
 run bin_batch1024 bin_batch1024_1024 bin_gemm_qs4_kernel          50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 1024 --k 30 --steps 3 --warmup 2
 run bin_batch128 bin_batch128_1024  bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 128 --k 30 --steps 10 --warmup 5
 run bin_batch256 bin_batch256_1024  bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 256 --k 30 --steps 10 --warmup 5
-run batch256    u8_batch256_768     u8_gemm_qr16_kernel           10000000  768    1 0 -- --batch-queries 256 --k 30 --steps 10 --warmup 5
+run batch256    u8_batch256_768     u8_gemm_qr16_kernel           10000000  772    1 0 -- --batch-queries 256 --k 30 --steps 10 --warmup 5
