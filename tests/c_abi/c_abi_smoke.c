@@ -116,6 +116,45 @@ int main(int argc, char **argv) {
         return 1;
     }
 
+    /* the rank-per-GPU route of encode: two holders of half the rows each find their own min / max
+     * (quantile.rs:5-19), fold them (order-free), and encode their rows with the agreed interval
+     * (alpha_offset_from_min_max, encoded_vectors_u8.rs:228-232): the two stores together are the one-shot store */
+    {
+        const uint64_t half = COUNT / 2 + 3; /* ragged on purpose */
+        float mn0, mx0, mn1, mx1, ao[2];
+        qamd_u8 *h0 = NULL, *h1 = NULL;
+        qamd_vector_parameters vp0 = vp, vp1 = vp;
+        int peer_state = -1;
+        const char *why = NULL;
+        CHECK(qamd_u8_find_min_max(data, QAMD_MEM_HOST, half, DIM, NULL, &mn0, &mx0));
+        CHECK(qamd_u8_find_min_max(data + half * DIM, QAMD_MEM_HOST, COUNT - half, DIM, NULL, &mn1, &mx1));
+        ao[1] = mn0 < mn1 ? mn0 : mn1;
+        ao[0] = ((mx0 > mx1 ? mx0 : mx1) - ao[1]) / 127.0f;
+        vp0.count = half;
+        vp1.count = COUNT - half;
+        CHECK(qamd_u8_encode(data, QAMD_MEM_HOST, &vp0, NULL, ao, stop_never, NULL, NULL, &h0));
+        CHECK(qamd_u8_encode(data + half * DIM, QAMD_MEM_HOST, &vp1, NULL, ao, stop_never, NULL, NULL, &h1));
+        CHECK(qamd_u8_export_rows(h0, rows2, QAMD_MEM_HOST, NULL));
+        CHECK(qamd_u8_export_rows(h1, rows2 + half * stride, QAMD_MEM_HOST, NULL));
+        CHECK(qamd_u8_get_metadata(h1, &meta2));
+        if (memcmp(rows, rows2, stride * COUNT) != 0 || bits_of(meta.alpha) != bits_of(meta2.alpha) ||
+            bits_of(meta.offset) != bits_of(meta2.offset) || bits_of(meta.multiplier) != bits_of(meta2.multiplier)) {
+            fprintf(stderr, "two holders that agreed on the interval do not reproduce the one-shot encode\n");
+            return 1;
+        }
+        qamd_u8_free(h0);
+        qamd_u8_free(h1);
+        /* how a logical shard reaches devices[0] is on record (peer access is never silently ignored) */
+        CHECK(qamd_u8_sharded_from_rows(rows, QAMD_MEM_HOST, &meta, devices, 2, NULL, &sh));
+        CHECK(qamd_u8_sharded_peer_access(sh, 1, &peer_state, &why));
+        if (peer_state != QAMD_PEER_SAME_DEVICE || !why) {
+            fprintf(stderr, "a logical shard of device 0 must report QAMD_PEER_SAME_DEVICE\n");
+            return 1;
+        }
+        qamd_u8_sharded_free(sh);
+        sh = NULL;
+    }
+
     /* query, scan, selection */
     CHECK(qamd_u8_encode_query(h, query, DIM, QAMD_MEM_HOST, NULL, &q));
     CHECK(qamd_u8_score_all(h, q, scores, QAMD_MEM_HOST, NULL));
