@@ -374,3 +374,41 @@ def test_division_free_quantize_is_exact_at_every_code_boundary(qo):
     enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(512, 4096, D.Dot, False))
     rows, _ = qo.u8_encode(data, qo.DOT, False)
     assert np.array_equal(enc.storage_bytes(), rows)
+
+
+def test_pass1_statistics_on_their_own(qo):
+    """qamd_u8_find_min_max / qamd_u8_find_quantile_interval / qamd_pq_find_centroids - the global statistics of `encode` as
+    separate entry points for hosts that hold the rows in several places: equal to the oracle's find_min_max_from_iter
+    (quantile.rs:5-19; NaN never wins, no rows -> (f32::MAX, f32::MIN)), find_quantile_interval (:21-71) and to what the
+    one-shot encoders use."""
+    rng = np.random.default_rng(12)
+    data = (rng.standard_normal((5000, 24)) * 3).astype(np.float32)
+    data[7, 3] = np.nan
+    data[100, 0] = np.float32(-0.0)
+    for rows in (data, data[:1], data[:0], data[:4097, :17].copy()):
+        mn, mx = qa.EncodedVectorsU8.find_min_max(rows)
+        wmn, wmx = qo.find_min_max(rows)
+        assert (np.float32(mn).view(np.uint32), np.float32(mx).view(np.uint32)) == (wmn.view(np.uint32), wmx.view(np.uint32))
+    assert qa.EncodedVectorsU8.find_min_max(data[:0]) == (np.finfo(np.float32).max, -np.finfo(np.float32).max)
+    clean = np.nan_to_num(data)
+    for q in (0.99, 0.9, 0.5):
+        got = qa.EncodedVectorsU8.find_quantile_interval(clean, q)
+        want = qo.find_quantile_interval(clean, q)
+        assert (got is None) == (want is None)
+        if got is not None:
+            assert np.float32(got[0]).view(np.uint32) == want[0].view(np.uint32) and np.float32(got[1]).view(np.uint32) == want[1].view(np.uint32)
+    assert qa.EncodedVectorsU8.find_quantile_interval(clean[:100], 0.99) is None  # fewer than 127 vectors (quantile.rs:27-29)
+    assert qa.EncodedVectorsU8.find_quantile_interval(clean, 1.0) is None
+    # the interval from the two statistics = the one-shot encode's
+    enc = qa.EncodedVectorsU8.encode(clean, qa.VectorParameters(24, 5000, D.Dot, False), 0.95)
+    mn, mx = qa.EncodedVectorsU8.find_quantile_interval(clean, 0.95)
+    a, o = qo.alpha_offset(mn, mx)
+    assert np.float32(enc.metadata["alpha"]).view(np.uint32) == a.view(np.uint32)
+    assert np.float32(enc.metadata["offset"]).view(np.uint32) == o.view(np.uint32)
+    # PQ: find_centroids on its own = the centroids `encode` trains
+    pdata = rng.random((3000, 16), dtype=np.float32)
+    cen = qa.EncodedVectorsPQ.find_centroids(pdata, 4, 2)
+    penc = qa.EncodedVectorsPQ.encode(pdata, qa.VectorParameters(16, 3000, D.L2, False), 4, max_kmeans_threads=2)
+    assert np.array_equal(cen.view(np.uint32), penc.centroids.view(np.uint32))
+    small = qa.EncodedVectorsPQ.find_centroids(pdata[:100], 4)  # count <= 256: the vectors themselves (:290-297)
+    assert np.array_equal(small, qo.pq_centroids_small(pdata[:100]))
