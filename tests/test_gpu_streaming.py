@@ -142,6 +142,30 @@ def test_pq_stream_equals_one_shot_and_oracle(qo):
     assert z.count == 0
 
 
+@pytest.mark.parametrize("dim,chunk", [(640, 4), (576, 3), (192, 4)])
+def test_pq_stream_builds_the_scan_image_batch_by_batch(dim, chunk, qo):
+    """Rows of several LUT slices (m = 160, 192: the planar scan image) and of 48 chunks (two rows per ring row) encoded by the
+    streaming encoder in ragged host and device batches, by the one-shot encoder and loaded from reference-format rows: the
+    same row bytes, and the whole-store scan (which reads the scan image) gives the oracle's score_point_sse bits."""
+    rng = np.random.default_rng(dim)
+    n = 21_001
+    m = dim // chunk
+    data = rng.random((n, dim), dtype=np.float32)
+    cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)
+    vp = qa.VectorParameters(dim, n, D.Dot, True)
+    rows = qo.pq_encode(data, chunk, cen)
+    query = (rng.random(dim, dtype=np.float32) - 0.5).astype(np.float32)
+    want = qo.pq_score_all(rows, qo.pq_encode_query(query, chunk, cen, qo.DOT, True), order=qo.ORDER_SSE)
+    stores = [qa.EncodedVectorsPQ.encode_stream(batches_of(data, 2777), vp, chunk, centroids=cen),
+              qa.EncodedVectorsPQ.encode_stream(batches_of(torch.from_numpy(data).cuda(), 4096), vp, chunk, centroids=cen),
+              qa.EncodedVectorsPQ.encode(data, vp, chunk, centroids=cen),
+              qa.EncodedVectorsPQ.from_storage(rows, vp, chunk, cen)]
+    for enc in stores:
+        assert enc.scan_kernel()[0].startswith("pq_scan_skew_kernel") and enc.scan_kernel()[1] == (2 if m > 128 else 1)
+        assert np.array_equal(enc.storage_bytes(), rows)
+        assert_bits_equal(enc.score_all(enc.encode_query(query)), want, f"scan of the streamed store, m={m}")
+
+
 def test_aborted_and_failed_encoders_give_their_memory_back():
     """An encoder that is aborted (stop_condition, an exception in the caller's iterator, a count
     mismatch at finish) frees the store it was building."""
