@@ -2,9 +2,11 @@
  * qoracle.c — CPU restatement of qdrant/quantization's encode-and-score path.
  *
  * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/,
- * __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or
- * call it.  The product (quantization_amd/) never links or imports it and has
- * no CPU fallback.
+ * __graft_entry__.smoke() and the CPU-baseline legs of the two measurement
+ * harnesses (bench.py's cpu_baseline; the CPU column of tools/ann_protocol.py,
+ * the reference's own ann_benchmark protocol) may build, load or call it - as
+ * the checker or the timed CPU side, never as the thing shipped.  The product
+ * (quantization_amd/) never links or imports it and has no CPU fallback.
  *
  * Every function cites the reference file:line (under /root/reference/) whose
  * arithmetic it restates.  Plain C, sequential f32 in the reference's exact

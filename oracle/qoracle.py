@@ -1,7 +1,8 @@
 """ctypes/numpy front-end of the parity oracle (oracle/qoracle.c).
 
-TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
-bench.py's cpu_baseline leg — never by quantization_amd/.  See the header of
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the CPU-baseline legs of the
+two measurement harnesses (bench.py's cpu_baseline; the "oracle CPU loop" column of tools/ann_protocol.py,
+the reference's own ann_benchmark protocol) — as the checker / the timed CPU side, never by quantization_amd/.  See the header of
 qoracle.c for what pins it (compiled reference C kernels in oracle/_ref +
 committed golden vectors + the reference tests' own assertions).
 """
