@@ -370,7 +370,10 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     constexpr int MR = M / R, SR = S / R;  // chunks / chunk groups of one store row
     constexpr int D = 4;  // blocks of codes in flight per wave (registers)
     static_assert(M % 32 == 0 && S >= 8, "shape");
-    static_assert(M % R == 0 && MR % 4 == 0 && SR >= 8 && (R == 1 || !SLICED), "rows per ring row");
+    static_assert(M % R == 0 && MR % 4 == 0 && (SR >= 8 || (SR == 4 && R == 2)) && (R == 1 || !SLICED), "rows per ring row");
+    // SR = 4 (m = 16, two rows per 32-chunk ring row): the eight lags span TWO store rows - quads 1..4 finish a store row at
+    // steps 0..3 (mod 4), quads 5..8 the store row before it at the same steps
+    constexpr bool kTwoGen = SR < 8;
     constexpr int kWaves = skew_waves(M), kThreads = 64 * kWaves;
     constexpr uint32_t kSlot = 16u * M, kStage0 = 0, kLut0 = kWaves * 2u * kSlot;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -510,18 +513,24 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
                 for (int e = 0; e < 8; e++) {
                     acc += vals[(G + 1) & 1][e];
                     const int u = 8 * gp + e, w = u % SR, sub = u / SR;  // step w of store row `sub` for a quad without lag
-                    if (w < 8) {  // quads r = w + 1: that was the last chunk group of their previous store row
-                        const bool fin = (int)r == w + 1;
+                    if (w < 8) {  // quads r = w + 1 (mod SR): that was the last chunk group of their previous store row
+                        const bool fin = kTwoGen ? (int)((r - 1u) & (uint32_t)(SR - 1)) == w : (int)r == w + 1;
                         done = fin ? acc : done;
                         acc = fin ? (SLICED ? init_of[jjp & 1] : 0.0f) : acc;  // their next store row starts
                     }
-                    if (w == 7) {  // every quad's previous store row is complete:  (l0 + l2) + (l1 + l3)  (:430-432)
+                    if (w == 7 % SR) {  // every quad's previous store row is complete:  (l0 + l2) + (l1 + l3)  (:430-432)
                         const float a = done + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(done), 0x4E, 0xF, 0xF, false));
                         const float sc = a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, false));
                         // sub == 0: the last store row of the ring row of block jp - 1; else store row sub - 1 of block jp's
-                        const uint32_t jb = sub == 0 ? jp - 1u : jp;
-                        const uint32_t row = ((gw + jb * n_waves) * 16u + q) * (uint32_t)R + (uint32_t)(sub == 0 ? R - 1 : sub - 1);
-                        const bool live = jb < J && row < n_rows;  // (jb = -1, -2 as unsigned: the pipeline's first trips)
+                        uint32_t jb = sub == 0 ? jp - 1u : jp, srow = (uint32_t)(sub == 0 ? R - 1 : sub - 1);
+                        bool started = true;
+                        if (kTwoGen) {  // store row F = R jp + sub - 1 of the quad's stream, one earlier for the quads 5..8
+                            const int F = (int)R * (int)jp + sub - 1 - (r > (uint32_t)SR ? 1 : 0);
+                            started = F >= 0;
+                            jb = (uint32_t)(F >> 1), srow = (uint32_t)(F & 1);  // (R == 2)
+                        }
+                        const uint32_t row = ((gw + jb * n_waves) * 16u + q) * (uint32_t)R + srow;
+                        const bool live = started && jb < J && row < n_rows;  // (jb = -1, -2 as unsigned: the pipeline's first trips)
                         if (SLICED && !sl.last) {  // the lane sums go back to `partial` for the next slice
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done), partial_rsrc, live ? (row * 4u + k) * 4u : 0xFFFFFFFFu, 0, 0);
                         } else if (FILTER) {
@@ -1320,12 +1329,12 @@ template <bool FILTER, bool SLICED> bool skew_ready_for(uint32_t nv) {
 }
 // rows of several LUT slices with m % 32 == 0: the store holds a planar scan image (alloc_store)
 bool skew_sliced_capable(const qamd_pq *h) { return skew_enabled() && h->planar.ptr != nullptr; }
-// store rows per ring row: 1 for m = 32 / 64 / 96 / 128, 2 for m = 48; 0: not a shape of the kernel
+// store rows per ring row: 1 for m = 32 / 64 / 96 / 128, 2 for m = 48 and m = 16; 0: not a shape of the kernel
 uint32_t skew_rows_per_ring_row(const qamd_pq *h) {
     // (scores leave through one buffer resource: 32-bit byte offsets)
     if (!skew_enabled() || h->ds != h->m || h->count >= (1ull << 30)) return 0;
     if (h->m % 32 == 0 && h->m <= 128) return 1;
-    return h->m == 48 ? 2 : 0;
+    return (h->m == 48 || h->m == 16) ? 2 : 0;
 }
 bool skew_capable(const qamd_pq *h) { return skew_rows_per_ring_row(h) != 0; }
 
@@ -1338,7 +1347,8 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     const uint64_t n = h->count;
     const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
     const uint32_t ring_rows = skew_rows_per_ring_row(h);
-    if (ring_rows == 2 ? skew_ready<6, 2, FILTER, false>() : ring_rows == 1 && skew_ready_for<FILTER, false>(m / 16)) {
+    if (ring_rows == 2 ? (m == 48 ? skew_ready<6, 2, FILTER, false>() : skew_ready<2, 2, FILTER, false>())
+                       : ring_rows == 1 && skew_ready_for<FILTER, false>(m / 16)) {
         // the LUT as [code][chunk]: encode_query leaves that copy behind the chunk-major one; a caller without it pays a
         // transposing launch (96 KiB, L2-resident)
         const float *lut_t = lut_t_dev;
@@ -1352,7 +1362,8 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
                        skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev,         \
                        filt ? *filt : TopkFilter{}, SkewSlice{})
-        if (ring_rows == 2) QAMD_PQ_SKEW(6, 2);
+        if (ring_rows == 2 && m == 48) QAMD_PQ_SKEW(6, 2);
+        else if (ring_rows == 2) QAMD_PQ_SKEW(2, 2);
         else switch (m / 16) {
             case 2: QAMD_PQ_SKEW(2, 1); break;
             case 4: QAMD_PQ_SKEW(4, 1); break;

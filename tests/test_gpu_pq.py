@@ -162,6 +162,9 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
                                        (128, 8, 200_003), (128, 2, 4100),
                                        # m = 48: two store rows per ring row (odd and even row counts, a lone last row)
                                        (48, 16, 300_001), (48, 2, 4096), (48, 1, 4097), (48, 4, 70_002), (48, 8, 33),
+                                       # m = 16: two store rows per 32-chunk ring row, a row end every four steps (the eight
+                                       # lags span two store rows)
+                                       (16, 8, 300_001), (16, 1, 4096), (16, 4, 4097), (16, 2, 70_003), (16, 8, 4127),
                                        # rows of several LUT slices, scanned from the planar image (96 + 96, 128 + 32, 128 + 96,
                                        # 96 x 3, four of 128)
                                        (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (288, 2, 30_001), (512, 2, 20_011)])
@@ -197,7 +200,7 @@ def test_pq_skewed_scan_shapes(qo, m, chunk, n):
 def test_pq_skewed_and_older_scan_kernels_give_the_same_bits():
     """The same stores scanned by pq_scan_skew_kernel (default) and by pq_scan_fast_kernel (QAMD_PQ_SKEW=0, a developer switch
     that only the tools/lib build reads - the product library ignores it): identical score bits and identical top-k for whole
-    rows (m = 48, 64, 96, 128) and sliced rows (m = 192, 288)."""
+    rows (m = 16, 48, 64, 96, 128) and sliced rows (m = 192, 288)."""
     import hashlib
     import os
     import subprocess
@@ -211,7 +214,7 @@ import quantization_amd as qa
 D = qa.DistanceType
 h = hashlib.sha256()
 names = []
-for m, chunk, n in ((48, 4, 40001), (64, 2, 9000), (96, 8, 50001), (128, 4, 30007), (192, 4, 20011), (288, 1, 7001)):
+for m, chunk, n in ((16, 8, 60001), (48, 4, 40001), (64, 2, 9000), (96, 8, 50001), (128, 4, 30007), (192, 4, 20011), (288, 1, 7001)):
     rng = np.random.default_rng(m)
     dim = m * chunk
     cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)
