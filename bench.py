@@ -696,14 +696,22 @@ def main():
             qa.topk_scores(out, n, args.k, largest=True, out_ids=ids, out_scores=sc)
             topk.exchange(largest=True)
 
-    # set-up, like the encode above: a few untimed passes so that the W warm-up steps and the K timed
-    # steps start from a ramped clock and warm allocator pools (the first ~10 launches of a new shape
-    # measured 5-20 % slower); they use the plain score buffer and take part in no exchange
+    # set-up, like the encode above: untimed passes so that the W warm-up steps and the K timed steps start from a ramped
+    # clock and warm allocator pools.  The ramp takes TIME, not launches: a 0.2 ms PQ scan was still getting faster 40
+    # passes in (0.228 -> 0.195 ms per launch, profiles/r04_pq.txt), so the passes go on for about a quarter of a second
+    # of GPU work whatever a pass costs; they use the plain score buffer and take part in no exchange
     prewarm = torch.empty(max(n_max, 1), dtype=torch.float32, device=dev)
-    for i in range(20):
-        encode(i, stream)
-        f_score(h_store, h_query[i % 2], C.c_void_p(prewarm.data_ptr()), _lib.MEM_DEVICE, stream)
-    torch.cuda.synchronize()
+
+    def prewarm_passes(count):
+        t0 = time.perf_counter()
+        for i in range(count):
+            encode(i, stream)
+            f_score(h_store, h_query[i % 2], C.c_void_p(prewarm.data_ptr()), _lib.MEM_DEVICE, stream)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    per_pass = prewarm_passes(20) / 20
+    prewarm_passes(min(5000, int(float(os.environ.get("QAMD_BENCH_PREWARM_S", "0.25")) / max(per_pass, 1e-6))))
     del prewarm
     for i in range(args.warmup):
         step(i, False, first=(i == 0), last=(i == args.warmup - 1))

@@ -354,6 +354,7 @@ struct SkewSlice {
     uint32_t chunk0, m_total;
     int first, last;
     float *partial;
+    uint32_t run_shift;  // a wave's blocks come in runs of 1 << run_shift consecutive ones (0 or 2; COAL: 2)
 };
 
 // R > 1: a ring row is R consecutive store rows (M = R m bytes, m % 4 == 0, m / 4 >= 8) and the LUT's columns repeat R
@@ -362,7 +363,16 @@ struct SkewSlice {
 // stream's period in chunk groups is a multiple of 8 - R m / 4 is, m / 4 need not be (m = 48: R = 2, the m = 96 shape).  A
 // quad then finishes a store row every m / 4 steps instead of every M / 4.  Per row nothing changes: lane k adds chunks
 // k, k + 4, ... of ITS row in order, (l0 + l2) + (l1 + l3).
-template <int NV, int R, bool FILTER, bool SLICED>
+//
+// Which blocks a wave takes, and how the scores leave (round 4, tools/experiments/pq_skew_probe.hip, write_mix_probe.hip):
+// with its arithmetic taken out the kernel is a stream - 16 M bytes in, 64 bytes of scores out per block - and that
+// stream, not the gathers, sets its time (m = 96, 10M rows, warm clocks: the stream alone 0.172 ms, the whole kernel 0.187,
+// its LDS loop alone 0.132).  40 MB of scores cost as much as ~180 MB of reads however they are written, but least as whole
+// lines: a wave takes RUNS of four consecutive blocks (run_shift = 2; 6 KiB of codes in a row), lane k of a quad keeps the
+// score of the run's block k, and the run's 64 scores leave as one 256-byte nt store (COAL; 0.187 -> 0.176 ms) instead of
+// four 64-byte pieces that each only fill half a line.  Small stores keep single blocks (run_shift = 0) so that every wave
+// has work.
+template <int NV, int R, bool FILTER, bool SLICED, bool COAL>
 __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
                                                                  const float *__restrict__ lut_t_g, uint32_t n_rows,
                                                                  float *__restrict__ out, TopkFilter filt, SkewSlice sl) {
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     constexpr int D = 4;  // blocks of codes in flight per wave (registers)
     static_assert(M % 32 == 0 && S >= 8, "shape");
     static_assert(M % R == 0 && MR % 4 == 0 && (SR >= 8 || (SR == 4 && R == 2)) && (R == 1 || !SLICED), "rows per ring row");
+    static_assert(!COAL || (R == 1 && !FILTER && D == 4), "the coalesced score store: one store row per ring row, runs of D = 4 blocks");
     // SR = 4 (m = 16, two rows per 32-chunk ring row): the eight lags span TWO store rows - quads 1..4 finish a store row at
     // steps 0..3 (mod 4), quads 5..8 the store row before it at the same steps
     constexpr bool kTwoGen = SR < 8;
@@ -395,9 +406,12 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     const uint32_t k = lane & 3, q = lane >> 2, r = 8u - (q & 7u);
     const uint32_t gw = blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWaves;
-    const uint32_t n_blocks = ((n_rows + R - 1) / R + 15) / 16;  // blocks of 16 ring rows; this wave: gw, gw + n_waves, ...
-    if (gw >= n_blocks) return;
-    const uint32_t J = (n_blocks - gw + n_waves - 1) / n_waves;
+    const uint32_t n_blocks = ((n_rows + R - 1) / R + 15) / 16;  // blocks of 16 ring rows
+    // this wave: the runs gw, gw + n_waves, ... of 1 << rs consecutive blocks; its j-th block is block_of(j)
+    const uint32_t rs = COAL ? 2u : sl.run_shift, n_runs = (n_blocks + (1u << rs) - 1u) >> rs;
+    if (gw >= n_runs) return;
+    const uint32_t J = ((n_runs - gw + n_waves - 1) / n_waves) << rs;  // (blocks past the last one: read as the last, never stored)
+    auto block_of = [&](uint32_t j) { return (gw << rs) + (j & ((1u << rs) - 1u)) + (((j >> rs) * n_waves) << rs); };
     const uint32_t stage = kStage0 + (threadIdx.x >> 6) * 2u * kSlot;
     // LUT byte offset of chunk 4 (u - r) + k without the code (step u adds 16 u as an immediate); steps u < r belong to
     // the previous row (chunk group u - r + S): one table row (4 M bytes) further
@@ -432,10 +446,13 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         float init;  // SLICED: the lane's sum so far for its row of the block
     };
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(gw), n_waves_u = __builtin_amdgcn_readfirstlane(n_waves);
-    const uint32_t J_u = __builtin_amdgcn_readfirstlane(J);
+    const uint32_t J_u = __builtin_amdgcn_readfirstlane(J), rs_u = __builtin_amdgcn_readfirstlane(rs);
+    const uint32_t n_blocks_u = __builtin_amdgcn_readfirstlane(n_blocks);
     const uint8_t *rows_b = reinterpret_cast<const uint8_t *>(rows4);
     auto request = [&](Held &h, uint32_t j) {  // block j of this wave (past the end: its last block again, unused)
-        const uint32_t blk = wave_u + (j < J_u ? j : J_u - 1) * n_waves_u;  // wave-uniform
+        const uint32_t jc = j < J_u ? j : J_u - 1;  // wave-uniform, like everything up to `p`
+        const uint32_t b_run = (wave_u << rs_u) + (jc & ((1u << rs_u) - 1u)) + (((jc >> rs_u) * n_waves_u) << rs_u);
+        const uint32_t blk = b_run < n_blocks_u ? b_run : n_blocks_u - 1u;
         const uint8_t *p = rows_b + (size_t)blk * 16u * M;  // (SLICED: `rows4` is the slice's own [rows][M] array)
 #pragma unroll
         for (int i = 0; i < kWide; i++) h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         codes[0][e] = lds_raw[ring_addr(0, e)];  // A(0)
         vals[1][e] = 0.0f;
     }
-    float acc = 0.0f, done = 0.0f;
+    float acc = 0.0f, done = 0.0f, keep = 0.0f;
     // All of the prologue's loads have landed before the loop starts (once per wave).  The compiler places the loop's
     // `s_waitcnt vmcnt(n)` for the state of BOTH ways into the loop header, and it orders the prologue's loads its own way
     // (all 8-byte rounds first): coming from there a buffer had 3 younger loads, so the loop waited with vmcnt(3) - for
@@ -529,12 +546,23 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
                             started = F >= 0;
                             jb = (uint32_t)(F >> 1), srow = (uint32_t)(F & 1);  // (R == 2)
                         }
-                        const uint32_t row = ((gw + jb * n_waves) * 16u + q) * (uint32_t)R + srow;
+                        const uint32_t row = (block_of(jb) * 16u + q) * (uint32_t)R + srow;
                         const bool live = started && jb < J && row < n_rows;  // (jb = -1, -2 as unsigned: the pipeline's first trips)
                         if (SLICED && !sl.last) {  // the lane sums go back to `partial` for the next slice
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done), partial_rsrc, live ? (row * 4u + k) * 4u : 0xFFFFFFFFu, 0, 0);
                         } else if (FILTER) {
                             if (k == 0 && live) topk_offer(filt, pivot, sc, row);
+                        } else if (COAL) {
+                            // jb & 3 is a constant of the unrolled loop (D = 4, j0 % 4 == 0): lane k keeps block k's score, and
+                            // after the run's last block the quads' 64 scores leave as one 256-byte store
+                            const int c = G == 0 ? 2 : ((jjp + 3) & 3);
+                            keep = (int)k == c ? sc : keep;
+                            if (c == 3) {
+                                const uint32_t jbk = jb - 3u + k;
+                                const uint32_t row_k = block_of(jbk) * 16u + q;
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), out_rsrc,
+                                                                      jbk < J && row_k < n_rows ? row_k * 4u : 0xFFFFFFFFu, 0, 2 /* nt */);
+                            }
                         } else {
                             // all four lanes of the quad hold the same bits (f32 addition commutes): they store the same word;
                             // a buffer store drops the lanes whose offset is out of range, so there is no branch here either
@@ -1309,14 +1337,25 @@ bool skew_enabled() {
 template <int NV, int R, bool FILTER, bool SLICED> bool skew_ready() {
     static DeviceOnce once;
     const qamd_status st = once.run([] {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) != hipSuccess) {
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) == hipSuccess;
+        if constexpr (R == 1 && !FILTER)  // the instance with the coalesced score store
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) == hipSuccess;
+        if (!ok) {
             (void)hipGetLastError();
             g_skew_unusable.store(true, std::memory_order_relaxed);  // (a refusal is final: the set-up counts as done)
         }
         return QAMD_OK;
     });
     return st == QAMD_OK && !g_skew_unusable.load(std::memory_order_relaxed);
+}
+// Runs of four blocks per wave once every wave has at least four runs of them; below that single blocks keep all waves busy.
+inline uint32_t skew_run_shift(uint64_t n_rows, uint32_t rows_per_ring_row, int grid, uint32_t m_ring) {
+    static const bool off = [] { const char *e = dev_env("QAMD_PQ_RUNS"); return e && e[0] == '0'; }();  // developer A/B (tools/lib build)
+    if (off) return 0u;
+    const uint64_t n_blocks = ((n_rows + rows_per_ring_row - 1) / rows_per_ring_row + 15) / 16;
+    return n_blocks >= 16ull * (uint64_t)grid * (uint64_t)skew_waves(m_ring) ? 2u : 0u;
 }
 template <bool FILTER, bool SLICED> bool skew_ready_for(uint32_t nv) {
     switch (nv) {
@@ -1358,10 +1397,22 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             hipLaunchKernelGGL(pq_lut_transpose_kernel, dim3((m * kCentroids + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lut_dev, m, ws);
             lut_t = ws;
         }
-#define QAMD_PQ_SKEW(NVV, RR)                                                                                \
-    hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
+        const uint32_t run_shift = skew_run_shift(n, ring_rows, grid, ring_rows * m);
+        SkewSlice whole{};
+        whole.run_shift = run_shift;
+#define QAMD_PQ_SKEW_AS(NVV, RR, CO)                                                                          \
+    hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false, CO>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
                        skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev,         \
-                       filt ? *filt : TopkFilter{}, SkewSlice{})
+                       filt ? *filt : TopkFilter{}, whole)
+#define QAMD_PQ_SKEW(NVV, RR)                                                      \
+    do {                                                                           \
+        if constexpr (!FILTER && RR == 1) {                                        \
+            if (run_shift == 2) QAMD_PQ_SKEW_AS(NVV, RR, true);                    \
+            else QAMD_PQ_SKEW_AS(NVV, RR, false);                                  \
+        } else {                                                                   \
+            QAMD_PQ_SKEW_AS(NVV, RR, false);                                       \
+        }                                                                          \
+    } while (0)
         if (ring_rows == 2 && m == 48) QAMD_PQ_SKEW(6, 2);
         else if (ring_rows == 2) QAMD_PQ_SKEW(2, 2);
         else switch (m / 16) {
@@ -1370,6 +1421,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             case 6: QAMD_PQ_SKEW(6, 1); break;
             case 8: QAMD_PQ_SKEW(8, 1); break;
         }
+#undef QAMD_PQ_SKEW_AS
 #undef QAMD_PQ_SKEW
         if (ws) thread_ws_release(WS_PARTIAL, s);
         QAMD_HIP(hipGetLastError());
@@ -1383,15 +1435,25 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             QAMD_TRY(thread_ws_acquire(WS_PARTIAL, h->padded * 16, s, reinterpret_cast<void **>(&partial)));
             const size_t ns = h->slice_chunks.size();
             for (size_t sl = 0; sl < ns; sl++) {
-                const SkewSlice ss{h->slice_chunk0[sl], m, sl == 0, sl + 1 == ns, partial};
+                const uint32_t run_shift = skew_run_shift(n, 1, grid, h->slice_chunks[sl]);
+                const SkewSlice ss{h->slice_chunk0[sl], m, sl == 0, sl + 1 == ns, partial, run_shift};
                 const uint4 *slice = reinterpret_cast<const uint4 *>(h->planar.as<uint8_t>() + (uint64_t)h->slice_chunk0[sl] * h->padded);
+                const bool coal = !FILTER && run_shift == 2 && sl + 1 == ns;  // the last slice writes the scores
+#define QAMD_PQ_SKEW_SLICE_AS(NVV, CO)                                                                       \
+        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, 1, FILTER, true, CO>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
+                           skew_lds_bytes(16 * NVV), s, slice, lut_t_dev, (uint32_t)n, out_dev,              \
+                           filt ? *filt : TopkFilter{}, ss)
 #define QAMD_PQ_SKEW_SLICE(NVV)                                                                              \
     case NVV:                                                                                               \
-        hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, 1, FILTER, true>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
-                           skew_lds_bytes(16 * NVV), s, slice, lut_t_dev, (uint32_t)n, out_dev,              \
-                           filt ? *filt : TopkFilter{}, ss);                                                \
+        if constexpr (!FILTER) {                                                                            \
+            if (coal) QAMD_PQ_SKEW_SLICE_AS(NVV, true);                                                     \
+            else QAMD_PQ_SKEW_SLICE_AS(NVV, false);                                                         \
+        } else {                                                                                            \
+            QAMD_PQ_SKEW_SLICE_AS(NVV, false);                                                              \
+        }                                                                                                   \
         break;
                 switch (h->slice_chunks[sl] / 16) { QAMD_PQ_SKEW_SLICE(2) QAMD_PQ_SKEW_SLICE(4) QAMD_PQ_SKEW_SLICE(6) QAMD_PQ_SKEW_SLICE(8) }
+#undef QAMD_PQ_SKEW_SLICE_AS
 #undef QAMD_PQ_SKEW_SLICE
             }
             thread_ws_release(WS_PARTIAL, s);

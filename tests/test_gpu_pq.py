@@ -167,7 +167,12 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
                                        (16, 8, 300_001), (16, 1, 4096), (16, 4, 4097), (16, 2, 70_003), (16, 8, 4127),
                                        # rows of several LUT slices, scanned from the planar image (96 + 96, 128 + 32, 128 + 96,
                                        # 96 x 3, four of 128)
-                                       (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (288, 2, 30_001), (512, 2, 20_011)])
+                                       (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (288, 2, 30_001), (512, 2, 20_011),
+                                       # stores large enough for RUNS of four consecutive blocks per wave and the coalesced
+                                       # 256-byte score store (a last run of 1, 2 and 3 blocks; two rows per ring row keeps the
+                                       # per-block store on runs)
+                                       (96, 1, 1_100_003), (32, 1, 1_048_577), (64, 1, 1_050_030), (128, 1, 530_001),
+                                       (48, 1, 2_100_001), (16, 1, 2_100_003), (192, 1, 1_050_011)])
 def test_pq_skewed_scan_shapes(qo, m, chunk, n):
     """m = 32 / 64 / 96 / 128 whole-store scans take pq_scan_skew_kernel (transposed LUT, quads skewed in time, rows through a
     per-wave LDS ring): same bits as the oracle's score_point_sse order for row counts that are not multiples of 16, waves

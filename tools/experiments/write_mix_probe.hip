@@ -1,0 +1,140 @@
+// Stand-alone probe (not built into the library): what a thin stream of score writes costs a streaming read on MI355X.
+// Every wave reads blocks of 1536 bytes (16 rows of 96 code bytes: 16 + 8 bytes per lane, nt, four blocks in flight) and
+// owes 4 bytes per row = 64 bytes per block of output - the PQ scan's traffic (m = 96) without its arithmetic.
+//   BATCH  blocks a wave collects before it writes (its blocks are consecutive, so the batch is BATCH * 64 contiguous bytes)
+//   WIDE   bytes per lane and store instruction (4 or 16)
+//   AUX    cache policy of the stores (0 default, 2 nt, 16 sc1, 17 sc1 sc0, 3 nt sc0)
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/write_mix_probe tools/experiments/write_mix_probe.hip && /tmp/write_mix_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int BATCH, int WIDE, int AUX, int ROWB>  // ROWB: bytes per block = 16 rows of ROWB / 16 bytes (1536: m = 96; 2048: binary 1024 bits)
+__global__ __launch_bounds__(1024) void mix(const uint8_t *__restrict__ rows, uint32_t n_blocks, float *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t n_runs = n_blocks / BATCH;  // (the tail is dropped: timing only)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, n_blocks * 64u, 0x00020000);
+    constexpr int D = 4;
+    constexpr bool kHalf = ROWB == 1536;
+    u32x4 a[D];
+    u32x2 b[D];
+    const uint32_t my_runs = gw < n_runs ? (n_runs - gw + n_waves - 1) / n_waves : 0, my_blocks = my_runs * BATCH;
+    auto request = [&](int slot, uint32_t j) {  // this wave's j-th block (past its last: that one again)
+        const uint32_t jc = j < my_blocks ? j : my_blocks - 1;
+        const uint8_t *p = rows + ((size_t)(gw + (jc / BATCH) * n_waves) * BATCH + jc % BATCH) * ROWB;
+        a[slot] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p) + lane);
+        if (kHalf) b[slot] = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p + 1024) + lane);
+        else b[slot] = u32x2{a[slot].x, a[slot].y} , a[slot] = a[slot] ^ __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + 1024) + lane);
+    };
+    constexpr int NK = BATCH >= 4 ? BATCH / 4 : 1;  // dwords a lane owes per batch
+    constexpr int U = BATCH >= D ? BATCH : D;        // blocks per trip of the unrolled loop (a multiple of both)
+    if (my_runs == 0) return;
+#pragma unroll
+    for (int i = 0; i < D; i++) request(i, i);
+    uint32_t keep[NK];
+    for (uint32_t j0 = 0; j0 < my_blocks; j0 += U) {
+#pragma unroll
+      for (int ii = 0; ii < U; ii++) {
+        const int i = ii % BATCH;
+        const uint32_t run = gw + ((j0 + ii) / BATCH) * n_waves;
+        {
+            const u32x4 va = a[ii % D];
+            const u32x2 vb = b[ii % D];
+            request(ii % D, j0 + ii + D);
+            uint32_t v = va.x ^ va.y ^ va.z ^ va.w ^ vb.x ^ vb.y;
+            v ^= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+            v ^= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+            if (BATCH >= 4) keep[i >> 2] = (int)(lane & 3) == (i & 3) ? v : ((i & 3) == 0 ? 0u : keep[i >> 2]);
+            else keep[0] = v;
+        }
+        if (i != BATCH - 1 || j0 + ii >= my_blocks) continue;
+        uint32_t base = run * BATCH * 64u;  // bytes (BATCH < 4: of the run's first block)
+        if (AUX < 0) {  // no stores at all (the value test never passes)
+            uint32_t any = 0;
+#pragma unroll
+            for (int z = 0; z < NK; z++) any |= keep[z];
+            if (any == 0x12345678u) out[lane] = 1.0f;
+            continue;
+        }
+        if (BATCH < 4) {  // one row quad = one dword: 16 dwords per block
+            __builtin_amdgcn_raw_buffer_store_b32(keep[0], rsrc, (lane & 3) == 0 ? base + (uint32_t)i * 64u + (lane >> 2) * 4u : 0xFFFFFFFFu, 0, AUX < 0 ? 0 : AUX);
+        } else if (WIDE == 4) {
+#pragma unroll
+            for (int z = 0; z < NK; z++) __builtin_amdgcn_raw_buffer_store_b32(keep[z], rsrc, base + z * 256u + lane * 4u, 0, AUX < 0 ? 0 : AUX);
+        } else {
+#pragma unroll
+            for (int z = 0; z < NK; z += 4) {
+                u32x4 w = {keep[z], keep[z + (NK > 1 ? 1 : 0)], keep[z + (NK > 2 ? 2 : 0)], keep[z + (NK > 3 ? 3 : 0)]};
+                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, base + z * 256u + lane * 16u, 0, AUX < 0 ? 0 : AUX);
+            }
+        }
+      }
+    }
+}
+
+template <int BATCH, int WIDE, int AUX, int ROWB>
+static float once(const uint8_t *rows, uint32_t n_blocks, float *out, int waves) {
+    auto k = mix<BATCH, WIDE, AUX, ROWB>;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(256), dim3(64 * waves), 0, 0, rows, n_blocks, out);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(k, dim3(256), dim3(64 * waves), 0, 0, rows, n_blocks, out);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ms / 10;
+}
+
+struct Cfg {
+    const char *name;
+    float (*fn)(const uint8_t *, uint32_t, float *, int);
+    int waves;
+    int rowb;
+};
+
+int main() {
+    const size_t bytes = 960000000ull;  // 10M rows of 96 bytes = 625 000 blocks of 1536
+    uint8_t *rows;
+    float *out;
+    CK(hipMalloc(&rows, bytes + 65536));
+    {
+        std::vector<uint32_t> h((bytes + 65536) / 4);
+        uint32_t x = 12345;
+        for (auto &w : h) x = x * 1664525u + 1013904223u, w = x;
+        CK(hipMemcpy(rows, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&out, 64ull * (bytes / 1536) + 65536));
+#define C(B, W, A, R, WV) {"batch " #B " blocks, " #W " B/lane, aux " #A ", block " #R " B, " #WV " waves", once<B, W, A, R>, WV, R}
+    Cfg cfgs[] = {
+        C(4, 4, -1, 1536, 16), C(4, 4, -1, 2048, 16), C(4, 4, -1, 1536, 8), C(16, 4, -1, 1536, 16), C(16, 4, -1, 1536, 12),
+        C(1, 4, 0, 1536, 16),   C(4, 4, 0, 1536, 16),   C(4, 4, 2, 1536, 16),   C(16, 4, 0, 1536, 16),  C(16, 4, 2, 1536, 16),
+        C(16, 16, 0, 1536, 16), C(16, 16, 2, 1536, 16), C(64, 16, 0, 1536, 16), C(64, 16, 2, 1536, 16), C(64, 4, 2, 1536, 16),
+        C(16, 16, 16, 1536, 16), C(16, 16, 17, 1536, 16), C(16, 16, 3, 1536, 16), C(16, 16, 2, 1536, 8), C(64, 16, 2, 1536, 8),
+        C(1, 4, 0, 2048, 16),   C(4, 4, 2, 2048, 16),   C(16, 16, 2, 2048, 16), C(64, 16, 2, 2048, 16),
+    };
+    const int NC = sizeof(cfgs) / sizeof(cfgs[0]), ROUNDS = 4;
+    double t[64][ROUNDS];
+    for (int r = -1; r < ROUNDS; r++)
+        for (int c = 0; c < NC; c++) {
+            const float ms = cfgs[c].fn(rows, (uint32_t)(bytes / cfgs[c].rowb), out, cfgs[c].waves);
+            if (r >= 0) t[c][r] = ms;
+        }
+    for (int c = 0; c < NC; c++) {
+        double mn = 1e9, sum = 0;
+        for (int r = 0; r < ROUNDS; r++) mn = t[c][r] < mn ? t[c][r] : mn, sum += t[c][r];
+        printf("%-60s min %.4f mean %.4f ms  reads %.2f TB/s\n", cfgs[c].name, mn, sum / ROUNDS, bytes / (sum / ROUNDS) / 1e9);
+    }
+    return 0;
+}

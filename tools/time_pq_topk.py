@@ -29,14 +29,16 @@ for n, dim, chunk in shapes:
     sc = torch.empty(30, dtype=torch.float32, device=dev)
     out = torch.empty(n, dtype=torch.float32, device=dev)
     for name, fn in (("topk(30)", lambda: enc.topk(q, 30, out_ids=ids, out_scores=sc)), ("score_all", lambda: enc.score_all(q, out=out))):
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize()
+        t_warm = time.perf_counter()  # the clock ramps with busy TIME, not launches: a quarter of a second of calls first
+        while time.perf_counter() - t_warm < 0.25:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(50):
+        for _ in range(200):
             fn()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 50 * 1e3
+        ms = (time.perf_counter() - t0) / 200 * 1e3
         print(f"{n} x {dim} m={m} {enc.scan_kernel()} {name}: {ms:.4f} ms per call = {n * m / ms / 1e9:.2f} TB/s of code bytes = "
               f"{n * m / ms / 1e9 / 8:.3f} of 8 TB/s", flush=True)
     del enc, out
