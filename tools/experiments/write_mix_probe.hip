@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -97,6 +98,44 @@ static float once(const uint8_t *rows, uint32_t n_blocks, float *out, int waves)
     return ms / 10;
 }
 
+
+// The u8 encoder's traffic without its arithmetic: per row 3072 bytes of f32 read (nt) and 768 + 4 bytes written.  A wave
+// takes 4 KiB of input per trip (64 lanes x 4 x 16 bytes, RD_PER_WR trips per KiB written), two trips in flight.
+template <int RD_PER_WR, int AUX>
+__global__ __launch_bounds__(512) void copy_ratio(const u32x4 *__restrict__ in, uint64_t n_kib_in, u32x4 *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t n_units = n_kib_in / RD_PER_WR;  // a unit: RD_PER_WR KiB in, 1 KiB out
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0xFFFFFFFFu, 0x00020000);
+    for (uint64_t u = gw; u < n_units; u += n_waves) {
+        u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < RD_PER_WR; i++) acc ^= __builtin_nontemporal_load(in + (u * RD_PER_WR + i) * 64 + lane);
+        if (AUX < 0) {
+            if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[lane] = acc;
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(acc, rsrc, (uint32_t)(u * 1024 + lane * 16), 0, AUX < 0 ? 0 : AUX);
+        }
+    }
+}
+template <int RD_PER_WR, int AUX>
+static float once_copy(const uint8_t *rows, uint32_t, float *out, int) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const uint64_t n_kib = 960000000ull / 1024;
+    auto k = copy_ratio<RD_PER_WR, AUX>;
+    hipLaunchKernelGGL(k, dim3(256 * 8), dim3(512), 0, 0, reinterpret_cast<const u32x4 *>(rows), n_kib, reinterpret_cast<u32x4 *>(out));
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 10; i++)
+        hipLaunchKernelGGL(k, dim3(256 * 8), dim3(512), 0, 0, reinterpret_cast<const u32x4 *>(rows), n_kib, reinterpret_cast<u32x4 *>(out));
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / 10;
+}
+
 struct Cfg {
     const char *name;
     float (*fn)(const uint8_t *, uint32_t, float *, int);
@@ -115,7 +154,7 @@ int main() {
         for (auto &w : h) x = x * 1664525u + 1013904223u, w = x;
         CK(hipMemcpy(rows, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     }
-    CK(hipMalloc(&out, 64ull * (bytes / 1536) + 65536));
+    CK(hipMalloc(&out, bytes / 2 + 65536));  // (the copy kernels write up to half of what they read)
 #define C(B, W, A, R, WV) {"batch " #B " blocks, " #W " B/lane, aux " #A ", block " #R " B, " #WV " waves", once<B, W, A, R>, WV, R}
     Cfg cfgs[] = {
         C(4, 4, -1, 1536, 16), C(4, 4, -1, 2048, 16), C(4, 4, -1, 1536, 8), C(16, 4, -1, 1536, 16), C(16, 4, -1, 1536, 12),
@@ -123,18 +162,26 @@ int main() {
         C(16, 16, 0, 1536, 16), C(16, 16, 2, 1536, 16), C(64, 16, 0, 1536, 16), C(64, 16, 2, 1536, 16), C(64, 4, 2, 1536, 16),
         C(16, 16, 16, 1536, 16), C(16, 16, 17, 1536, 16), C(16, 16, 3, 1536, 16), C(16, 16, 2, 1536, 8), C(64, 16, 2, 1536, 8),
         C(1, 4, 0, 2048, 16),   C(4, 4, 2, 2048, 16),   C(16, 16, 2, 2048, 16), C(64, 16, 2, 2048, 16),
+        {"960 MB read, nothing written (4 KiB per wave and trip)", once_copy<4, -1>, 8, 0},
+        {"read 4 : written 1, nt (the u8 encoder's ratio: 3072 B in, 772 out)", once_copy<4, 2>, 8, 4},
+        {"read 4 : written 1, default policy", once_copy<4, 0>, 8, 4},
+        {"read 2 : written 1, nt", once_copy<2, 2>, 8, 2},
+        {"read 8 : written 1, nt", once_copy<8, 2>, 8, 8},
+        {"read 16 : written 1, nt", once_copy<16, 2>, 8, 16},
     };
     const int NC = sizeof(cfgs) / sizeof(cfgs[0]), ROUNDS = 4;
     double t[64][ROUNDS];
     for (int r = -1; r < ROUNDS; r++)
         for (int c = 0; c < NC; c++) {
-            const float ms = cfgs[c].fn(rows, (uint32_t)(bytes / cfgs[c].rowb), out, cfgs[c].waves);
+            const float ms = cfgs[c].fn(rows, cfgs[c].rowb >= 1024 ? (uint32_t)(bytes / cfgs[c].rowb) : 0u, out, cfgs[c].waves);
             if (r >= 0) t[c][r] = ms;
         }
     for (int c = 0; c < NC; c++) {
         double mn = 1e9, sum = 0;
         for (int r = 0; r < ROUNDS; r++) mn = t[c][r] < mn ? t[c][r] : mn, sum += t[c][r];
-        printf("%-60s min %.4f mean %.4f ms  reads %.2f TB/s\n", cfgs[c].name, mn, sum / ROUNDS, bytes / (sum / ROUNDS) / 1e9);
+        const double wr = cfgs[c].rowb >= 1024 ? (strstr(cfgs[c].name, "aux -1") ? 0.0 : 64.0 * (bytes / cfgs[c].rowb)) : (cfgs[c].rowb ? (double)bytes / cfgs[c].rowb : 0.0);
+        printf("%-72s min %.4f mean %.4f ms  reads %.2f TB/s  reads + writes %.2f TB/s\n", cfgs[c].name, mn, sum / ROUNDS, bytes / (sum / ROUNDS) / 1e9,
+               (bytes + wr) / (sum / ROUNDS) / 1e9);
     }
     return 0;
 }
