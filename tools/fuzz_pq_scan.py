@@ -23,8 +23,12 @@ bad = 0
 for case in range(cases):
     m = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256, 288, 384, 512, 16, 48, 80, 100, 144, 176]))
     chunk = int(rng.choice([1, 2, 4, 8]))
+    # (from ~0.5M / 1M / 2M rows on - by waves per workgroup and rows per ring row - a wave takes runs of four blocks and the
+    # plain score output leaves as 256-byte stores: the last choice)
+    n = int(rng.choice([rng.integers(4096, 4200), rng.integers(4200, 70_000), rng.integers(70_000, 600_000), rng.integers(520_000, 2_300_000)]))
+    if n > 600_000:
+        chunk = 1
     dim = m * chunk - (int(rng.integers(0, chunk)) if m % 16 else 0)
-    n = int(rng.choice([rng.integers(4096, 4200), rng.integers(4200, 70_000), rng.integers(70_000, 600_000)]))
     dist = [D.Dot, D.L2, D.L1][int(rng.integers(0, 3))]
     invert, largest = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     k = int(rng.choice([1, 10, 30, 64, 100]))
