@@ -18,7 +18,8 @@ run batch1024   u8_batch1024_768    u8_gemm_qs16_kernel           10000000  772 
 run batch1024_1536 u8_batch1024_1536 u8_gemm_qs16_kernel          12500000  1540   1 0 -- --batch-queries 1024 --k 30 --steps 5 --warmup 3 --dim 1536 --rows 12500000
 run batch64     u8_batch64_768      u8_gemm_rs_kernel             10000000  772    1 0 -- --batch-queries 64 --k 30 --steps 10 --warmup 5
 run bin_batch64 bin_batch64_1024    bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 64 --k 30 --steps 10 --warmup 5
-run bin_batch1024 bin_batch1024_1024 bin_gemm_qs4_kernel          50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 1024 --k 30 --steps 3 --warmup 2
+run bin_batch1024 bin_batch1024_1024 bin_gemm_rs4_kernel          50000000  128    4 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 1024 --k 30 --steps 3 --warmup 2
 run bin_batch128 bin_batch128_1024  bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 128 --k 30 --steps 10 --warmup 5
 run bin_batch256 bin_batch256_1024  bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 256 --k 30 --steps 10 --warmup 5
+run bin_batch512 bin_batch512_1024  bin_gemm_rs4_kernel           50000000  128    2 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 512 --k 30 --steps 5 --warmup 3
 run batch256    u8_batch256_768     u8_gemm_qr16_kernel           10000000  772    1 0 -- --batch-queries 256 --k 30 --steps 10 --warmup 5

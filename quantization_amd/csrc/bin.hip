@@ -1551,6 +1551,7 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
 // where the staging copy puts it (any pairing of K positions is the same dot product).  Arithmetic, bounds and candidate
 // lists are bin_gemm_qs4_kernel's.
 constexpr uint32_t kRs4MinQueries = 12;
+constexpr uint32_t kRs4MaxPasses = 4;  // (measured: profiles/r04_bin_batch.txt; four passes tie with the query-streaming form)
 inline uint32_t rs4_max_queries(uint64_t ds) {  // whole 32-query tile pairs whose nibble image + bounds fit the CU's LDS
     return (uint32_t)((160 * 1024 - 1024) / (ds * 4 + 4) / 32 * 32);
 }
@@ -1795,9 +1796,16 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     static const char *ers4 = dev_env("QAMD_BIN_RS4");  // developer A/B: 0 = without the row-streaming fp4 form
     const bool fp4_shape = (h->ds == 64 || h->ds == 96 || h->ds == 128 || h->ds == 192) && !(e4 && e4[0] == '0');
     // the whole batch's nibble image in LDS: the row-streaming fp4 form (one pass, no barriers); larger batches: query-streaming
-    const bool rs4 = fp4_shape && !(ers4 && ers4[0] == '0') && Q >= kRs4MinQueries && round_up(Q, 32) <= rs4_max_queries(h->ds);
+    // A batch of up to kRs4MaxPasses LDS images goes through that form in as many passes over the rows, the queries spread evenly
+    // (50M x 1024 bits: 289 queries = two passes of 160: 6.4 ms against the query-streaming form's 10.1; 576 = 2 x 288: 10.4 / 15.7)
+    static const char *ers4p = dev_env("QAMD_BIN_RS4_PASSES");  // developer A/B: the most passes the row-streaming form may take
+    const uint32_t rs4_cap = rs4_max_queries(h->ds), rs4_most = ers4p ? (uint32_t)atoi(ers4p) : kRs4MaxPasses;
+    const uint32_t rs4_passes = rs4_cap ? (uint32_t)((round_up(Q, 32) + rs4_cap - 1) / rs4_cap) : 0u;
+    const bool rs4 = fp4_shape && !(ers4 && ers4[0] == '0') && Q >= kRs4MinQueries && rs4_passes >= 1 && rs4_passes <= rs4_most;
+    const uint32_t rs4_per_pass = rs4 ? (uint32_t)round_up((Q + rs4_passes - 1) / rs4_passes, 32) : 0u;  // queries per pass (whole tile pairs)
     const bool qs4 = rs4 || (fp4_shape && Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries));
-    const uint32_t n_lists = rs4 ? pp_waves_per_launch() / 8 * (uint32_t)rs4_waves((int)(h->ds / 16))  // one list per wave of the launch
+    const uint32_t rs4_lists = pp_waves_per_launch() / 8 * (uint32_t)rs4_waves((int)(h->ds / 16));  // one list per wave of a launch
+    const uint32_t n_lists = rs4 ? rs4_passes * rs4_lists
                                  : pp_waves_per_launch() * (qs4 ? (uint32_t)((Q + kQs4Slice - 1) / kQs4Slice) : 1u);
     const double per_wave = 2.0 * target * (double)std::min<uint64_t>(Q, qs4 ? kQs4Slice : TQ) / (double)pp_waves_per_launch();
     // (at least 1024 slots: queries of one batch can be near-duplicates, and then a passing row appends to every
@@ -1861,17 +1869,22 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
         const size_t qs_rows = h->ds > 128 ? 96 : 128;
         const size_t lds = 2 * qs_rows * round_up(h->ds * 4, 256) + 4 * qs_rows * 4 + 64 + kQs4Slice * 4;
         const uint32_t grid = (uint32_t)std::max(1, device_info().cu_count / 8) * 8;
-        if (rs4) {
-            const uint32_t n_tiles = (uint32_t)(round_up(Q, 32) / 16);
+        if (rs4)
+        for (uint32_t pass = 0; pass < rs4_passes; pass++) {
+            const uint64_t q_base = (uint64_t)pass * rs4_per_pass;
+            if (q_base >= Q) break;
+            const uint32_t nq = (uint32_t)std::min<uint64_t>(rs4_per_pass, Q - q_base);
+            const uint32_t n_tiles = (uint32_t)(round_up(nq, 32) / 16);
             const size_t lds4 = (size_t)n_tiles * h->ds * 64 + (size_t)n_tiles * 64 + 64;
             BatchFilter fs = f;
-            fs.query_base = 0;
-            fs.wave_base = 0;
+            fs.pivot_scores = pivots + q_base;
+            fs.query_base = (uint32_t)q_base;
+            fs.wave_base = pass * rs4_lists;
 #define QAMD_RS4_NS(M_, LOW_, NS_)                                                                                          \
     do {                                                                                                                   \
         QAMD_LDS_OPT_IN((&bin_gemm_rs4_kernel<M_, LOW_, NS_>), 160 * 1024);                                                 \
-        hipLaunchKernelGGL((bin_gemm_rs4_kernel<M_, LOW_, NS_>), dim3(grid), dim3(64 * rs4_waves(NS_)), lds4, s, h->rows.as<uint8_t>(), frag, \
-                           q_off, bq, zx ? 1 : 0, (uint32_t)n, n_tiles, fs);                                               \
+        hipLaunchKernelGGL((bin_gemm_rs4_kernel<M_, LOW_, NS_>), dim3(grid), dim3(64 * rs4_waves(NS_)), lds4, s, h->rows.as<uint8_t>(), \
+                           frag + (q_base / 16) * nsteps * 64, q_off + q_base, bq + q_base, zx ? 1 : 0, (uint32_t)n, n_tiles, fs); \
     } while (0)
 #define QAMD_RS4(M_, LOW_)                                                                                                  \
     do {                                                                                                                   \

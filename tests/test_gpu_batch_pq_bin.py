@@ -110,6 +110,12 @@ def test_batch_edge_cases():
     (1536, 50_000, 192),    # ... of 1536-bit rows: twelve k-steps (193 queries go to the query-streaming form)
     (768, 33_333, 16),      # six k-steps (8-byte row loads), a ragged last trip
     (1024, 32_768 + 31, 64),
+    # ... and larger batches in up to four passes of that form, the queries spread evenly over the passes:
+    (1024, 40_000, 289),    # two passes of 160
+    (1024, 33_000, 1024),   # four of 256
+    (1024, 33_000, 1152),   # four of 288: the largest; 1153 queries go to the query-streaming form
+    (1024, 33_000, 1153),
+    (768, 33_000, 900),     # three passes of 320 at 768 bits
 ])
 def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
     """12 queries and more on 32k rows and more take the matrix cores - bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
@@ -127,7 +133,8 @@ def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
     for dist, invert, largest in ((D.Dot, False, True), (D.L2, False, False), (D.Dot, True, False), (D.L1, True, True)):
         enc = qa.EncodedVectorsBin.encode(data, qa.VectorParameters(dim, n, dist, invert))
         ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30, largest=largest)
-        picks = sorted({0, 1, min(31, nq - 1), min(32, nq - 1), nq // 2, nq - 2, nq - 1})
+        picks = sorted({0, 1, min(31, nq - 1), min(32, nq - 1), nq // 2, nq - 2, nq - 1} |
+                       {q for b in (160, 256, 288, 320, 512, 576, 640, 768, 864) for q in (b - 1, b, b + 1) if q < nq})  # pass boundaries
         for j, qi in enumerate(picks):
             wi, ws = enc.topk(enc.encode_query(queries[qi]), 30, largest=largest)
             assert np.array_equal(ids[qi], wi), (dist, invert, largest, qi)

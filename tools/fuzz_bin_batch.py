@@ -21,7 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda", 0)
 bad = 0
 for case in range(cases):
-    nq = int(rng.choice([5, 11, 12, 13, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200, 256, 257, 288, 300, 700]))
+    nq = int(rng.choice([5, 11, 12, 13, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200, 256, 257, 288, 289, 300, 576, 577, 700, 1000, 1152, 1153]))
     dim = int(rng.choice([64, 65, 100, 128, 129, 256, 384, 512, 500, 768, 700, 1000, 1024, 1536, 1500, 2048, 2304, 2320, 4096, 4992, 5000, 8192]))
     n = int(rng.choice([rng.integers(32_768, 40_000), rng.integers(40_000, 300_000), rng.integers(1000, 32_768)]))
     dist = [D.Dot, D.L2, D.L1][int(rng.integers(0, 3))]
