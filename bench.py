@@ -550,6 +550,17 @@ def main():
             el = float(t.item())
         return el
 
+    def batch_roofline(tops, mfma_peak, ops_per_step, read_bytes_per_step, step_s):
+        """A batch step has two floors: the store's rows leave HBM once, and the pairs cost 2 * actual_dim matrix-core ops each.
+        The larger floor is the bound the step is priced against; the other side's figures ride along."""
+        t_hbm, t_mfma = read_bytes_per_step / (HBM_PEAK_GBPS * 1e9), ops_per_step / (mfma_peak * 1e12)
+        gbps = read_bytes_per_step / step_s / 1e9
+        both = {"mfma_achieved_TOPs": tops, "mfma_peak_TOPs": mfma_peak, "mfma_frac": tops / mfma_peak,
+                "hbm_achieved_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS, "floor_ms": {"hbm": t_hbm * 1e3, "mfma": t_mfma * 1e3}}
+        if t_hbm >= t_mfma:
+            return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, **both}
+        return {"bound": "mfma", "achieved": tops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tops / mfma_peak, **both}
+
     if args.batch_queries > 0:
         if args.quantizer not in ("u8", "binary"):
             raise SystemExit("--batch-queries is the matrix-core multi-query path (u8, binary)")
@@ -587,9 +598,9 @@ def main():
             is_bin = args.quantizer == "binary"
             ad = dim if is_bin else enc.metadata["actual_dim"]  # binary: one 0/1 operand byte per bit on the matrix cores
             ops = 2.0 * Q * n * ad  # per GPU and step
-            # binary batches of 12+ queries on rows of 4 / 6 / 8 / 12 128-bit words take the fp4 matrix-core kernels (csrc/bin.hip:
+            # binary batches of 3 and of 5+ queries on rows of 4 / 6 / 8 / 12 128-bit words take the fp4 matrix-core kernels (csrc/bin.hip:
             # bin_gemm_rs4_kernel while the batch's nibble image fits in LDS, bin_gemm_qs4_kernel beyond)
-            bin_fp4 = is_bin and Q >= 12 and (ad + 127) // 128 in (4, 6, 8, 12)
+            bin_fp4 = is_bin and (Q == 3 or Q >= 5) and (ad + 127) // 128 in (4, 6, 8, 12)
             mfma_peak = MFMA_FP4_PEAK_TOPS if bin_fp4 else MFMA_INT8_PEAK_TOPS
             per_gpu_tops = ops * args.steps / elapsed / 1e12
             row_bytes = nb if is_bin else bytes_per_row
@@ -628,8 +639,8 @@ def main():
                                        f"topk_batch over the shard + all-gather of world*Q*k pairs + per-query merge "
                                        f"on the GPU",
                            "rows_per_gpu": n, "dim": dim, "queries": Q, "k": k, "total_rows": total_rows, **dist_info},
-                "roofline": {"bound": "mfma", "achieved": per_gpu_tops, "peak": mfma_peak, "unit": "TFLOP/s",
-                             "frac": per_gpu_tops / mfma_peak, "traffic": traffic, "traffic_source": source,
+                "roofline": batch_roofline(per_gpu_tops, mfma_peak, ops, n * row_bytes, elapsed / args.steps) | {
+                             "traffic": traffic, "traffic_source": source,
                              "algorithmic_read_bytes_per_step": n * row_bytes,
                              "note": ("fp4" if bin_fp4 else "int8") + " op/s per GPU over the whole step (sample pass, filter GEMM, scatter, "
                                      "sort, exchange); algorithmic ops = 2 * actual_dim per (query, row) pair; traffic = HBM bytes "

@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(512) void bin_gemm_qs4_kernel(const uint8_t *__rest
 // loads, every line fetched once); k-step s multiplies dword NS g + s of the row with the same dword of the query, which is
 // where the staging copy puts it (any pairing of K positions is the same dot product).  Arithmetic, bounds and candidate
 // lists are bin_gemm_qs4_kernel's.
-constexpr uint32_t kRs4MinQueries = 12;
+constexpr uint32_t kRs4MinQueries = 12;  // (the int8 matrix-core form; the fp4 form takes 3 and 5+ queries)
 constexpr uint32_t kRs4MaxPasses = 4;  // (measured: profiles/r04_bin_batch.txt; four passes tie with the query-streaming form)
 inline uint32_t rs4_max_queries(uint64_t ds) {  // whole 32-query tile pairs whose nibble image + bounds fit the CU's LDS
     return (uint32_t)((160 * 1024 - 1024) / (ds * 4 + 4) / 32 * 32);
@@ -1801,7 +1801,7 @@ qamd_status bin_topk_batch_mfma(const qamd_bin *h, const qamd_bin_query_batch *b
     static const char *ers4p = dev_env("QAMD_BIN_RS4_PASSES");  // developer A/B: the most passes the row-streaming form may take
     const uint32_t rs4_cap = rs4_max_queries(h->ds), rs4_most = ers4p ? (uint32_t)atoi(ers4p) : kRs4MaxPasses;
     const uint32_t rs4_passes = rs4_cap ? (uint32_t)((round_up(Q, 32) + rs4_cap - 1) / rs4_cap) : 0u;
-    const bool rs4 = fp4_shape && !(ers4 && ers4[0] == '0') && Q >= kRs4MinQueries && rs4_passes >= 1 && rs4_passes <= rs4_most;
+    const bool rs4 = fp4_shape && !(ers4 && ers4[0] == '0') && rs4_passes >= 1 && rs4_passes <= rs4_most;
     const uint32_t rs4_per_pass = rs4 ? (uint32_t)round_up((Q + rs4_passes - 1) / rs4_passes, 32) : 0u;  // queries per pass (whole tile pairs)
     const bool qs4 = rs4 || (fp4_shape && Q >= (e4min ? (uint64_t)atoll(e4min) : kQs4MinQueries));
     const uint32_t rs4_lists = pp_waves_per_launch() / 8 * (uint32_t)rs4_waves((int)(h->ds / 16));  // one list per wave of a launch
@@ -2126,7 +2126,12 @@ qamd_status qamd_bin_topk_batch(const qamd_bin *h, const qamd_bin_query_batch *b
     // candidate list over- or underflowed there (heavy ties at small dims) go through the path below one by one
     const uint64_t Q = b->n_queries;
     hipStream_t s = as_stream(stream);
-    if (Q >= 12 && h->count >= 32768 && k <= 1024 && fused_capable(h) && bin_mfma_frags(h->ds) != 0 && h->vp.dim >= 64) {
+    static const char *emin = dev_env("QAMD_BIN_MFMA_MIN");  // developer A/B: the smallest batch the matrix cores take
+    // rows of 512 / 768 / 1024 / 1536 bits: a pass of the row-streaming fp4 kernel costs 1.4-1.5 ms per 50M x 1024 whatever the batch,
+    // the vector-ALU scan 1.04 / 1.98 / 1.26 / 2.2 / 1.8 / 3.7 ms at 2 / 3 / 4 / 5 / 8 / 11 queries (profiles/r04_bin_batch.txt)
+    const bool fp4_rows = h->ds == 64 || h->ds == 96 || h->ds == 128 || h->ds == 192;
+    const bool enough = emin ? Q >= (uint64_t)atoll(emin) : (fp4_rows ? (Q == 3 || Q >= 5) : Q >= kRs4MinQueries);
+    if (enough && h->count >= 32768 && k <= 1024 && fused_capable(h) && bin_mfma_frags(h->ds) != 0 && h->vp.dim >= 64) {
         StreamBuf ids_tmp, sc_tmp;
         uint32_t *ids_dev = out_ids;
         float *sc_dev = out_scores;

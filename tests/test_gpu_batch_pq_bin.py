@@ -103,8 +103,10 @@ def test_batch_edge_cases():
     (1536, 40_000, 300),    # 1536-bit rows: 96-row blocks, twelve k-steps
     (1500, 35_000, 100 + 60),  # ... pad bits, chunks of 32 queries in registers (12 k-steps x 2 tiles)
     (1024, 40_000, 2100),   # two launch slices of 2048 queries
-    # round 4: batches whose nibble image fits in LDS take the row-streaming fp4 form (bin_gemm_rs4_kernel) from 12 queries on:
+    # round 4: batches whose nibble image fits in LDS take the row-streaming fp4 form (bin_gemm_rs4_kernel), from 3 / 5 queries on:
     (1024, 70_001, 12),     # one tile pair, the second tile all padding
+    (1024, 50_001, 3), (1024, 50_001, 5), (768, 40_000, 7), (512, 40_000, 11), (1536, 40_000, 9),  # the smallest batches it takes
+    (1024, 50_001, 4), (2048, 40_000, 5),  # (4 queries, other row lengths: the vector-ALU scan)
     (1024, 33_000, 288),    # the largest batch of 1024-bit rows (144 KiB of nibbles)
     (512, 40_000, 608),     # ... of 512-bit rows: 38 query tiles, four k-steps
     (1536, 50_000, 192),    # ... of 1536-bit rows: twelve k-steps (193 queries go to the query-streaming form)
@@ -118,7 +120,7 @@ def test_batch_edge_cases():
     (768, 33_000, 900),     # three passes of 320 at 768 bits
 ])
 def test_binary_batch_on_the_matrix_cores(dim, n, nq, qo):
-    """12 queries and more on 32k rows and more take the matrix cores - bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
+    """3 and 5+ queries (12+ on other row lengths) on 32k rows and more take the matrix cores - bin_gemm_rs_kernel (bits expanded to 0/1 bytes in
     registers, int8 MFMA, u8-style epilogue with integer operands); on rows of 512 / 768 / 1024 / 1536 bits the FP4 matrix
     cores (bits as E2M1 nibbles, exact f32 counts): bin_gemm_rs4_kernel while the batch's nibble image fits in LDS (queries
     resident, every wave streams its own rows), bin_gemm_qs4_kernel beyond: every list must equal the single-query
