@@ -1950,6 +1950,160 @@ __global__ __launch_bounds__(512) void u8_gemm_qr16_kernel(const uint8_t *__rest
     if (FILTER && lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * 8 + wave] = *wcount_s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Queries RESIDENT, rows streamed, 16 x 16 x 64 (late round 4): the form that took the binary batches off their floor
+// (bin_gemm_rs4_kernel), for u8.  The query-streaming kernel pays per 128-row block a synchronous block change and an
+// epilogue during which its matrix pipes idle (K loop 72 % of a block at 1024 queries); here a workgroup keeps a GROUP of
+// the batch's query tiles in LDS in fragment order (up to 12 tiles of 768-byte queries: 144 KiB) for the whole launch, and
+// every wave streams its OWN rows - 32 per trip (two 16-row tiles), straight from memory into registers in fragment order
+// (lane (i, g): bytes [64 j + 16 g, + 16) of row i for k-step j, exactly the B operand; no LDS hop, no re-layout), the
+// next trip's rows requested a whole trip ahead into a second register set - and multiplies them with every tile of its
+// group: per pair of query tiles and k-step two fragment reads (conflict-free: a tile x k-step is one lane-linear 1 KiB
+// piece) feed four MFMAs.  No barrier after the set-up.
+// A batch larger than one group's LDS is cut into G groups that run AT THE SAME TIME on different CUs of the same XCD:
+// workgroup b sits on XCD b % 8 (round-robin placement - speed only), its slot b / 8 there gives group slot % G and row
+// stream slot / G, and the G workgroups of a stream walk the same rows in the same order, so a row leaves HBM once and
+// the other groups find it in that XCD's L2 (or the memory-side cache).  Arithmetic, bounds and candidate lists are
+// u8_gemm_qr16_kernel's.
+struct RqGeometry {
+    uint32_t groups, pairs_lo /* tile pairs of every group */, pairs_extra /* the first so many groups take one more */,
+        streams_per_xcd, n_tiles /* of the batch, even */;
+};
+constexpr uint32_t rq_tile_cap(uint32_t nsteps) { return ((160u * 1024u - 2048u) / (nsteps * 1024u + 64u)) & ~1u; }
+template <int MODE, bool LOW, int NSTEPS>
+__global__ __launch_bounds__(512) void u8_gemm_rq16_kernel(const uint8_t *__restrict__ codes, const float *__restrict__ v_offsets,
+                                                          const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
+                                                          const int *__restrict__ bq_all, float multiplier, uint32_t n_rows,
+                                                          RqGeometry geo, BatchFilter filt) {
+    static_assert(MODE == 1 || MODE == 2, "the filter pass of topk_batch");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr int RT = 2, QP = 2, AD = 64 * NSTEPS, WAVES = 8;
+    constexpr bool LARGEST = MODE == 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
+    const uint32_t xcd_slot = blockIdx.x / 8u, grp = xcd_slot % geo.groups, stream_local = xcd_slot / geo.groups;
+    if (stream_local >= geo.streams_per_xcd) return;  // (32 CUs per XCD do not divide by every group count)
+    const uint32_t stream = (blockIdx.x % 8u) * geo.streams_per_xcd + stream_local, n_streams = 8u * geo.streams_per_xcd;
+    // group g: tile pairs [g lo + min(g, extra), + lo + (g < extra))
+    const uint32_t tile0 = 2u * (grp * geo.pairs_lo + min(grp, geo.pairs_extra));
+    const uint32_t my_tiles = 2u * (geo.pairs_lo + (grp < geo.pairs_extra ? 1u : 0u)), max_tiles = 2u * (geo.pairs_lo + (geo.pairs_extra ? 1u : 0u));
+    uint4 *img = reinterpret_cast<uint4 *>(lds_raw);                                  // [my_tiles][NSTEPS][64] x 16 B
+    int *nbq_s = reinterpret_cast<int *>(lds_raw + (size_t)max_tiles * NSTEPS * 1024);  // [16 my_tiles]: MINUS the query bounds
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(nbq_s + 16 * max_tiles) + wave;
+    if (lane == 0) *wcount_s = 0;
+    {
+        const uint4 *src = qfrag + (size_t)tile0 * NSTEPS * 64;
+        for (uint32_t idx = t; idx < my_tiles * NSTEPS * 64; idx += 64 * WAVES) img[idx] = src[idx];
+        for (uint32_t i = t; i < 16 * my_tiles; i += 64 * WAVES) nbq_s[i] = -bq_all[16 * tile0 + i];
+    }
+    __syncthreads();
+    uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * WAVES + wave) * filt.wave_cap;
+    if (my_tiles) {
+        const uint32_t n_chunks = (n_rows + 16 * RT - 1) / (16 * RT), stride = n_streams * WAVES;
+        const uint32_t first = stream * WAVES + wave;
+        auto clamp_chunk = [&](uint32_t c) { return c < n_chunks ? c : n_chunks - 1u; };  // past the end: a harmless re-read
+        // the rows of a trip, as B operands: lane (i, g) holds bytes [64 j + 16 g, + 16) of row 16 rt + i.  Plain loads: the other
+        // groups of this stream want the lines from L2.
+        auto load_rows = [&](v4i (&rows)[RT][NSTEPS], float (&vo)[RT], uint32_t chunk) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const uint64_t row = (uint64_t)chunk * (16 * RT) + rt * 16 + i16;  // (the codes are padded by a 256-row tile)
+                const uint8_t *p = codes + row * AD + 16u * g4;
+#pragma unroll
+                for (int j = 0; j < NSTEPS; j++) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(p + 64 * j);
+                    rows[rt][j] = v4i{(int)x.x, (int)x.y, (int)x.z, (int)x.w};
+                }
+                vo[rt] = v_offsets[row];
+            }
+        };
+        v4i rows_a[RT][NSTEPS], rows_b[RT][NSTEPS];
+        float vo_a[RT], vo_b[RT];
+        load_rows(rows_a, vo_a, clamp_chunk(first));
+        load_rows(rows_b, vo_b, clamp_chunk(first + stride));
+        auto trip = [&](uint32_t chunk, v4i (&rows)[RT][NSTEPS], float (&vo)[RT]) {
+            const uint64_t row0 = (uint64_t)chunk * (16 * RT);
+            float v_off[RT];
+            int br[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                v_off[rt] = vo[rt];
+                const bool ok = row0 + rt * 16 + i16 < n_rows;
+                br[rt] = ok ? pp_bound<LOW>(-v_off[rt], fabsf(v_off[rt]), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+            }
+            for (uint32_t qt = 0; qt < my_tiles; qt += QP) {
+                v4i acc[QP][RT];
+                const uint4 *a_base = img + (size_t)qt * NSTEPS * 64 + lane;
+#pragma unroll
+                for (int qp = 0; qp < QP; qp++) {
+                    const v4i nb = *reinterpret_cast<const v4i *>(nbq_s + 16 * (qt + qp) + 4 * g4);  // -(bound of queries 4 g .. 4 g + 3)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[qp][rt][e] = nb[e] - br[rt];
+                }
+#pragma unroll
+                for (int j = 0; j < NSTEPS; j++) {
+#pragma unroll
+                    for (int qp = 0; qp < QP; qp++) {
+                        const uint4 a = a_base[(qp * NSTEPS + j) * 64];
+                        const v4i a4 = {(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+#pragma unroll
+                        for (int rt = 0; rt < RT; rt++) acc[qp][rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, rows[rt][j], acc[qp][rt], 0, 0, 0);
+                    }
+                }
+                // ---- epilogue: lane (i, g) holds queries 16 (tile0 + qt + qp) + 4 g + e against row 16 rt + i of the trip;
+                // "some accumulator may pass" = the smallest is negative (LOW) / the largest is not
+                int ext = acc[0][0][0];
+#pragma unroll
+                for (int qp = 0; qp < QP; qp++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        ext = LOW ? min(min(ext, acc[qp][rt][0]), acc[qp][rt][1]) : max(max(ext, acc[qp][rt][0]), acc[qp][rt][1]);
+                        ext = LOW ? min(min(ext, acc[qp][rt][2]), acc[qp][rt][3]) : max(max(ext, acc[qp][rt][2]), acc[qp][rt][3]);
+                    }
+                if (__builtin_amdgcn_readfirstlane(__ballot(LOW ? ext < 0 : ext >= 0) != 0)) {
+#pragma unroll
+                    for (int qp = 0; qp < QP; qp++)
+#pragma unroll
+                        for (int rt = 0; rt < RT; rt++) {
+                            const int a0 = acc[qp][rt][0], a1 = acc[qp][rt][1], a2 = acc[qp][rt][2], a3 = acc[qp][rt][3];
+                            const bool may_pass = LOW ? ((a0 | a1 | a2 | a3) < 0) : ((a0 & a1 & a2 & a3) >= 0);
+                            if (may_pass) {
+                                const uint32_t ql = 16u * (qt + qp) + 4u * g4, q = 16u * tile0 + ql;  // in the group / in the launch's batch
+                                const uint64_t row = row0 + rt * 16 + i16;
+                                const float4 pv4 = *reinterpret_cast<const float4 *>(filt.pivot_scores + q);
+                                const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + q);
+                                const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w}, qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                                const int av[4] = {a0, a1, a2, a3};
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int s_int = av[e] - nbq_s[ql + e] + br[rt];  // the plain integer dot product
+                                    const float sc = (multiplier * (float)s_int + qo[e]) + v_off[rt];
+                                    const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
+                                    if (d >= 0.0f) {
+                                        const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                        if (pos < filt.wave_cap)
+                                            wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row, filt.query_base + q + e, 0u);
+                                    }
+                                }
+                            }
+                        }
+                }
+            }
+            load_rows(rows, vo, clamp_chunk(chunk + 2 * stride));  // this set is free: the trip after the next one, a whole trip ahead
+        };
+        for (uint32_t chunk = first; chunk < n_chunks; chunk += 2 * stride) {
+            trip(chunk, rows_a, vo_a);
+            if (chunk + stride >= n_chunks) break;
+            trip(chunk + stride, rows_b, vo_b);
+        }
+    }
+    if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * WAVES + wave] = *wcount_s;
+}
+
 }  // namespace
 
 struct qamd_u8_query_batch {
@@ -2275,10 +2429,94 @@ qamd_status launch_gemm_qr(const qamd_u8 *h, const qamd_u8_query_batch *b, const
                : launch_gemm_qr_cfg<M, false>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, bq, s);
 }
 
+// Queries resident, rows streamed (u8_gemm_rq16_kernel): the filter pass of topk_batch for batches of kRqMinQueries and more
+// on rows of 256 / 384 / 512 / 768 bytes, in groups of query tiles that run side by side on the CUs of an XCD.
+// QAMD_GEMM_CFG=s forces it where it can run, QAMD_RQ=0 switches it off (developer A/B, tools/lib build).
+constexpr uint64_t kRqMinQueries = 129;
+inline RqGeometry rq_geometry(uint64_t n_queries, uint32_t nsteps) {
+    // the fewest groups whose tile pairs fit a CU's LDS, the pairs spread evenly; 32 / G row streams per XCD (QAMD_RQ_GROUPS:
+    // developer A/B).  More groups than needed only add L2 -> CU traffic: at 10M x 768, 1024 queries, 6 groups 8.3 ms, 8 groups 8.7.
+    static const char *eg = dev_env("QAMD_RQ_GROUPS");
+    RqGeometry g{};
+    g.n_tiles = (uint32_t)(round_up(n_queries, 32) / 16);
+    const uint32_t pairs = g.n_tiles / 2, cap_pairs = rq_tile_cap(nsteps) / 2;
+    g.groups = eg ? (uint32_t)atoi(eg) : (pairs + cap_pairs - 1) / cap_pairs;
+    if (g.groups == 0 || g.groups > 8 || g.groups > pairs || (pairs + g.groups - 1) / g.groups > cap_pairs) {
+        g.groups = 0;
+        return g;
+    }
+    g.pairs_lo = pairs / g.groups;
+    g.pairs_extra = pairs % g.groups;
+    g.streams_per_xcd = 32u / g.groups;
+    return g;
+}
+bool rq_selected(const qamd_u8 *h, const qamd_u8_query_batch *b) {
+    static const char *cfg = dev_env("QAMD_GEMM_CFG"), *off = dev_env("QAMD_RQ"), *lo = dev_env("QAMD_RQ_MIN"), *hi = dev_env("QAMD_RQ_MAX");
+    if ((cfg && cfg[0] != 's') || (off && off[0] == '0')) return false;
+    const float m = h->meta.multiplier;
+    const uint64_t ad = h->meta.actual_dim;
+    if (!(std::isfinite(m) && m != 0.0f) || !b->frag.ptr || !b->frag16) return false;
+    if (!(ad == 256 || ad == 384 || ad == 512 || ad == 768)) return false;
+    if (device_info().cu_count != 256 || b->q_pad < round_up(b->n_queries, 32)) return false;  // (8 XCDs of 32 CUs: the group / stream map)
+    const RqGeometry g = rq_geometry(b->n_queries, (uint32_t)(ad / 64));
+    if (g.groups == 0) return false;  // (more than eight LDS images)
+    if (cfg) return true;
+    if (h->count < 131072) return false;  // (a small store: the row-streaming tiles split it evenly)
+    if (lo || hi) return b->n_queries >= (lo ? (uint64_t)atoll(lo) : kRqMinQueries) && b->n_queries <= (hi ? (uint64_t)atoll(hi) : ~0ull);
+    if (b->n_queries < kRqMinQueries) return false;
+    // Measured, whole topk_batch(30) ms, before / this kernel (tools/experiments/u8_rq_sweep.sh, profiles/r04_u8_rq.txt):
+    //   10M x 768:  one group  129 q 1.71 / 1.49   192 q 1.83 / 1.59;   two groups  193 q 1.87 / 2.56  256 q 1.99 / 2.50 (the queries-in-
+    //               registers kernel keeps those)  257 q 3.07 / 2.72  320 q 3.03 / 2.68  384 q 3.25 / 2.88;   three and more: 512 q 3.77 / 4.39
+    //   15M x 512:  129 q 1.95 / 1.49  288 q 3.42 / 2.19 | 289 q 3.40 / 2.64  576 q 5.32 / 4.14 | 768 q 5.84 / 5.48  1152 q 7.91 / 7.61
+    //   30M x 256:  129 q 2.75 / 1.60  608 q 7.04 / 4.77 | 609 q 7.05 / 5.10  1216 q 10.6 / 8.89 | 1800 q 14.0 / 12.5  2400 q 19.7 / 16.6
+    if (ad == 768) return g.groups == 1 || (g.groups == 2 && b->n_queries > kQrQueries);
+    return g.groups <= 4;
+}
+template <int MODE, bool LOW>
+qamd_status launch_gemm_rq_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes, const float *v_offsets,
+                               uint64_t n_rows, const BatchFilter &filt, const int *bq, hipStream_t s) {
+    const uint32_t nsteps = (uint32_t)(h->meta.actual_dim / 64);
+    const RqGeometry g = rq_geometry(b->n_queries, nsteps);
+    const size_t max_tiles = 2 * (size_t)(g.pairs_lo + (g.pairs_extra ? 1 : 0));
+    const size_t lds_bytes = max_tiles * nsteps * 1024 + max_tiles * 64 + 64;
+    BatchFilter f = filt;
+    f.query_base = 0;
+    f.wave_base = 0;
+#define QAMD_RQ(NS_)                                                                                                       \
+    do {                                                                                                                  \
+        QAMD_LDS_OPT_IN((&u8_gemm_rq16_kernel<MODE, LOW, NS_>), 160 * 1024);                                               \
+        hipLaunchKernelGGL((u8_gemm_rq16_kernel<MODE, LOW, NS_>), dim3(256), dim3(512), lds_bytes, s, codes, v_offsets,    \
+                           b->frag.as<uint4>(), b->offsets.as<float>(), bq, h->meta.multiplier, (uint32_t)n_rows, g, f);  \
+    } while (0)
+    switch (nsteps) {
+        case 4: QAMD_RQ(4); break;
+        case 6: QAMD_RQ(6); break;
+        case 8: QAMD_RQ(8); break;
+        default: QAMD_RQ(12); break;
+    }
+#undef QAMD_RQ
+    QAMD_HIP(hipGetLastError());
+    return QAMD_OK;
+}
+
 template <int MODE>
 qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const uint8_t *codes,
                            const float *v_offsets, uint64_t n_rows, float *out, uint64_t out_pitch,
                            const BatchFilter &filt, hipStream_t s) {
+    if ((MODE == 1 || MODE == 2) && n_rows == h->count && rq_selected(h, b)) {  // the filter pass over the store itself
+        constexpr int M = (MODE == 1 || MODE == 2) ? MODE : 1;
+        const bool low = (h->meta.multiplier < 0.0f) != (MODE == 2);
+        int *bq = filt.query_bounds;
+        if (low)
+            hipLaunchKernelGGL(qs_bounds_kernel<true>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
+                               b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
+        else
+            hipLaunchKernelGGL(qs_bounds_kernel<false>, dim3((unsigned)(b->q_pad / 256)), dim3(256), 0, s, filt.pivot_scores,
+                               b->offsets.as<float>(), h->meta.multiplier, filt.largest, (uint32_t)b->q_pad, bq);
+        QAMD_HIP(hipGetLastError());
+        return low ? launch_gemm_rq_cfg<M, true>(h, b, codes, v_offsets, n_rows, filt, bq, s)
+                   : launch_gemm_rq_cfg<M, false>(h, b, codes, v_offsets, n_rows, filt, bq, s);
+    }
     if (qr_selected(h, b, MODE != 0)) return launch_gemm_qr<MODE>(h, b, codes, v_offsets, n_rows, out, out_pitch, filt, s);
     const bool wide = b->frag_nkb <= 9;  // 128 resident rows fit (rows of up to 1152 B), else 96
     const bool tall = b->frag_nkb <= 8;  // 16x16x64 form: 128 resident rows of up to 1024 bytes, else 96
@@ -2321,6 +2559,7 @@ qamd_status launch_gemm_qs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
 bool qs_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode) {
     static const char *cfg = dev_env("QAMD_GEMM_CFG");
     if (qr_selected(h, b, filter_mode)) return true;  // a form of it (launch_gemm_qs dispatches)
+    if (filter_mode && rq_selected(h, b)) return true;  // (the sample pass of such a batch takes the query-streaming forms)
     if (cfg && cfg[0] != 'q') return false;
     const float m = h->meta.multiplier;
     if (filter_mode && !(std::isfinite(m) && m != 0.0f)) return false;

@@ -413,6 +413,79 @@ def test_query_streaming_kernel_shapes(n, dim, nq, qo):
             assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (qi, n, dim)
 
 
+# ---- queries resident, rows streamed (u8_gemm_rq16_kernel, late round 4): the filter pass of 129+ queries on stores of 131072+
+# rows of 256 / 384 / 512 / 768 bytes; the batch in groups of query tiles (as many as fit a CU's LDS: 12 / 18 / 24 / 38 tiles) that run
+# side by side on the CUs of an XCD - one or two groups at 768 bytes (two only past the queries-in-registers kernel's 256), up
+# to four on shorter rows
+@pytest.mark.parametrize("n,dim,nq", [
+    (140_001, 768, 129),    # one group of 10 tiles (the second half of the last tile pair is padding)
+    (140_001, 768, 192),    # one full group: 12 tiles, 144 KiB of fragments
+    (140_001, 768, 193),    # (two groups would be needed: the queries-in-registers kernel keeps 193 .. 256)
+    (140_001, 768, 257),    # two groups of 10 and 8 tiles, 16 row streams per XCD
+    (150_000, 768, 384),    # two full groups: the largest batch of 768-byte rows it takes; 385 go to the query-streaming kernel
+    (131_072, 768, 385),
+    (140_001, 512, 700),    # eight k-steps: three groups of 16 / 14 / 14 tiles, ten row streams per XCD (two CUs of 32 idle)
+    (140_001, 512, 1152),   # four full groups of 18 tiles
+    (140_001, 384, 300),    # six k-steps, one group
+    (200_003, 256, 400),    # four k-steps, one group of 26 tiles
+    (140_001, 256, 2400),   # four groups of 38 / 38 / 38 / 36 tiles
+    (140_001, 760, 300),    # 760 code bytes + 8 of padding: the pad bytes are zero in rows and queries
+])
+def test_resident_queries_kernel_shapes(n, dim, nq):
+    rng = np.random.default_rng(n + dim + nq)
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    queries[nq // 2] = queries[0]  # the same query twice, in different groups at most sizes
+    for dist, invert, largest in ((D.Dot, False, True), (D.L2, True, False), (D.Dot, True, False)):
+        enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, dist, invert))
+        ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30, largest=largest)
+        assert np.array_equal(ids[nq // 2], ids[0]) and np.array_equal(sc[nq // 2], sc[0])
+        qobj = None
+        for qi in sorted(set(range(0, nq, 37)) | {1, 15, 16, nq - 2, nq - 1}):
+            qobj = enc.encode_query(queries[qi], reuse=qobj)
+            wi, ws = enc.topk(qobj, 30, largest=largest)
+            assert np.array_equal(ids[qi], wi), (qi, n, dim)
+            assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (qi, n, dim)
+
+
+def test_resident_queries_kernel_forced_for_many_groups():
+    """QAMD_GEMM_CFG=s (a developer switch: only the tools/lib build reads it) sends batches of up to eight LDS images through
+    u8_gemm_rq16_kernel - 1024 queries of 768 bytes are six groups, 1536 eight: the same ids and score bits as the product
+    library's own selection (the query-streaming kernel)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev_lib = os.path.join(root, "tools", "lib", "libquantization_amd_dev.so")
+    if not os.path.exists(dev_lib):
+        pytest.skip("developer build not present")
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import quantization_amd as qa
+D = qa.DistanceType
+h = hashlib.sha256()
+for n, dim, nq in ((140_001, 768, 1024), (131_072, 768, 1536), (140_001, 512, 2000), (140_001, 768, 200)):
+    rng = np.random.default_rng(n + nq)
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    enc = qa.EncodedVectorsU8.encode(data, qa.VectorParameters(dim, n, D.Dot, False))
+    for largest in (True, False):
+        ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30, largest=largest)
+        h.update(np.asarray(ids).tobytes()); h.update(np.asarray(sc).tobytes())
+print("DIGEST", h.hexdigest())
+""" % root
+    outs = []
+    for env_extra in ({}, {"QAMD_LIB_PATH": dev_lib, "QAMD_GEMM_CFG": "s"}):
+        env = dict(os.environ, **env_extra)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+        outs.append([ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert outs[0] == outs[1], outs
+
+
 def test_query_streaming_kernel_reused_batch_object():
     """A batch object re-encoded with other queries (same shape) rebuilds its fragment-order copy."""
     rng = np.random.default_rng(11)
