@@ -22,6 +22,7 @@ run bin_batch1024 bin_batch1024_1024 bin_gemm_rs4_kernel          50000000  128 
 run bin_batch128 bin_batch128_1024  bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 128 --k 30 --steps 10 --warmup 5
 run bin_batch256 bin_batch256_1024  bin_gemm_rs4_kernel           50000000  128    1 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 256 --k 30 --steps 10 --warmup 5
 run bin_batch512 bin_batch512_1024  bin_gemm_rs4_kernel           50000000  128    2 0 -- --quantizer binary --dim 1024 --rows 50000000 --batch-queries 512 --k 30 --steps 5 --warmup 3
-run batch192    u8_batch192_768     u8_gemm_rq16_kernel           10000000  772    1 0 -- --batch-queries 192 --k 30 --steps 10 --warmup 5
-run batch384    u8_batch384_768     u8_gemm_rq16_kernel           10000000  772    1 0 -- --batch-queries 384 --k 30 --steps 10 --warmup 5
+run batch192    u8_batch192_768     u8_gemm_rk16_kernel           10000000  772    1 0 -- --batch-queries 192 --k 30 --steps 10 --warmup 5
+run batch384    u8_batch384_768     u8_gemm_rk16_kernel           10000000  772    1 0 -- --batch-queries 384 --k 30 --steps 10 --warmup 5
+run batch768    u8_batch768_768     u8_gemm_rk16_kernel           10000000  772    1 0 -- --batch-queries 768 --k 30 --steps 8 --warmup 3
 run batch256    u8_batch256_768     u8_gemm_qr16_kernel           10000000  772    1 0 -- --batch-queries 256 --k 30 --steps 10 --warmup 5

@@ -2104,6 +2104,187 @@ __global__ __launch_bounds__(512) void u8_gemm_rq16_kernel(const uint8_t *__rest
     if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * WAVES + wave] = *wcount_s;
 }
 
+
+// The same kernel with the loops the other way round, for rows of 768 bytes (12 k-steps), where u8_gemm_rq16_kernel's two
+// register sets of rows (192 of 256 registers) leave the compiler nothing to pipeline the fragment reads with (it emits
+// read, wait, two MFMAs, read, wait, ...: half the matrix pipe's time).  Here the K loop is OUTSIDE: a wave keeps the
+// accumulators of ALL of its group's tiles (NT x 2 x 4 registers: 96 at 12 tiles) and takes its 32 rows one 64-byte k-step
+// slice at a time - 8 registers, multiplied with every tile and then dead - out of a ring of D = 6 slices that is refilled
+// half a trip ahead, across trips.  Per k-step NT fragment reads feed 2 NT MFMAs back to back; one bound test and one
+// ballot per trip.  NT is a template parameter (8, 10, 12: the accumulators must be registers); a group with fewer tiles
+// pads with zero tiles whose bounds never pass.
+template <int MODE, bool LOW, int NSTEPS, int NT>
+__global__ __launch_bounds__(512) void u8_gemm_rk16_kernel(const uint8_t *__restrict__ codes, const float *__restrict__ v_offsets,
+                                                          const uint4 *__restrict__ qfrag, const float *__restrict__ q_offsets,
+                                                          const int *__restrict__ bq_all, float multiplier, uint32_t n_rows,
+                                                          RqGeometry geo, BatchFilter filt) {
+    static_assert(MODE == 1 || MODE == 2, "the filter pass of topk_batch");
+    // (measured, tools/experiments/rk_variants.sh: fragment reads 2 / 4 / 8 tiles ahead, slices 6 / 12 k-steps ahead, 8 / 12 waves
+    // per workgroup at 8 tiles: the same time to the percent, or slower where 12 slices spill)
+    constexpr int RT = 2, AD = 64 * NSTEPS, WAVES = 8, D = NSTEPS % 6 == 0 ? 6 : 4;
+    static_assert(NSTEPS % D == 0 && NT % 2 == 0, "ring of k-step slices");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
+    constexpr bool LARGEST = MODE == 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t i16 = (uint32_t)lane & 15u, g4 = (uint32_t)lane >> 4;
+    const uint32_t xcd_slot = blockIdx.x / 8u, grp = xcd_slot % geo.groups, stream_local = xcd_slot / geo.groups;
+    if (stream_local >= geo.streams_per_xcd) return;
+    const uint32_t stream = (blockIdx.x % 8u) * geo.streams_per_xcd + stream_local, n_streams = 8u * geo.streams_per_xcd;
+    const uint32_t tile0 = 2u * (grp * geo.pairs_lo + min(grp, geo.pairs_extra));
+    const uint32_t my_tiles = 2u * (geo.pairs_lo + (grp < geo.pairs_extra ? 1u : 0u));  // <= NT
+    uint4 *img = reinterpret_cast<uint4 *>(lds_raw);                           // [NSTEPS][NT][64] x 16 B: a k-step's fragments side by side
+    int *nbq_s = reinterpret_cast<int *>(lds_raw + (size_t)NT * NSTEPS * 1024);  // [16 NT]: MINUS the query bounds
+    uint32_t *wcount_s = reinterpret_cast<uint32_t *>(nbq_s + 16 * NT) + wave;
+    if (lane == 0) *wcount_s = 0;
+    {
+        const uint4 *src = qfrag + (size_t)tile0 * NSTEPS * 64;
+        for (uint32_t idx = t; idx < (uint32_t)NT * NSTEPS * 64; idx += 64 * WAVES) {  // idx = (j, q, lane) <- the batch copy's (q, j, lane)
+            const uint32_t l = idx & 63u, q = (idx >> 6) % NT, j = (idx >> 6) / NT;
+            img[idx] = q < my_tiles ? src[((size_t)q * NSTEPS + j) * 64 + l] : make_uint4(0, 0, 0, 0);
+        }
+        for (uint32_t i = t; i < 16u * NT; i += 64 * WAVES)  // a padding tile: accumulators that can never pass (|bound of a row| <= 2^29)
+            nbq_s[i] = i < 16 * my_tiles ? -bq_all[16 * tile0 + i] : (LOW ? (1 << 30) : -(1 << 30));
+    }
+    __syncthreads();
+    uint4 *wave_list = filt.wave_cand + (uint64_t)(filt.wave_base + blockIdx.x * WAVES + wave) * filt.wave_cap;
+    const uint32_t n_chunks = (n_rows + 16 * RT - 1) / (16 * RT), stride = n_streams * WAVES;
+    const uint32_t first = stream * WAVES + wave;
+    unsigned long long *stamps = QAMD_GEMM_STAMPS();  // (developer build: phase times in shader cycles, tools/gemm_timeline.py)
+    const bool timed = stamps != nullptr;
+    unsigned long long tm_prev = timed ? __builtin_amdgcn_s_memtime() : 0ull, tm_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tm_first = tm_prev, rt_first = timed ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto lap = [&](int slot) {
+        if (timed) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tm_acc[slot] += now - tm_prev;
+            tm_prev = now;
+        }
+    };
+    if (first < n_chunks) {
+        auto clamp_chunk = [&](uint32_t c) { return c < n_chunks ? c : n_chunks - 1u; };  // past the end: a harmless re-read
+        // slice j of a chunk, as B operands: lane (i, g) holds bytes [64 j + 16 g, + 16) of row 16 rt + i (plain loads: the
+        // stream's other groups want the lines from L2)
+        auto load_slice = [&](v4i (&w)[RT], uint32_t chunk, int j) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const uint64_t row = (uint64_t)chunk * (16 * RT) + rt * 16 + i16;  // (the codes are padded by a 256-row tile)
+                const uint4 x = *reinterpret_cast<const uint4 *>(codes + row * AD + 64 * j + 16u * g4);
+                w[rt] = v4i{(int)x.x, (int)x.y, (int)x.z, (int)x.w};
+            }
+        };
+        v4i win[D][RT];
+        float vo_cur[RT], vo_nxt[RT];
+#pragma unroll
+        for (int d = 0; d < D; d++) load_slice(win[d], first, d);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) vo_cur[rt] = v_offsets[(uint64_t)first * (16 * RT) + rt * 16 + i16];
+        for (uint32_t chunk = first; chunk < n_chunks; chunk += stride) {
+            const uint32_t next = clamp_chunk(chunk + stride);
+            const uint64_t row0 = (uint64_t)chunk * (16 * RT);
+            float v_off[RT];
+            int br[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                v_off[rt] = vo_cur[rt];
+                const bool ok = row0 + rt * 16 + i16 < n_rows;
+                br[rt] = ok ? pp_bound<LOW>(-v_off[rt], fabsf(v_off[rt]), multiplier, 0) : (LOW ? -(int)kPpLim : (int)kPpLim);
+                vo_nxt[rt] = v_offsets[(uint64_t)next * (16 * RT) + rt * 16 + i16];
+            }
+            lap(5);
+            v4i acc[NT][RT];
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                const v4i nb = *reinterpret_cast<const v4i *>(nbq_s + 16 * q + 4 * g4);  // -(bound of queries 4 g .. 4 g + 3 of tile q)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[q][rt][e] = nb[e] - br[rt];
+            }
+            lap(2);
+            // The fragment reads run PF tiles ahead of the MFMAs that use them, across k-steps, in a pinned order (left alone the
+            // compiler emits read, read, wait, two MFMAs, wait, two MFMAs: the LDS round trip lies open in front of every pair):
+            // unit (j, q) = the read of unit + PF, then the two MFMAs of tile q at k-step j.
+            constexpr int PF = 4, R = PF + 1, UNITS = NSTEPS * NT;
+            v4i a[R];
+            // (opaque: left alone the compiler keeps an address register per (k-step, tile) across the loop - and spills)
+            uint32_t a_addr = (uint32_t)lane * 16u;
+            asm volatile("" : "+v"(a_addr));
+            auto read_unit = [&](int u) {  // fragment of tile u % NT at k-step u / NT: img is [k-step][tile][lane], so unit u is piece u
+                const uint4 x = *reinterpret_cast<const uint4 *>(lds_raw + a_addr + (uint32_t)(u % 48) * 1024u);
+                a[u % R] = v4i{(int)x.x, (int)x.y, (int)x.z, (int)x.w};
+            };
+#pragma unroll
+            for (int u = 0; u < PF; u++) read_unit(u);
+#pragma unroll
+            for (int u = 0; u < UNITS; u++) {
+                const int j = u / NT, q = u % NT;
+                if ((u + PF) % 48 == 0 && u + PF < UNITS) {  // the immediate offset of a read reaches 64 KiB: a new base every 48 pieces
+                    a_addr += 48u * 1024u;
+                    asm volatile("" : "+v"(a_addr));
+                }
+                if (u + PF < UNITS) read_unit(u + PF);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[q][rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u % R], win[j % D][rt], acc[q][rt], 0, 0, 0);
+                if (q == NT - 1)  // the slice's slot is free: slice j + D - of this chunk, or of the wave's next one
+                    load_slice(win[j % D], j + D < NSTEPS ? chunk : next, (j + D) % NSTEPS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lap(3);
+            // ---- epilogue: lane (i, g) holds queries 16 (tile0 + q) + 4 g + e against row 16 rt + i of the chunk
+            int ext = acc[0][0][0];
+#pragma unroll
+            for (int q = 0; q < NT; q++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    ext = LOW ? min(min(ext, acc[q][rt][0]), acc[q][rt][1]) : max(max(ext, acc[q][rt][0]), acc[q][rt][1]);
+                    ext = LOW ? min(min(ext, acc[q][rt][2]), acc[q][rt][3]) : max(max(ext, acc[q][rt][2]), acc[q][rt][3]);
+                }
+            if (__builtin_amdgcn_readfirstlane(__ballot(LOW ? ext < 0 : ext >= 0) != 0)) {
+                uint32_t g_e = g4;  // (opaque: no per-tile index registers kept across the K loop)
+                asm volatile("" : "+v"(g_e));
+#pragma unroll
+                for (int q = 0; q < NT; q++)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        const int a0 = acc[q][rt][0], a1 = acc[q][rt][1], a2 = acc[q][rt][2], a3 = acc[q][rt][3];
+                        const bool may_pass = LOW ? ((a0 | a1 | a2 | a3) < 0) : ((a0 & a1 & a2 & a3) >= 0);
+                        if (may_pass) {
+                            const uint32_t ql = 16u * q + 4u * g_e, qq = 16u * tile0 + ql;  // in the group / in the launch's batch
+                            const uint64_t row = row0 + rt * 16 + i16;
+                            const float4 pv4 = *reinterpret_cast<const float4 *>(filt.pivot_scores + qq);
+                            const float4 qo4 = *reinterpret_cast<const float4 *>(q_offsets + qq);
+                            const float pv[4] = {pv4.x, pv4.y, pv4.z, pv4.w}, qo[4] = {qo4.x, qo4.y, qo4.z, qo4.w};
+                            const int av[4] = {a0, a1, a2, a3};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int s_int = av[e] - nbq_s[ql + e] + br[rt];  // the plain integer dot product
+                                const float sc = (multiplier * (float)s_int + qo[e]) + v_off[rt];
+                                const float d = LARGEST ? sc - pv[e] : pv[e] - sc;
+                                if (d >= 0.0f) {
+                                    const uint32_t pos = atomicAdd(wcount_s, 1u);
+                                    if (pos < filt.wave_cap)
+                                        wave_list[pos] = make_uint4(topk_ordered_bits(sc, LARGEST), (uint32_t)row, filt.query_base + qq + e, 0u);
+                                }
+                            }
+                        }
+                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) vo_cur[rt] = vo_nxt[rt];
+            lap(4);
+        }
+    }
+    if (timed && lane == 0 && blockIdx.x < kStampBlocks) {
+        unsigned long long *o = stamps + ((uint64_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 6; i++) o[i] = tm_acc[i];
+        o[6] = __builtin_amdgcn_s_memtime() - tm_first;
+        o[7] = __builtin_amdgcn_s_memrealtime() - rt_first;
+        o[15] = 1;
+    }
+    if (lane == 0) filt.wave_counts[filt.wave_base + blockIdx.x * WAVES + wave] = *wcount_s;
+}
+
 }  // namespace
 
 struct qamd_u8_query_batch {
@@ -2264,6 +2445,7 @@ qamd_status launch_gemm_rs(const qamd_u8 *h, const qamd_u8_query_batch *b, const
 
 // Queries per launch slice of the kernel that serves this batch (wave-list bookkeeping).
 bool qr_selected(const qamd_u8 *h, const qamd_u8_query_batch *b, bool filter_mode);
+bool rq_selected(const qamd_u8 *h, const qamd_u8_query_batch *b);
 inline uint32_t gemm_launches(const qamd_u8 *h, const qamd_u8_query_batch *b, bool rs, bool qs) {
     if (qs && qr_selected(h, b, true)) return (uint32_t)((b->n_queries + 255) / 256);  // passes of the queries-in-registers form
     if (qs) return (uint32_t)((b->n_queries + 2048 - 1) / 2048);
@@ -2465,11 +2647,15 @@ bool rq_selected(const qamd_u8 *h, const qamd_u8_query_batch *b) {
     if (lo || hi) return b->n_queries >= (lo ? (uint64_t)atoll(lo) : kRqMinQueries) && b->n_queries <= (hi ? (uint64_t)atoll(hi) : ~0ull);
     if (b->n_queries < kRqMinQueries) return false;
     // Measured, whole topk_batch(30) ms, before / this kernel (tools/experiments/u8_rq_sweep.sh, profiles/r04_u8_rq.txt):
-    //   10M x 768:  one group  129 q 1.71 / 1.49   192 q 1.83 / 1.59;   two groups  193 q 1.87 / 2.56  256 q 1.99 / 2.50 (the queries-in-
-    //               registers kernel keeps those)  257 q 3.07 / 2.72  320 q 3.03 / 2.68  384 q 3.25 / 2.88;   three and more: 512 q 3.77 / 4.39
     //   15M x 512:  129 q 1.95 / 1.49  288 q 3.42 / 2.19 | 289 q 3.40 / 2.64  576 q 5.32 / 4.14 | 768 q 5.84 / 5.48  1152 q 7.91 / 7.61
     //   30M x 256:  129 q 2.75 / 1.60  608 q 7.04 / 4.77 | 609 q 7.05 / 5.10  1216 q 10.6 / 8.89 | 1800 q 14.0 / 12.5  2400 q 19.7 / 16.6
-    if (ad == 768) return g.groups == 1 || (g.groups == 2 && b->n_queries > kQrQueries);
+    // 768-byte rows, the K-outer form (u8_gemm_rk16_kernel), before / with it:  129 q 1.64 / 1.49   192 q 1.78 / 1.54 | 193-256 q (two
+    // groups) 1.92-2.03 / 2.33-2.38: the queries-in-registers kernel keeps those | 257 q 2.94 / 2.50  288 q 2.99 / 2.51  384 q 3.26 / 2.62 |
+    // three groups: 400 q 3.52 / 3.65  512 q 3.83 / 3.91 (no), 576 q 4.80 / 4.00 (past the query-streaming kernel's step at 513) |
+    // four: 640 q 5.07 / 4.71  768 q 5.50 / 5.08 | five and more (30 of an XCD's 32 CUs, or half-empty groups): 832 q 5.85 / 6.25,
+    // 1024 q in eight groups of eight tiles 6.44 / 6.44
+    if (ad == 768)
+        return g.groups == 1 || (g.groups == 2 && b->n_queries > kQrQueries) || (g.groups == 3 && b->n_queries > 512) || g.groups == 4;
     return g.groups <= 4;
 }
 template <int MODE, bool LOW>
@@ -2482,6 +2668,22 @@ qamd_status launch_gemm_rq_cfg(const qamd_u8 *h, const qamd_u8_query_batch *b, c
     BatchFilter f = filt;
     f.query_base = 0;
     f.wave_base = 0;
+    static const char *ek = dev_env("QAMD_RQ_K");  // developer A/B: 0 = the tile-outer form on 768-byte rows as well
+    if (nsteps == 12 && !(ek && ek[0] == '0')) {    // the K-outer form: all tiles' accumulators in registers
+#define QAMD_RK(NT_)                                                                                                       \
+    do {                                                                                                                  \
+        QAMD_LDS_OPT_IN((&u8_gemm_rk16_kernel<MODE, LOW, 12, NT_>), 160 * 1024);                                           \
+        hipLaunchKernelGGL((u8_gemm_rk16_kernel<MODE, LOW, 12, NT_>), dim3(256), dim3(512),                                \
+                           (size_t)NT_ * 12 * 1024 + (size_t)NT_ * 64 + 64, s, codes, v_offsets, b->frag.as<uint4>(),     \
+                           b->offsets.as<float>(), bq, h->meta.multiplier, (uint32_t)n_rows, g, f);                       \
+    } while (0)
+        if (max_tiles <= 8) QAMD_RK(8);
+        else if (max_tiles <= 10) QAMD_RK(10);
+        else QAMD_RK(12);
+#undef QAMD_RK
+        QAMD_HIP(hipGetLastError());
+        return QAMD_OK;
+    }
 #define QAMD_RQ(NS_)                                                                                                       \
     do {                                                                                                                  \
         QAMD_LDS_OPT_IN((&u8_gemm_rq16_kernel<MODE, LOW, NS_>), 160 * 1024);                                               \

@@ -413,18 +413,22 @@ def test_query_streaming_kernel_shapes(n, dim, nq, qo):
             assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (qi, n, dim)
 
 
-# ---- queries resident, rows streamed (u8_gemm_rq16_kernel, late round 4): the filter pass of 129+ queries on stores of 131072+
-# rows of 256 / 384 / 512 / 768 bytes; the batch in groups of query tiles (as many as fit a CU's LDS: 12 / 18 / 24 / 38 tiles) that run
-# side by side on the CUs of an XCD - one or two groups at 768 bytes (two only past the queries-in-registers kernel's 256), up
-# to four on shorter rows
+# ---- queries resident, rows streamed (late round 4): the filter pass of 129+ queries on stores of 131072+ rows of 256 / 384 / 512 /
+# 768 bytes; the batch in groups of query tiles (as many as fit a CU's LDS: 12 / 18 / 24 / 38 tiles) that run side by side on the CUs
+# of an XCD.  768-byte rows: u8_gemm_rk16_kernel (K loop outside, all tiles' accumulators in registers: 8, 10 or 12 tiles per
+# group, padded), one to four groups where measured faster; shorter rows: u8_gemm_rq16_kernel (tiles outside), up to four groups
 @pytest.mark.parametrize("n,dim,nq", [
     (140_001, 768, 129),    # one group of 10 tiles (the second half of the last tile pair is padding)
     (140_001, 768, 192),    # one full group: 12 tiles, 144 KiB of fragments
     (140_001, 768, 193),    # (two groups would be needed: the queries-in-registers kernel keeps 193 .. 256)
-    (140_001, 768, 257),    # two groups of 10 and 8 tiles, 16 row streams per XCD
-    (150_000, 768, 384),    # two full groups: the largest batch of 768-byte rows it takes; 385 go to the query-streaming kernel
-    (131_072, 768, 385),
-    (140_001, 512, 700),    # eight k-steps: three groups of 16 / 14 / 14 tiles, ten row streams per XCD (two CUs of 32 idle)
+    (140_001, 768, 257),    # two groups of 10 and 8 tiles (both as 10: the smaller one padded with a tile pair that never passes)
+    (150_000, 768, 384),    # two full groups
+    (131_072, 768, 385),    # (three groups up to 512 queries: the query-streaming kernel keeps those)
+    (140_001, 768, 545),    # three groups of 12 / 12 / 12 tiles (36 for 35), ten row streams per XCD (two CUs of 32 idle)
+    (140_001, 768, 640),    # four groups of 10 tiles
+    (140_001, 768, 768),    # four full groups: the largest batch of 768-byte rows it takes
+    (140_001, 768, 769),
+    (140_001, 512, 700),    # eight k-steps: three groups of 16 / 14 / 14 tiles
     (140_001, 512, 1152),   # four full groups of 18 tiles
     (140_001, 384, 300),    # six k-steps, one group
     (200_003, 256, 400),    # four k-steps, one group of 26 tiles
@@ -450,8 +454,8 @@ def test_resident_queries_kernel_shapes(n, dim, nq):
 
 def test_resident_queries_kernel_forced_for_many_groups():
     """QAMD_GEMM_CFG=s (a developer switch: only the tools/lib build reads it) sends batches of up to eight LDS images through
-    u8_gemm_rq16_kernel - 1024 queries of 768 bytes are six groups, 1536 eight: the same ids and score bits as the product
-    library's own selection (the query-streaming kernel)."""
+    the resident-queries kernels - 1024 queries of 768 bytes are six groups, 1536 eight, 200 two of 8 tiles: the same ids and
+    score bits as the product library's own selection (the query-streaming / queries-in-registers kernels)."""
     import hashlib
     import os
     import subprocess

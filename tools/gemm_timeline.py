@@ -44,7 +44,7 @@ torch.cuda.synchronize()
 L.qamd_dev_gemm_stamps(None)
 print(f"topk_batch with stamps: {e0.elapsed_time(e1):.2f} ms")
 st = stamps.cpu().numpy().reshape(4096, WAVES, 16)
-if os.environ.get("QAMD_GEMM_CFG", "p")[0] in "qg":  # g: the queries-in-registers form (BLK_ROWS=64, CHUNK_Q=32)
+if os.environ.get("QAMD_GEMM_CFG", "p")[0] in "qgs":  # g: the queries-in-registers form (BLK_ROWS=64, CHUNK_Q=32); s: resident queries
     # query-streaming kernel: per wave, cycles summed over its row blocks
     n_wg, blk_rows = 256, int(os.environ.get("BLK_ROWS", 128))  # BLK_ROWS=96: rows of 1153-1536 bytes
     blk = st[:n_wg]
