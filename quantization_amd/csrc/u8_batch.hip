@@ -2121,6 +2121,7 @@ __global__ __launch_bounds__(512) void u8_gemm_rk16_kernel(const uint8_t *__rest
     static_assert(MODE == 1 || MODE == 2, "the filter pass of topk_batch");
     // (measured, tools/experiments/rk_variants.sh: fragment reads 2 / 4 / 8 tiles ahead, slices 6 / 12 k-steps ahead, 8 / 12 waves
     // per workgroup at 8 tiles: the same time to the percent, or slower where 12 slices spill)
+    // (... and so do four row tiles per trip at 8 tiles - half the fragment reads per MFMA: 1024 queries 6.68 against 6.68 ms)
     constexpr int RT = 2, AD = 64 * NSTEPS, WAVES = 8, D = NSTEPS % 6 == 0 ? 6 : 4;
     static_assert(NSTEPS % D == 0 && NT % 2 == 0, "ring of k-step slices");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[];
