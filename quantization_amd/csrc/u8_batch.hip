@@ -2170,6 +2170,8 @@ __global__ __launch_bounds__(512) void u8_gemm_rk16_kernel(const uint8_t *__rest
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 const uint64_t row = (uint64_t)chunk * (16 * RT) + rt * 16 + i16;  // (the codes are padded by a 256-row tile)
+                // (plain, not nontemporal, also for a single group: a load takes 64 bytes of a row's 128-byte line and the next k-step
+                // the other half - nt re-fetches it: 192 queries 1.57 -> 1.70 ms)
                 const uint4 x = *reinterpret_cast<const uint4 *>(codes + row * AD + 64 * j + 16u * g4);
                 w[rt] = v4i{(int)x.x, (int)x.y, (int)x.z, (int)x.w};
             }
