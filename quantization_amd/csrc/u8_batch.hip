@@ -2120,7 +2120,9 @@ __global__ __launch_bounds__(512) void u8_gemm_rk16_kernel(const uint8_t *__rest
                                                           RqGeometry geo, BatchFilter filt) {
     static_assert(MODE == 1 || MODE == 2, "the filter pass of topk_batch");
     // (measured, tools/experiments/rk_variants.sh: fragment reads 2 / 4 / 8 tiles ahead, slices 6 / 12 k-steps ahead, 8 / 12 waves
-    // per workgroup at 8 tiles: the same time to the percent, or slower where 12 slices spill)
+    // per workgroup at 8 tiles: the same time to the percent, or slower where 12 slices spill.  With the row loads taken out of
+    // the K loop - wrong rows, timing only - a single group's K loop takes 45 % fewer cycles, and a ring twice as deep does not
+    // get any of that back: at one group the loop runs at what the rows' arrival allows, 5.3 TB/s of 64-byte half lines)
     // (... and so do four row tiles per trip at 8 tiles - half the fragment reads per MFMA: 1024 queries 6.68 against 6.68 ms)
     constexpr int RT = 2, AD = 64 * NSTEPS, WAVES = 8, D = NSTEPS % 6 == 0 ? 6 : 4;
     static_assert(NSTEPS % D == 0 && NT % 2 == 0, "ring of k-step slices");
