@@ -771,16 +771,17 @@ def main():
                     "score_bytes_written_per_row": 4,
                     "achieved_incl_score_writes": (bytes_per_row + 4) * n / (kern_ms * 1e-3) / 1e9}
         if args.quantizer == "pq":
-            # The PQ scan reads only m bytes per row from HBM; its limiter is the LDS gather (one
-            # ds_read_b32 per chunk and row, bank-conflicting by construction: DESIGN 3.3).
+            # The PQ scan reads only m bytes per row from HBM; the LDS gather rate rides along.
             lds = 4.0 * bytes_per_row * n / (kern_ms * 1e-3) / 1e9
             if pq_skew:
                 # pq_scan_skew_kernel (m = 32 / 64 / 96 / 128): transposed LUT + quads skewed in time, no bank conflicts
                 # (SQ_LDS_BANK_CONFLICT = 0): the nominal bound, HBM reads of m bytes per row, is the roofline again
                 roofline.update({"lds_gather_GBps": lds, "lds_gather_frac_of_conflict_free_peak": lds / LDS_B32_PEAK_GBPS,
                                  "note": "m code bytes per row from HBM; per chunk and row one ds_read_u8 (code), one "
-                                         "ds_read_b32 (table entry) and two vector-ALU operations, all conflict-free: the "
-                                         "kernel is bound by instruction issue (LDS pipe 62 %, vector ALU 47 % busy)"})
+                                         "ds_read_b32 (table entry) and two vector-ALU operations, all conflict-free.  The "
+                                         "kernel runs 3 % above its own stream (loads, LDS ring, 4-byte score stores); the "
+                                         "stores - 4 % of the bytes - cost a quarter of that stream's time "
+                                         "(profiles/r04_pq_skew_probe.txt)"})
             else:
                 roofline.update({"bound": "lds", "achieved": lds, "peak": LDS_B32_PEAK_GBPS, "frac": lds / LDS_B32_PEAK_GBPS,
                                  "hbm_achieved_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBPS,
