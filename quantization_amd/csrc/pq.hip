@@ -372,7 +372,11 @@ struct SkewSlice {
 // score of the run's block k, and the run's 64 scores leave as one 256-byte nt store (COAL; 0.187 -> 0.176 ms) instead of
 // four 64-byte pieces that each only fill half a line.  Small stores keep single blocks (run_shift = 0) so that every wave
 // has work.
-template <int NV, int R, bool FILTER, bool SLICED, bool COAL>
+// PAD > 0 (m = 80, 112: rows of M - PAD chunks): the ring rows are M bytes all the same, the row's PAD missing chunks get table
+// columns of +0.0 - whatever byte lies in the ring's padding is a valid code, and a lane sum that starts at +0.0 never is -0.0,
+// so the padded steps leave every sum bit for bit what it was.  The padded steps are executed (96 for 80, 128 for 112), but
+// the kernel's time is its stream's (above), and that carries the row's own m bytes only.
+template <int NV, int R, bool FILTER, bool SLICED, bool COAL, int PAD = 0>
 __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
                                                                  const float *__restrict__ lut_t_g, uint32_t n_rows,
                                                                  float *__restrict__ out, TopkFilter filt, SkewSlice sl) {
@@ -382,6 +386,8 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     static_assert(M % 32 == 0 && S >= 8, "shape");
     static_assert(M % R == 0 && MR % 4 == 0 && (SR >= 8 || (SR == 4 && R == 2)) && (R == 1 || !SLICED), "rows per ring row");
     static_assert(!COAL || (R == 1 && !FILTER && D == 4), "the coalesced score store: one store row per ring row, runs of D = 4 blocks");
+    static_assert(PAD == 0 || (PAD == 16 && R == 1 && !SLICED && M >= 96), "padded rows: one 16-chunk piece short of the ring row");
+    constexpr int MROW = M - PAD;  // bytes of a store row
     // SR = 4 (m = 16, two rows per 32-chunk ring row): the eight lags span TWO store rows - quads 1..4 finish a store row at
     // steps 0..3 (mod 4), quads 5..8 the store row before it at the same steps
     constexpr bool kTwoGen = SR < 8;
@@ -393,6 +399,11 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         if (SLICED) {  // the slice's columns of the [code][m_total] table
             for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads)
                 dst[i] = *reinterpret_cast<const float4 *>(lut_t_g + (size_t)(i / (M / 4)) * sl.m_total + sl.chunk0 + 4u * (i % (M / 4)));
+        } else if (PAD) {  // [code][MROW] in memory; the ring row's last PAD columns: +0.0 for every code
+            for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads) {
+                const uint32_t code = i / (M / 4), c4 = i % (M / 4);
+                dst[i] = c4 < MROW / 4 ? *reinterpret_cast<const float4 *>(lut_t_g + (size_t)code * MROW + 4u * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         } else if (R > 1) {  // [code][MR] in memory, every row of it R times in LDS
             for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads)
                 dst[i] = *reinterpret_cast<const float4 *>(lut_t_g + (size_t)(i / (M / 4)) * MR + 4u * ((i % (M / 4)) % (MR / 4)));
@@ -438,8 +449,12 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     // A block is 16 M contiguous bytes: 1024 of them go as one 16-byte piece per lane, the other 512 (M = 32: the only
     // 512, M = 96: the second round) as 8 bytes per lane - every lane loads and writes in every round, so the refill has no
     // branch (a branch would cut the loop body into basic blocks, and a code byte that crosses one is masked to 8 bits again)
-    constexpr int kWide = 16 * M / 1024;             // rounds of 16 bytes per lane: 0 (M = 32), 1, 1, 2 (M = 128)
-    constexpr bool kHalf = (16 * M) % 1024 != 0;     // one more round of 8 bytes per lane (M = 32, 96)
+    // (PAD: a block is MROW 16-byte pieces - 80 or 112: lane l takes pieces l and 64 + l, the latter clamped to the last one, and
+    // writes piece p to ring row p / (MROW / 16), column p % (MROW / 16))
+    constexpr int kWide = PAD ? 2 : 16 * M / 1024;             // rounds of 16 bytes per lane: 0 (M = 32), 1, 1, 2 (M = 128)
+    constexpr bool kHalf = !PAD && (16 * M) % 1024 != 0;       // one more round of 8 bytes per lane (M = 32, 96)
+    const uint32_t pad_p1 = min(64u + lane, (uint32_t)MROW - 1u);
+    const uint32_t pad_a0 = (lane / (MROW / 16)) * M + (lane % (MROW / 16)) * 16u, pad_a1 = (pad_p1 / (MROW / 16)) * M + (pad_p1 % (MROW / 16)) * 16u;
     struct Held {
         uint4 wide[kWide > 0 ? kWide : 1];
         uint2 half;
@@ -453,9 +468,14 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         const uint32_t jc = j < J_u ? j : J_u - 1;  // wave-uniform, like everything up to `p`
         const uint32_t b_run = (wave_u << rs_u) + (jc & ((1u << rs_u) - 1u)) + (((jc >> rs_u) * n_waves_u) << rs_u);
         const uint32_t blk = b_run < n_blocks_u ? b_run : n_blocks_u - 1u;
-        const uint8_t *p = rows_b + (size_t)blk * 16u * M;  // (SLICED: `rows4` is the slice's own [rows][M] array)
+        const uint8_t *p = rows_b + (size_t)blk * 16u * MROW;  // (SLICED: `rows4` is the slice's own [rows][M] array)
+        if (PAD) {
+            h.wide[0] = ld_nt(reinterpret_cast<const uint4 *>(p) + lane);
+            h.wide[kWide > 1 ? 1 : 0] = ld_nt(reinterpret_cast<const uint4 *>(p) + pad_p1);
+        } else {
 #pragma unroll
-        for (int i = 0; i < kWide; i++) h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
+            for (int i = 0; i < kWide; i++) h.wide[i] = ld_nt(reinterpret_cast<const uint4 *>(p + 1024 * i) + lane);
+        }
         if (kHalf) {
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p + 1024u * kWide + 8u * lane));
@@ -466,6 +486,11 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     };
     auto refill = [&](const Held &h, uint32_t slot) {
         uint8_t *d = lds_raw + stage + slot * kSlot;
+        if (PAD) {
+            *reinterpret_cast<uint4 *>(d + pad_a0) = h.wide[0];
+            *reinterpret_cast<uint4 *>(d + pad_a1) = h.wide[kWide > 1 ? 1 : 0];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kWide; i++) *reinterpret_cast<uint4 *>(d + 1024u * i + 16u * lane) = h.wide[i];
         if (kHalf) *reinterpret_cast<uint2 *>(d + 1024u * kWide + 8u * lane) = h.half;
@@ -1334,13 +1359,13 @@ bool skew_enabled() {
     return !g_skew_unusable.load(std::memory_order_relaxed);
 }
 // Opt in to the instance's dynamic LDS (up to the CU's whole 160 KiB) once per device; false: not available here.
-template <int NV, int R, bool FILTER, bool SLICED> bool skew_ready() {
+template <int NV, int R, bool FILTER, bool SLICED, int PAD = 0> bool skew_ready() {
     static DeviceOnce once;
     const qamd_status st = once.run([] {
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED, false>),
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED, false, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) == hipSuccess;
         if constexpr (R == 1 && !FILTER)  // the instance with the coalesced score store
-            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED, true>),
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_scan_skew_kernel<NV, R, FILTER, SLICED, true, PAD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)skew_lds_bytes(16 * NV)) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
@@ -1375,7 +1400,12 @@ uint32_t skew_rows_per_ring_row(const qamd_pq *h) {
     if (h->m % 32 == 0 && h->m <= 128) return 1;
     return (h->m == 48 || h->m == 16) ? 2 : 0;
 }
-bool skew_capable(const qamd_pq *h) { return skew_rows_per_ring_row(h) != 0; }
+// rows one 16-chunk piece short of a ring row (m = 80 -> 96, 112 -> 128): the missing chunks get table columns of +0.0
+uint32_t skew_pad(const qamd_pq *h) {
+    if (!skew_enabled() || h->ds != h->m || h->count >= (1ull << 30)) return 0;
+    return (h->m == 80 || h->m == 112) ? 16u : 0u;
+}
+bool skew_capable(const qamd_pq *h) { return skew_rows_per_ring_row(h) != 0 || skew_pad(h) != 0; }
 
 template <bool FILTER>
 qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, const TopkFilter *filt,
@@ -1385,9 +1415,10 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     const uint32_t n_slices = (pieces + per - 1) / per;
     const uint64_t n = h->count;
     const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
-    const uint32_t ring_rows = skew_rows_per_ring_row(h);
-    if (ring_rows == 2 ? (m == 48 ? skew_ready<6, 2, FILTER, false>() : skew_ready<2, 2, FILTER, false>())
-                       : ring_rows == 1 && skew_ready_for<FILTER, false>(m / 16)) {
+    const uint32_t ring_rows = skew_rows_per_ring_row(h), pad = skew_pad(h);
+    if (pad ? (m == 80 ? skew_ready<6, 1, FILTER, false, 16>() : skew_ready<8, 1, FILTER, false, 16>())
+            : ring_rows == 2 ? (m == 48 ? skew_ready<6, 2, FILTER, false>() : skew_ready<2, 2, FILTER, false>())
+                             : ring_rows == 1 && skew_ready_for<FILTER, false>(m / 16)) {
         // the LUT as [code][chunk]: encode_query leaves that copy behind the chunk-major one; a caller without it pays a
         // transposing launch (96 KiB, L2-resident)
         const float *lut_t = lut_t_dev;
@@ -1397,23 +1428,26 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             hipLaunchKernelGGL(pq_lut_transpose_kernel, dim3((m * kCentroids + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lut_dev, m, ws);
             lut_t = ws;
         }
-        const uint32_t run_shift = skew_run_shift(n, ring_rows, grid, ring_rows * m);
+        const uint32_t run_shift = skew_run_shift(n, pad ? 1 : ring_rows, grid, pad ? m + pad : ring_rows * m);
         SkewSlice whole{};
         whole.run_shift = run_shift;
-#define QAMD_PQ_SKEW_AS(NVV, RR, CO)                                                                          \
-    hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false, CO>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
+#define QAMD_PQ_SKEW_AS(NVV, RR, CO, PD)                                                                      \
+    hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false, CO, PD>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
                        skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev,         \
                        filt ? *filt : TopkFilter{}, whole)
-#define QAMD_PQ_SKEW(NVV, RR)                                                      \
+#define QAMD_PQ_SKEW_P(NVV, RR, PD)                                                \
     do {                                                                           \
         if constexpr (!FILTER && RR == 1) {                                        \
-            if (run_shift == 2) QAMD_PQ_SKEW_AS(NVV, RR, true);                    \
-            else QAMD_PQ_SKEW_AS(NVV, RR, false);                                  \
+            if (run_shift == 2) QAMD_PQ_SKEW_AS(NVV, RR, true, PD);                \
+            else QAMD_PQ_SKEW_AS(NVV, RR, false, PD);                              \
         } else {                                                                   \
-            QAMD_PQ_SKEW_AS(NVV, RR, false);                                       \
+            QAMD_PQ_SKEW_AS(NVV, RR, false, PD);                                   \
         }                                                                          \
     } while (0)
-        if (ring_rows == 2 && m == 48) QAMD_PQ_SKEW(6, 2);
+#define QAMD_PQ_SKEW(NVV, RR) QAMD_PQ_SKEW_P(NVV, RR, 0)
+        if (pad && m == 80) QAMD_PQ_SKEW_P(6, 1, 16);
+        else if (pad) QAMD_PQ_SKEW_P(8, 1, 16);
+        else if (ring_rows == 2 && m == 48) QAMD_PQ_SKEW(6, 2);
         else if (ring_rows == 2) QAMD_PQ_SKEW(2, 2);
         else switch (m / 16) {
             case 2: QAMD_PQ_SKEW(2, 1); break;
@@ -1422,6 +1456,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             case 8: QAMD_PQ_SKEW(8, 1); break;
         }
 #undef QAMD_PQ_SKEW_AS
+#undef QAMD_PQ_SKEW_P
 #undef QAMD_PQ_SKEW
         if (ws) thread_ws_release(WS_PARTIAL, s);
         QAMD_HIP(hipGetLastError());

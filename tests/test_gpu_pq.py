@@ -165,6 +165,10 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
                                        # m = 16: two store rows per 32-chunk ring row, a row end every four steps (the eight
                                        # lags span two store rows)
                                        (16, 8, 300_001), (16, 1, 4096), (16, 4, 4097), (16, 2, 70_003), (16, 8, 4127),
+                                       # m = 80 / 112: rows one 16-chunk piece short of a 96 / 128-chunk ring row; the missing chunks read
+                                       # table columns of +0.0 (ragged row counts, the run / coalesced-store path, dim not a multiple of the chunk)
+                                       (80, 8, 300_001), (80, 1, 4097), (80, 2, 70_003), (112, 2, 70_003), (112, 1, 4100), (112, 4, 33),
+                                       (80, 1, 1_100_003), (112, 1, 530_001),
                                        # rows of several LUT slices, scanned from the planar image (96 + 96, 128 + 32, 128 + 96,
                                        # 96 x 3, four of 128)
                                        (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (288, 2, 30_001), (512, 2, 20_011),
@@ -205,7 +209,7 @@ def test_pq_skewed_scan_shapes(qo, m, chunk, n):
 def test_pq_skewed_and_older_scan_kernels_give_the_same_bits():
     """The same stores scanned by pq_scan_skew_kernel (default) and by pq_scan_fast_kernel (QAMD_PQ_SKEW=0, a developer switch
     that only the tools/lib build reads - the product library ignores it): identical score bits and identical top-k for whole
-    rows (m = 16, 48, 64, 96, 128) and sliced rows (m = 192, 288)."""
+    rows (m = 16, 48, 64, 80, 96, 112, 128) and sliced rows (m = 192, 288)."""
     import hashlib
     import os
     import subprocess
@@ -219,7 +223,7 @@ import quantization_amd as qa
 D = qa.DistanceType
 h = hashlib.sha256()
 names = []
-for m, chunk, n in ((16, 8, 60001), (48, 4, 40001), (64, 2, 9000), (96, 8, 50001), (128, 4, 30007), (192, 4, 20011), (288, 1, 7001)):
+for m, chunk, n in ((16, 8, 60001), (48, 4, 40001), (64, 2, 9000), (80, 2, 45001), (96, 8, 50001), (112, 1, 33333), (128, 4, 30007), (192, 4, 20011), (288, 1, 7001)):
     rng = np.random.default_rng(m)
     dim = m * chunk
     cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)

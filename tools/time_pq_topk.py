@@ -1,6 +1,6 @@
 """PQ single-query top-k and score_all, ms per call with device outputs: config 2's shape (10M x 768, m = 96), config 4's PQ
 leg (12.5M x 1536, m = 192: two LUT slices of the planar scan image), m = 48 (dim 768 at chunk 16: two rows per ring row),
-m = 16 (two rows per 32-chunk ring row), m = 80 / 112 (row lengths the conflict-free kernel does not take) and the reference bench's m = 512.  With
+m = 16 (two rows per 32-chunk ring row), m = 80 / 112 (ring rows padded to 96 / 128 chunks with zero table columns) and the reference bench's m = 512.  With
 QAMD_LIB_PATH=tools/lib/libquantization_amd_dev.so, QAMD_PQ_SKEW=0 selects the older scan kernel for comparison."""
 import sys as _sys
 if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:
