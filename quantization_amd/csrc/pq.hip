@@ -372,7 +372,7 @@ struct SkewSlice {
 // score of the run's block k, and the run's 64 scores leave as one 256-byte nt store (COAL; 0.187 -> 0.176 ms) instead of
 // four 64-byte pieces that each only fill half a line.  Small stores keep single blocks (run_shift = 0) so that every wave
 // has work.
-// PAD > 0 (m = 80, 112: rows of M - PAD chunks): the ring rows are M bytes all the same, the row's PAD missing chunks get table
+// PAD > 0 (rows of M - PAD bytes: m = 80, 112, and every m % 4 == 0 whose 16-byte-padded row is 48, 80 or 112 bytes): the ring rows are M bytes all the same, the row's PAD missing chunks get table
 // columns of +0.0 - whatever byte lies in the ring's padding is a valid code, and a lane sum that starts at +0.0 never is -0.0,
 // so the padded steps leave every sum bit for bit what it was.  The padded steps are executed (96 for 80, 128 for 112), but
 // the kernel's time is its stream's (above), and that carries the row's own m bytes only.
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     static_assert(M % 32 == 0 && S >= 8, "shape");
     static_assert(M % R == 0 && MR % 4 == 0 && (SR >= 8 || (SR == 4 && R == 2)) && (R == 1 || !SLICED), "rows per ring row");
     static_assert(!COAL || (R == 1 && !FILTER && D == 4), "the coalesced score store: one store row per ring row, runs of D = 4 blocks");
-    static_assert(PAD == 0 || (PAD == 16 && R == 1 && !SLICED && M >= 96), "padded rows: one 16-chunk piece short of the ring row");
+    static_assert(PAD == 0 || (PAD == 16 && R == 1 && !SLICED && M >= 64), "padded rows: one 16-chunk piece short of the ring row");
     constexpr int MROW = M - PAD;  // bytes of a store row
     // SR = 4 (m = 16, two rows per 32-chunk ring row): the eight lags span TWO store rows - quads 1..4 finish a store row at
     // steps 0..3 (mod 4), quads 5..8 the store row before it at the same steps
@@ -399,10 +399,13 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         if (SLICED) {  // the slice's columns of the [code][m_total] table
             for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads)
                 dst[i] = *reinterpret_cast<const float4 *>(lut_t_g + (size_t)(i / (M / 4)) * sl.m_total + sl.chunk0 + 4u * (i % (M / 4)));
-        } else if (PAD) {  // [code][MROW] in memory; the ring row's last PAD columns: +0.0 for every code
+        } else if (R == 1 && (PAD || (sl.m_total && sl.m_total != (uint32_t)M))) {
+            // [code][m] in memory, m = sl.m_total chunks (a multiple of 4, <= MROW): the ring row's other columns - the PAD ones and
+            // those of the row's own padding to whole 16-byte pieces - are +0.0 for every code
+            const uint32_t m_real = sl.m_total ? sl.m_total : (uint32_t)MROW;
             for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads) {
                 const uint32_t code = i / (M / 4), c4 = i % (M / 4);
-                dst[i] = c4 < MROW / 4 ? *reinterpret_cast<const float4 *>(lut_t_g + (size_t)code * MROW + 4u * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[i] = 4u * c4 < m_real ? *reinterpret_cast<const float4 *>(lut_t_g + (size_t)code * m_real + 4u * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else if (R > 1) {  // [code][MR] in memory, every row of it R times in LDS
             for (uint32_t i = threadIdx.x; i < (uint32_t)M * (kCentroids / 4); i += kThreads)
@@ -453,8 +456,8 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     // writes piece p to ring row p / (MROW / 16), column p % (MROW / 16))
     constexpr int kWide = PAD ? 2 : 16 * M / 1024;             // rounds of 16 bytes per lane: 0 (M = 32), 1, 1, 2 (M = 128)
     constexpr bool kHalf = !PAD && (16 * M) % 1024 != 0;       // one more round of 8 bytes per lane (M = 32, 96)
-    const uint32_t pad_p1 = min(64u + lane, (uint32_t)MROW - 1u);
-    const uint32_t pad_a0 = (lane / (MROW / 16)) * M + (lane % (MROW / 16)) * 16u, pad_a1 = (pad_p1 / (MROW / 16)) * M + (pad_p1 % (MROW / 16)) * 16u;
+    const uint32_t pad_p0 = min(lane, (uint32_t)MROW - 1u), pad_p1 = min(64u + lane, (uint32_t)MROW - 1u);
+    const uint32_t pad_a0 = (pad_p0 / (MROW / 16)) * M + (pad_p0 % (MROW / 16)) * 16u, pad_a1 = (pad_p1 / (MROW / 16)) * M + (pad_p1 % (MROW / 16)) * 16u;
     struct Held {
         uint4 wide[kWide > 0 ? kWide : 1];
         uint2 half;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
         const uint32_t blk = b_run < n_blocks_u ? b_run : n_blocks_u - 1u;
         const uint8_t *p = rows_b + (size_t)blk * 16u * MROW;  // (SLICED: `rows4` is the slice's own [rows][M] array)
         if (PAD) {
-            h.wide[0] = ld_nt(reinterpret_cast<const uint4 *>(p) + lane);
+            h.wide[0] = ld_nt(reinterpret_cast<const uint4 *>(p) + pad_p0);
             h.wide[kWide > 1 ? 1 : 0] = ld_nt(reinterpret_cast<const uint4 *>(p) + pad_p1);
         } else {
 #pragma unroll
@@ -1400,10 +1403,22 @@ uint32_t skew_rows_per_ring_row(const qamd_pq *h) {
     if (h->m % 32 == 0 && h->m <= 128) return 1;
     return (h->m == 48 || h->m == 16) ? 2 : 0;
 }
-// rows one 16-chunk piece short of a ring row (m = 80 -> 96, 112 -> 128): the missing chunks get table columns of +0.0
-uint32_t skew_pad(const qamd_pq *h) {
-    if (!skew_enabled() || h->ds != h->m || h->count >= (1ull << 30)) return 0;
-    return (h->m == 80 || h->m == 112) ? 16u : 0u;
+// Rows whose chunks do not fill a ring row of 32 / 64 / 96 / 128: m % 4 == 0 (no tail chunks: the lane sums are the reference's),
+// stored on their pitch of whole 16-byte pieces (ds = 32 .. 128); the ring row is the next multiple of 32 bytes (PAD = 0 or 16 more
+// than ds) and every table column past m is +0.0 - m = 80 -> 96, 112 -> 128, 120 (dim 960 at chunk 8) -> 128, 100 -> 112 -> 128 ...
+// 0: not such a shape (or one the kernel takes as it is); else the ring row's chunks, and *pad its bytes past ds.
+uint32_t skew_padded_ring(const qamd_pq *h, uint32_t *pad) {
+    *pad = 0;
+    if (!skew_enabled() || h->count >= (1ull << 30) || h->m % 4 != 0 || h->ds % 16 != 0 || h->ds < 32 || h->ds > 128) return 0;
+    if (h->ds != round_up(h->m, 16)) return 0;
+    const uint32_t ring = (uint32_t)round_up(h->ds, 32);
+    if (ring == h->m || h->m == 48 || h->m == 16) return 0;  // whole ring rows, or two store rows per ring row
+    *pad = ring - (uint32_t)h->ds;
+    return ring;
+}
+uint32_t skew_pad(const qamd_pq *h) {  // (the ring row's chunks; 0: not a padded shape)
+    uint32_t pad;
+    return skew_padded_ring(h, &pad);
 }
 bool skew_capable(const qamd_pq *h) { return skew_rows_per_ring_row(h) != 0 || skew_pad(h) != 0; }
 
@@ -1415,8 +1430,21 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
     const uint32_t n_slices = (pieces + per - 1) / per;
     const uint64_t n = h->count;
     const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
-    const uint32_t ring_rows = skew_rows_per_ring_row(h), pad = skew_pad(h);
-    if (pad ? (m == 80 ? skew_ready<6, 1, FILTER, false, 16>() : skew_ready<8, 1, FILTER, false, 16>())
+    uint32_t pad_bytes = 0;
+    const uint32_t ring_rows = skew_rows_per_ring_row(h), pad = skew_padded_ring(h, &pad_bytes);  // pad: the padded ring row's chunks
+    auto padded_ready = [&]() {
+        switch (pad / 16 * 100 + pad_bytes) {
+            case 200: return skew_ready<2, 1, FILTER, false, 0>();
+            case 400: return skew_ready<4, 1, FILTER, false, 0>();
+            case 416: return skew_ready<4, 1, FILTER, false, 16>();
+            case 600: return skew_ready<6, 1, FILTER, false, 0>();
+            case 616: return skew_ready<6, 1, FILTER, false, 16>();
+            case 800: return skew_ready<8, 1, FILTER, false, 0>();
+            case 816: return skew_ready<8, 1, FILTER, false, 16>();
+        }
+        return false;
+    };
+    if (pad ? padded_ready()
             : ring_rows == 2 ? (m == 48 ? skew_ready<6, 2, FILTER, false>() : skew_ready<2, 2, FILTER, false>())
                              : ring_rows == 1 && skew_ready_for<FILTER, false>(m / 16)) {
         // the LUT as [code][chunk]: encode_query leaves that copy behind the chunk-major one; a caller without it pays a
@@ -1428,9 +1456,10 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             hipLaunchKernelGGL(pq_lut_transpose_kernel, dim3((m * kCentroids + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lut_dev, m, ws);
             lut_t = ws;
         }
-        const uint32_t run_shift = skew_run_shift(n, pad ? 1 : ring_rows, grid, pad ? m + pad : ring_rows * m);
+        const uint32_t run_shift = skew_run_shift(n, pad ? 1 : ring_rows, grid, pad ? pad : ring_rows * m);
         SkewSlice whole{};
         whole.run_shift = run_shift;
+        if (pad) whole.m_total = m;  // (the table in memory is [code][m]; the kernel pads it with +0.0 columns)
 #define QAMD_PQ_SKEW_AS(NVV, RR, CO, PD)                                                                      \
     hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false, CO, PD>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
                        skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev,         \
@@ -1445,8 +1474,15 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         }                                                                          \
     } while (0)
 #define QAMD_PQ_SKEW(NVV, RR) QAMD_PQ_SKEW_P(NVV, RR, 0)
-        if (pad && m == 80) QAMD_PQ_SKEW_P(6, 1, 16);
-        else if (pad) QAMD_PQ_SKEW_P(8, 1, 16);
+        if (pad) switch (pad / 16 * 100 + pad_bytes) {
+            case 200: QAMD_PQ_SKEW_P(2, 1, 0); break;
+            case 400: QAMD_PQ_SKEW_P(4, 1, 0); break;
+            case 416: QAMD_PQ_SKEW_P(4, 1, 16); break;
+            case 600: QAMD_PQ_SKEW_P(6, 1, 0); break;
+            case 616: QAMD_PQ_SKEW_P(6, 1, 16); break;
+            case 800: QAMD_PQ_SKEW_P(8, 1, 0); break;
+            case 816: QAMD_PQ_SKEW_P(8, 1, 16); break;
+        }
         else if (ring_rows == 2 && m == 48) QAMD_PQ_SKEW(6, 2);
         else if (ring_rows == 2) QAMD_PQ_SKEW(2, 2);
         else switch (m / 16) {

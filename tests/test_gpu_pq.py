@@ -169,6 +169,10 @@ def test_pq_sliced_fast_scan_any_m(qo, dim, chunk):
                                        # table columns of +0.0 (ragged row counts, the run / coalesced-store path, dim not a multiple of the chunk)
                                        (80, 8, 300_001), (80, 1, 4097), (80, 2, 70_003), (112, 2, 70_003), (112, 1, 4100), (112, 4, 33),
                                        (80, 1, 1_100_003), (112, 1, 530_001),
+                                       # ... and every m % 4 == 0 below 128 the same way: rows on their pitch of whole 16-byte pieces, ring rows of
+                                       # the next 32, zero table columns past m (120 = dim 960 at chunk 8; 100 -> 112 -> 128; 88 -> 96; 36 -> 48 -> 64)
+                                       (120, 8, 300_001), (100, 2, 70_003), (88, 1, 4097), (72, 4, 50_001), (36, 2, 40_000), (52, 1, 4099),
+                                       (20, 4, 70_001), (124, 1, 1_100_003), (120, 1, 530_001), (68, 1, 33),
                                        # rows of several LUT slices, scanned from the planar image (96 + 96, 128 + 32, 128 + 96,
                                        # 96 x 3, four of 128)
                                        (192, 4, 100_003), (160, 1, 5000), (224, 1, 9001), (288, 2, 30_001), (512, 2, 20_011),

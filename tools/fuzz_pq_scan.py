@@ -21,7 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda", 0)
 bad = 0
 for case in range(cases):
-    m = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256, 288, 384, 512, 16, 48, 80, 112, 100, 144, 176]))
+    m = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256, 288, 384, 512, 16, 48, 80, 112, 100, 144, 176, 20, 36, 52, 72, 88, 120, 124, 65, 33]))
     chunk = int(rng.choice([1, 2, 4, 8]))
     # (from ~0.5M / 1M / 2M rows on - by waves per workgroup and rows per ring row - a wave takes runs of four blocks and the
     # plain score output leaves as 256-byte stores: the last choice)

@@ -1,6 +1,6 @@
 """PQ single-query top-k and score_all, ms per call with device outputs: config 2's shape (10M x 768, m = 96), config 4's PQ
 leg (12.5M x 1536, m = 192: two LUT slices of the planar scan image), m = 48 (dim 768 at chunk 16: two rows per ring row),
-m = 16 (two rows per 32-chunk ring row), m = 80 / 112 (ring rows padded to 96 / 128 chunks with zero table columns) and the reference bench's m = 512.  With
+m = 16 (two rows per 32-chunk ring row), m = 80 / 112 (ring rows padded to 96 / 128 chunks with zero table columns) the reference bench's m = 512, and m = 120 / 100 (dim 960 / 800 at chunk 8: rows padded to 128 / 112 bytes, zero table columns past m).  With
 QAMD_LIB_PATH=tools/lib/libquantization_amd_dev.so, QAMD_PQ_SKEW=0 selects the older scan kernel for comparison."""
 import sys as _sys
 if "--help" in _sys.argv[1:] or "-h" in _sys.argv[1:]:
@@ -14,7 +14,7 @@ import quantization_amd as qa
 D = qa.DistanceType
 dev = torch.device("cuda", 0)
 shapes = ((10_000_000, 768, 8), (12_500_000, 1536, 8), (20_000_000, 768, 16), (12_000_000, 640, 8), (8_000_000, 896, 8),
-          (20_000_000, 128, 8), (2_000_000, 1024, 2))
+          (20_000_000, 128, 8), (2_000_000, 1024, 2), (8_000_000, 960, 8), (10_000_000, 800, 8))
 only = [int(a) for a in _sys.argv[1:] if a.isdigit()]  # optional: the m values to run
 for n, dim, chunk in shapes:
     if only and dim // chunk not in only:
