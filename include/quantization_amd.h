@@ -382,7 +382,7 @@ QAMD_API qamd_status qamd_pq_encode(const float *data, qamd_mem data_mem,
 QAMD_API qamd_status qamd_pq_kmeans_info(const qamd_pq *h, uint32_t *iterations, uint32_t *empty_clusters);
 /* Which kernel the whole-store scan (score_all / topk; the caller loop of demos/src/ann_benchmark.rs:245-252 over
  * score_point, encoded_vectors_pq.rs:549-561) takes for THIS store, as a static string - "pq_scan_skew_kernel" (rows of
- * 32 / 48 / 64 / 96 / 128 chunks), "pq_scan_skew_kernel<SLICED>" (longer rows with m % 32 == 0: one launch per LUT slice of
+ * 16 .. 128 chunks with m % 4 == 0), "pq_scan_skew_kernel<SLICED>" (longer rows with m % 32 == 0: one launch per LUT slice of
  * the store's planar scan image), "pq_scan_fast_kernel" (other row lengths), "pq_scan_kernel" (fewer than 4096 rows) - and
  * in *n_launches how many launches one scan is.  For measurement harnesses: bench.py names the kernel it times and picks
  * its roofline bound from this instead of re-deriving the library's dispatch. */
