@@ -6,6 +6,8 @@ TAG=${1:-r04}; COMMIT=${2:-unknown}; shift 2 || true
 want() { [ $# -eq 0 ] && return 0; }
 sel="$*"
 run() { n=$1; if [ -z "$sel" ] || [[ " $sel " == *" $n "* ]]; then bash profiles/collect_config.sh "$TAG" "$COMMIT" "$@" || exit 1; fi; }
+# (line_only: the bench line alone - a PQ batch is the single scan's kernel once per query; its line quotes that scan's PMC profile x queries)
+line_only() { n=$1; shift 2; if [ -z "$sel" ] || [[ " $sel " == *" $n "* ]]; then python3 bench.py "$@" 2> gpurun_out/${TAG}_line_$n.err | tail -1 > gpurun_out/${TAG}_bench_line_$n.json || exit 1; fi; }
 #   name        key                 needle                         rows      row B  launches  score B -- bench args
 run u8          u8_scan             u8_scan_kernel                 10000000  772    1 4 --
 run u8l2        u8_scan             u8_scan_kernel                 10000000  772    1 4 -- --distance l2
@@ -26,3 +28,5 @@ run batch192    u8_batch192_768     u8_gemm_rk16_kernel           10000000  772 
 run batch384    u8_batch384_768     u8_gemm_rk16_kernel           10000000  772    1 0 -- --batch-queries 384 --k 30 --steps 10 --warmup 5
 run batch768    u8_batch768_768     u8_gemm_rk16_kernel           10000000  772    1 0 -- --batch-queries 768 --k 30 --steps 8 --warmup 3
 run batch256    u8_batch256_768     u8_gemm_qr16_kernel           10000000  772    1 0 -- --batch-queries 256 --k 30 --steps 10 --warmup 5
+line_only pq_batch64 -- --quantizer pq --batch-queries 64 --k 30 --steps 3 --warmup 1
+line_only pq_batch1024_1536 -- --quantizer pq --dim 1536 --rows 12500000 --batch-queries 1024 --k 30 --steps 2 --warmup 1

@@ -116,6 +116,20 @@ def test_bench_batched_topk_mode(ranks):
         assert cb["batch_topk_of_that_query_matches"] is True
 
 
+def test_bench_pq_batched_mode():
+    """--quantizer pq --batch-queries: BASELINE config 4's PQ leg in small - the per-query pipelines back to back, priced against the code
+    bytes every query streams; one query of the batch checked against the oracle's caller loop."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--quantizer", "pq", "--steps", "1", "--warmup", "1", "--rows", "300000", "--dim",
+           "192", "--batch-queries", "8", "--k", "10"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, QAMD_BENCH_PREWARM_S="0.02"))
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    j = _last_json(res.stdout)
+    assert j["unit"] == "pairs/s" and j["value"] > 0 and j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["roofline"]["algorithmic_read_bytes_per_step"] == 8 * 300000 * 24
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["gpu_matches_cpu_bits"] is True and cb["batch_topk_of_that_query_matches"] is True
+
+
 def test_bench_starts_its_own_ranks_without_torchrun():
     """`python bench.py --gpus 2` with no rank environment: the parent (which never touches the GPU) starts the
     two ranks as a child torch.distributed.run, relays rank 0's line and exits with the child's code.  The line
