@@ -350,6 +350,16 @@ constexpr size_t skew_lds_bytes(uint32_t m) { return (size_t)skew_waves(m) * 32u
 // whose rows ARE that slice (round 3 read them out of row-major rows on a 256-byte pitch: 1.33 x the bytes at m = 192).
 // `rows4` is the slice's array.  A lane's sum for a row starts from partial[row][k] instead of 0 (unless first) and goes
 // back there (unless last): the reference's SSE lane sum (:405-440), its order unchanged, parked between two launches.
+// Several queries of a batch side by side (the filter pass of topk_batch): workgroup b sits on XCD b % 8, its slot b / 8 there
+// gives query slot % n and row stream slot / n; the n workgroups of a stream - one per query, each with its own table in
+// LDS - walk the same rows in the same order, so the codes leave HBM once per n queries and the others find them in
+// that XCD's L2.  n <= 1: one query, every workgroup its own rows (the single-query scan).
+struct SkewBatch {
+    uint32_t n;              // queries in this launch (2, 4 or 8; 0 / 1: not a batch)
+    uint32_t lut_stride;     // floats between two queries' [code][chunk] tables
+    uint64_t partial_stride; // floats between two queries' lane-sum buffers (rows of several slices)
+    TopkFilterSlices fsl;    // the queries' filter states
+};
 struct SkewSlice {
     uint32_t chunk0, m_total;
     int first, last;
@@ -379,8 +389,18 @@ struct SkewSlice {
 template <int NV, int R, bool FILTER, bool SLICED, bool COAL, int PAD = 0>
 __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(const uint4 *__restrict__ rows4,
                                                                  const float *__restrict__ lut_t_g, uint32_t n_rows,
-                                                                 float *__restrict__ out, TopkFilter filt, SkewSlice sl) {
+                                                                 float *__restrict__ out, TopkFilter filt, SkewSlice sl, SkewBatch bt) {
     constexpr int M = 16 * NV, S = 4 * NV;
+    uint32_t wg = blockIdx.x, n_wg = gridDim.x;  // this workgroup's place among those that share the rows
+    if (bt.n > 1) {
+        const uint32_t slot = blockIdx.x / 8u, streams = (gridDim.x / 8u) / bt.n, qi = slot % bt.n, stream_local = slot / bt.n;
+        if (stream_local >= streams) return;
+        wg = (blockIdx.x % 8u) * streams + stream_local;
+        n_wg = 8u * streams;
+        lut_t_g += (size_t)qi * bt.lut_stride;
+        if (FILTER) filt = topk_filter_of(bt.fsl, qi);
+        if (SLICED) sl.partial += (size_t)qi * bt.partial_stride;
+    }
     constexpr int MR = M / R, SR = S / R;  // chunks / chunk groups of one store row
     constexpr int D = 4;  // blocks of codes in flight per wave (registers)
     static_assert(M % 32 == 0 && S >= 8, "shape");
@@ -418,8 +438,8 @@ __global__ __launch_bounds__(64 * skew_waves(16 * NV)) void pq_scan_skew_kernel(
     }
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = lane & 3, q = lane >> 2, r = 8u - (q & 7u);
-    const uint32_t gw = blockIdx.x * kWaves + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * kWaves;
+    const uint32_t gw = wg * kWaves + (threadIdx.x >> 6);
+    const uint32_t n_waves = n_wg * kWaves;
     const uint32_t n_blocks = ((n_rows + R - 1) / R + 15) / 16;  // blocks of 16 ring rows
     // this wave: the runs gw, gw + n_waves, ... of 1 << rs consecutive blocks; its j-th block is block_of(j)
     const uint32_t rs = COAL ? 2u : sl.run_shift, n_runs = (n_blocks + (1u << rs) - 1u) >> rs;
@@ -1422,14 +1442,21 @@ uint32_t skew_pad(const qamd_pq *h) {  // (the ring row's chunks; 0: not a padde
 }
 bool skew_capable(const qamd_pq *h) { return skew_rows_per_ring_row(h) != 0 || skew_pad(h) != 0; }
 
+// `many` (FILTER only): the launch serves many->n queries side by side (SkewBatch) - only the conflict-free kernel does that;
+// *many_done says whether it was launched that way (false: nothing was launched, the caller goes query by query).
 template <bool FILTER>
 qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, const TopkFilter *filt,
-                        hipStream_t s, const float *lut_t_dev) {
+                        hipStream_t s, const float *lut_t_dev, const SkewBatch *many = nullptr, bool *many_done = nullptr) {
     const uint32_t m = (uint32_t)h->m, pitch_pieces = (uint32_t)(h->ds / 16), pieces = (uint32_t)valid_pieces(m);
     const uint32_t per = pieces <= kMaxSlicePieces ? pieces : kSlicePiecesAligned;
     const uint32_t n_slices = (pieces + per - 1) / per;
     const uint64_t n = h->count;
-    const int grid = (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
+    SkewBatch batch{};
+    if (many) batch = *many;
+    if (many_done) *many_done = false;
+    // (side by side: all 256 CUs, eight XCDs of 32 - the slot / stream map of the kernel)
+    const int grid = many ? 256 : (int)std::min<uint64_t>(device_info().cu_count, (n + 1023) / 1024);
+    const int grid_rows = many ? 256 / (int)many->n : grid;  // workgroups that share the rows among themselves
     uint32_t pad_bytes = 0;
     const uint32_t ring_rows = skew_rows_per_ring_row(h), pad = skew_padded_ring(h, &pad_bytes);  // pad: the padded ring row's chunks
     auto padded_ready = [&]() {
@@ -1451,19 +1478,20 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         // transposing launch (96 KiB, L2-resident)
         const float *lut_t = lut_t_dev;
         float *ws = nullptr;
+        if (!lut_t && many) return QAMD_OK;  // (a side-by-side launch needs the batch's [code][chunk] tables)
         if (!lut_t) {
             QAMD_TRY(thread_ws_acquire(WS_PARTIAL, (size_t)m * kCentroids * sizeof(float), s, reinterpret_cast<void **>(&ws)));
             hipLaunchKernelGGL(pq_lut_transpose_kernel, dim3((m * kCentroids + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lut_dev, m, ws);
             lut_t = ws;
         }
-        const uint32_t run_shift = skew_run_shift(n, pad ? 1 : ring_rows, grid, pad ? pad : ring_rows * m);
+        const uint32_t run_shift = skew_run_shift(n, pad ? 1 : ring_rows, grid_rows, pad ? pad : ring_rows * m);
         SkewSlice whole{};
         whole.run_shift = run_shift;
         if (pad) whole.m_total = m;  // (the table in memory is [code][m]; the kernel pads it with +0.0 columns)
 #define QAMD_PQ_SKEW_AS(NVV, RR, CO, PD)                                                                      \
     hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, RR, FILTER, false, CO, PD>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
                        skew_lds_bytes(16 * NVV), s, h->rows.as<uint4>(), lut_t, (uint32_t)n, out_dev,         \
-                       filt ? *filt : TopkFilter{}, whole)
+                       filt ? *filt : TopkFilter{}, whole, batch)
 #define QAMD_PQ_SKEW_P(NVV, RR, PD)                                                \
     do {                                                                           \
         if constexpr (!FILTER && RR == 1) {                                        \
@@ -1496,6 +1524,7 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
 #undef QAMD_PQ_SKEW
         if (ws) thread_ws_release(WS_PARTIAL, s);
         QAMD_HIP(hipGetLastError());
+        if (many_done) *many_done = true;
         return QAMD_OK;
     }
     if (lut_t_dev && skew_sliced_capable(h)) {  // rows of several LUT slices: one launch per slice of the planar scan image
@@ -1503,17 +1532,18 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
         for (uint32_t c : h->slice_chunks) ready = ready && skew_ready_for<FILTER, true>(c / 16);
         if (ready) {
             float *partial = nullptr;
-            QAMD_TRY(thread_ws_acquire(WS_PARTIAL, h->padded * 16, s, reinterpret_cast<void **>(&partial)));
+            QAMD_TRY(thread_ws_acquire(WS_PARTIAL, h->padded * 16 * (many ? many->n : 1), s, reinterpret_cast<void **>(&partial)));
+            batch.partial_stride = h->padded * 4;  // (floats: every query of a side-by-side launch has its own lane sums)
             const size_t ns = h->slice_chunks.size();
             for (size_t sl = 0; sl < ns; sl++) {
-                const uint32_t run_shift = skew_run_shift(n, 1, grid, h->slice_chunks[sl]);
+                const uint32_t run_shift = skew_run_shift(n, 1, grid_rows, h->slice_chunks[sl]);
                 const SkewSlice ss{h->slice_chunk0[sl], m, sl == 0, sl + 1 == ns, partial, run_shift};
                 const uint4 *slice = reinterpret_cast<const uint4 *>(h->planar.as<uint8_t>() + (uint64_t)h->slice_chunk0[sl] * h->padded);
                 const bool coal = !FILTER && run_shift == 2 && sl + 1 == ns;  // the last slice writes the scores
 #define QAMD_PQ_SKEW_SLICE_AS(NVV, CO)                                                                       \
         hipLaunchKernelGGL((pq_scan_skew_kernel<NVV, 1, FILTER, true, CO>), dim3(grid), dim3(64 * skew_waves(16 * NVV)), \
                            skew_lds_bytes(16 * NVV), s, slice, lut_t_dev, (uint32_t)n, out_dev,              \
-                           filt ? *filt : TopkFilter{}, ss)
+                           filt ? *filt : TopkFilter{}, ss, batch)
 #define QAMD_PQ_SKEW_SLICE(NVV)                                                                              \
     case NVV:                                                                                               \
         if constexpr (!FILTER) {                                                                            \
@@ -1529,9 +1559,11 @@ qamd_status launch_fast(const qamd_pq *h, const float *lut_dev, float *out_dev, 
             }
             thread_ws_release(WS_PARTIAL, s);
             QAMD_HIP(hipGetLastError());
+            if (many_done) *many_done = true;
             return QAMD_OK;
         }
     }
+    if (many) return QAMD_OK;  // (the older kernels take one query at a time: nothing launched)
     float *partial = nullptr;
     if (n_slices > 1) {
         const uint64_t padded = round_up(n, kRowPad) + kRowPad;
@@ -2602,6 +2634,25 @@ qamd_status qamd_pq_topk_batch(const qamd_pq *h, const qamd_pq_query_batch *b, u
     scan.topk_small = [&](uint32_t q, uint32_t *ids, float *sc, hipStream_t st, qamd_status &status) {
         return pq_topk_small(h, luts + q * per, k, largest, ids, sc, QAMD_MEM_DEVICE, st, status);
     };
+    // Four (two) queries' filter passes side by side: every query's table in the LDS of its own CUs, the rows shared through L2
+    // (SkewBatch).  Measured, ms per query of the whole batch step (bench.py --quantizer pq --batch-queries, profiles/r04_pq.txt):
+    //   10M x 768 (m = 96): query by query 0.223-0.229, two 0.2075, four 0.201-0.205, EIGHT 0.45 (all eight workgroups of a stream
+    //   ask the same L2 lines at the same time); 12.5M x 1536 (m = 192): 0.585, two 0.563, four 0.545.  Plain instead of nt loads: worse
+    //   everywhere (0.298 query by query).  Stores of a million rows and more (a quarter of the machine per query keeps its waves fed).
+    static const char *eside = dev_env("QAMD_PQ_SIDE");  // developer A/B: 0 = query by query; 2 / 4 / 8: at most so many side by side
+    if (b->transposed && fast_capable(h, h->count) && device_info().cu_count == 256 && h->count >= (1u << 20) && !(eside && eside[0] == '0'))
+        scan.scan_filter_multi = [&](uint32_t q, uint32_t avail, const TopkFilterSlices &fsl, hipStream_t st, qamd_status &status) -> uint32_t {
+            const uint32_t most = eside ? (uint32_t)atoi(eside) : 4u;
+            const uint32_t g = avail >= 8 && most >= 8 ? 8u : avail >= 4 && most >= 4 ? 4u : avail >= 2 && most >= 2 ? 2u : 0u;
+            if (g == 0) return 0;
+            SkewBatch many{};
+            many.n = g;
+            many.lut_stride = (uint32_t)per;
+            many.fsl = fsl;
+            bool done = false;
+            status = launch_fast<true>(h, nullptr, nullptr, nullptr, st, b->lut_t(q), &many, &done);
+            return status == QAMD_OK && done ? g : 0u;
+        };
     return fused_topk_batch(h->count, (uint32_t)b->n_queries, k, largest, out_ids, out_scores, out_mem, as_stream(stream),
                             scan);
 }

@@ -46,6 +46,37 @@ def test_pq_batch_equals_single_query_loop(n, m_dim, qo):
     assert np.array_equal(d_ids.cpu().numpy().view(np.uint32).reshape(Q, 30), ids)
 
 
+@pytest.mark.parametrize("m,chunk,n,nq", [
+    (96, 1, 1_100_003, 23),   # groups of 4 (five of them), 2 and one query alone; runs of four blocks per wave within a quarter of the machine
+    (192, 1, 1_050_011, 9),   # rows of two LUT slices: four queries' lane sums side by side in the carry buffer, twice, then one alone
+    (80, 1, 1_060_001, 8),    # padded ring rows
+    (48, 2, 1_200_002, 6),    # two rows per ring row: a group of 4 and one of 2
+    (100, 1, 1_048_579, 4),   # rows on a 112-byte pitch, zero table columns past m
+])
+def test_pq_batch_filter_passes_side_by_side(m, chunk, n, nq, qo):
+    """topk_batch on a PQ store of a million rows and more: the filter passes of 4 / 2 queries run in ONE launch, every query's table
+    in the LDS of its own CUs and the rows shared through L2 (SkewBatch) - ids and score bits of every query must be the single-query
+    top-k's (whose scan is pinned to the oracle by tests/test_gpu_pq.py), both directions; one query also against the oracle's scores."""
+    dim = m * chunk
+    rng = np.random.default_rng(m * 7 + nq)
+    cen = (rng.random((256, dim), dtype=np.float32) - 0.5).astype(np.float32)
+    rows = rng.integers(0, 256, size=(n, m), dtype=np.uint8)
+    queries = (rng.random((nq, dim), dtype=np.float32) - 0.5).astype(np.float32)
+    for dist, invert, largest in ((D.Dot, False, True), (D.L2, True, False)):
+        enc = qa.EncodedVectorsPQ.from_storage(rows, qa.VectorParameters(dim, n, dist, invert), chunk, cen)
+        ids, sc = enc.topk_batch(enc.encode_query_batch(queries), 30, largest=largest)
+        qobj = None
+        for qi in range(nq):
+            qobj = enc.encode_query(queries[qi], reuse=qobj)
+            wi, ws = enc.topk(qobj, 30, largest=largest)
+            assert np.array_equal(ids[qi], wi), (m, qi)
+            assert np.array_equal(sc[qi].view(np.uint32), ws.view(np.uint32)), (m, qi)
+        lut = qo.pq_encode_query(queries[nq - 1], chunk, cen, int(dist), invert)
+        want = qo.pq_score_all(rows, lut, order=qo.ORDER_SSE)
+        order = np.lexsort((np.arange(n), -want if largest else want))[:30]
+        assert np.array_equal(sc[nq - 1].view(np.uint32), want[order].view(np.uint32)), "vs oracle"
+
+
 @pytest.mark.parametrize("dim,n", [(1024, 200_000), (2048, 60_000), (4096, 40_000), (8192, 20_000), (256, 50_000), (65, 5000)])
 def test_binary_batch_equals_single_query_loop(dim, n, qo):
     rng = np.random.default_rng(dim)
