@@ -564,6 +564,8 @@ def main():
     if args.batch_queries > 0:
         # (u8 and binary: the matrix-core multi-query kernels; pq: one table fills the LDS, a batch is the per-query pipelines enqueued
         # back to back - BASELINE config 4's PQ leg, 1024 queries per step)
+        if not 1 <= args.k <= 1024:
+            raise SystemExit("--batch-queries: --k must be 1 .. 1024 (the library's limit for one top-k call)")
         from quantization_amd.sharded import ShardedTopKBatch
         Q, k = args.batch_queries, args.k
         bq = torch.rand((Q, dim), generator=qgen, device=dev, dtype=torch.float32)

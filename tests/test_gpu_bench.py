@@ -145,7 +145,7 @@ def test_bench_starts_its_own_ranks_without_torchrun():
     assert cfg["dist_backend"] == "gloo" and cfg["world_size_seen"] == 2 and len(cfg["rank_devices"]) == 2
     assert cfg["exchange"] == "scores" and "auto" in cfg["exchange_reason"]
     # a failing rank must fail the launcher too
-    bad = subprocess.run(cmd + ["--quantizer", "pq", "--batch-queries", "8"], capture_output=True, text=True, timeout=600,
+    bad = subprocess.run(cmd + ["--batch-queries", "8", "--k", "5000"], capture_output=True, text=True, timeout=600,
                          cwd=ROOT, env=env)
     assert bad.returncode != 0
 
